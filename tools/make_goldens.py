@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE ITSELF (imported, unmodified,
+from /root/reference/augmented_cyclegan) on CPU with torch.  Test infrastructure:
+runs only in the build container (the reference does not travel to the GPU box);
+the fixtures it writes are data (inputs + expected outputs), never reference source.
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/make_goldens.py
+
+Parameters come from oracle/recipe.py (regenerated from seeds on every box), so the
+fixtures hold only inputs, outputs, gradients and digests.
+"""
+import json
+import os
+import sys
+import warnings
+from collections import OrderedDict
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+REF = "/root/reference/augmented_cyclegan"
+sys.path.insert(0, REF)
+warnings.filterwarnings("ignore")
+
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+import networks as rnet  # noqa: E402  (reference)
+import modules as rmod  # noqa: E402  (reference)
+import model as rmodel  # noqa: E402  (reference)
+
+from oracle import recipe  # noqa: E402
+
+torch.set_num_threads(8)
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+META = dict(torch=torch.__version__, numpy=np.__version__, generator="tools/make_goldens.py",
+            reference="adrianalbert/domain-transfer-GAN @ /root/reference (imported unmodified)")
+
+
+def unique_named_parameters(net):
+    return OrderedDict(net.named_parameters())  # first name wins for aliased tensors
+
+
+def load_recipe(net, net_name, seed, flavour, double=False):
+    for k, p in unique_named_parameters(net).items():
+        v = recipe.param(seed, net_name, k, tuple(p.shape), flavour)
+        p.data.copy_(torch.from_numpy(v).to(p.dtype))
+    return net
+
+
+def with_blocks(gen, n_blocks, cin, ngf, nlatent=None):
+    """Re-compose a reference generator with `n_blocks` residual blocks using the reference's
+    own block classes (the constructor ignores n_blocks: networks.py:173,225 — SURVEY D3)."""
+    mods = list(gen.model.children())
+    stem, tail = mods[:10], mods[13:]
+    blocks = []
+    for _ in range(n_blocks):
+        if cin:
+            blocks.append(rmod.CINResnetBlock(x_dim=4 * ngf, z_dim=nlatent, padding_type="reflect",
+                                              norm_layer=rmod.CondInstanceNorm, use_dropout=False, use_bias=True))
+        else:
+            import functools
+            blocks.append(rmod.ResnetBlock(4 * ngf, padding_type="reflect",
+                                           norm_layer=functools.partial(rmod.InstanceNorm2d, affine=True),
+                                           use_dropout=False, use_bias=True))
+    seq = rmod.TwoInputSequential if cin else nn.Sequential
+    gen.model = seq(*(stem + blocks + tail))
+    return gen
+
+
+def grads_of(net):
+    return {("grad/" + k): (p.grad.detach().numpy().copy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32))
+            for k, p in unique_named_parameters(net).items()}
+
+
+def save(name, arrays, **meta):
+    m = dict(META); m.update(meta)
+    arrays = dict(arrays)
+    arrays["__meta__"] = np.frombuffer(json.dumps(m).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %-40s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024.0))
+
+
+def rnd(seed, shape):
+    return np.random.RandomState(seed).normal(0, 1, shape).astype(np.float32)
+
+
+# ---------------------------------------------------------------- network-level goldens
+def net_case(name, build, net_name, inputs, seed=0, flavour="rich", buffers=False, cfg=None):
+    net = load_recipe(build(), net_name, seed, flavour)
+    net.train()
+    tin = [torch.from_numpy(a.copy()).requires_grad_(True) for a in inputs]
+    out = net.forward(*tin)
+    outs = list(out) if isinstance(out, tuple) else [out]
+    Rs = [rnd(seed + 900 + i, tuple(o.shape)) for i, o in enumerate(outs)]
+    loss = sum((o * torch.from_numpy(R)).sum() for o, R in zip(outs, Rs))
+    loss.backward()
+    arr = {}
+    for i, a in enumerate(inputs):
+        arr["in%d" % i] = a
+        arr["gin%d" % i] = tin[i].grad.numpy().copy()
+    for i, (o, R) in enumerate(zip(outs, Rs)):
+        arr["out%d" % i] = o.detach().numpy().copy()
+        arr["R%d" % i] = R
+    arr.update(grads_of(net))
+    if buffers:
+        for k, b in net.named_buffers():
+            arr["buf/" + k] = b.detach().numpy().copy()
+    save(name, arr, kind="net", net=net_name, seed=seed, flavour=flavour, cfg=cfg or {})
+
+
+def make_net_goldens():
+    ngf, nl, nc = 8, 4, 3
+    x16 = np.random.RandomState(11).uniform(-1, 1, (2, nc, 16, 16)).astype(np.float32)
+    x32 = np.random.RandomState(12).uniform(-1, 1, (2, 1, 32, 32)).astype(np.float32)
+    z2 = rnd(13, (2, nl, 1, 1))
+    net_case("G_B_A_s16_nb3", lambda: rnet.define_G(nc, nc, ngf), "netG_B_A", [x16],
+             cfg=dict(input_nc=nc, output_nc=nc, ngf=ngf, n_blocks=3))
+    net_case("G_B_A_s32_nc1_nb3", lambda: rnet.define_G(1, 1, ngf), "netG_B_A", [x32],
+             cfg=dict(input_nc=1, output_nc=1, ngf=ngf, n_blocks=3))
+    net_case("G_B_A_s16_nb6", lambda: with_blocks(rnet.define_G(nc, nc, ngf), 6, False, ngf), "netG_B_A", [x16],
+             cfg=dict(input_nc=nc, output_nc=nc, ngf=ngf, n_blocks=6))
+    net_case("G_A_B_s16_nb3", lambda: rnet.define_stochastic_G(nl, nc, nc, ngf), "netG_A_B", [x16, z2],
+             cfg=dict(nlatent=nl, input_nc=nc, output_nc=nc, ngf=ngf, n_blocks=3))
+    net_case("G_A_B_s32_nc1_nb3", lambda: rnet.define_stochastic_G(nl, 1, 1, ngf), "netG_A_B", [x32, z2],
+             cfg=dict(nlatent=nl, input_nc=1, output_nc=1, ngf=ngf, n_blocks=3))
+    net_case("G_A_B_s16_nb9", lambda: with_blocks(rnet.define_stochastic_G(nl, nc, nc, ngf), 9, True, ngf, nl),
+             "netG_A_B", [x16, z2], cfg=dict(nlatent=nl, input_nc=nc, output_nc=nc, ngf=ngf, n_blocks=9))
+    x64 = np.random.RandomState(14).uniform(-1, 1, (2, nc, 64, 64)).astype(np.float32)
+    x40 = np.random.RandomState(15).uniform(-1, 1, (2, nc, 40, 40)).astype(np.float32)
+    net_case("D_B_s40", lambda: rnet.define_D_B(nc, 8, "basic", "instance"), "netD_B", [x40],
+             cfg=dict(input_nc=nc, ndf=8))
+    net_case("D_A_s64", lambda: rnet.define_D_A(nc, 8, "basic", "instance"), "netD_A", [x64],
+             cfg=dict(input_nc=nc, ndf=8))
+    x64e = np.random.RandomState(16).uniform(-1, 1, (3, 2 * nc, 64, 64)).astype(np.float32)
+    net_case("E_B_s64", lambda: rnet.define_E(nl, 2 * nc, 8, "batch"), "netE_B", [x64e], buffers=True,
+             cfg=dict(nlatent=nl, input_nc=2 * nc, nef=8))
+    z4 = rnd(17, (4, nl, 1, 1))
+    net_case("D_z_B_n4", lambda: rnet.define_LAT_D(nl, 8), "netD_z_B", [z4], buffers=True,
+             cfg=dict(nlatent=nl, ndf=8))
+
+
+# ---------------------------------------------------------------- step-level goldens
+class Namespace(object):
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def ref_opt(**kw):
+    d = dict(input_nc=3, output_nc=3, ngf=32, nef=32, ndf=64, nlatent=16, lr=2e-4, beta1=0.5, max_gnorm=500.0,
+             lambda_A=1.0, lambda_B=1.0, lambda_z_B=0.025, lambda_sup_A=0.1, lambda_sup_B=0.1,
+             stoch_enc=False, z_gan=1, enc_A_B=1, no_lsgan=False, norm="instance", use_dropout=False,
+             which_model_netG="resnet", which_model_netD="basic", gpu_ids=[], monitor_gnorm=True,
+             niter_decay=25, expr_dir="/tmp")
+    d.update(kw)
+    return Namespace(**d)
+
+
+def digest(a):
+    a = np.asarray(a, np.float64).ravel()
+    idx = (np.arange(8) * 2654435761 % max(a.size, 1)).astype(np.int64)
+    return np.concatenate([[a.sum(), np.abs(a).sum(), np.sqrt((a * a).sum())], a[idx]])
+
+
+class Recorder(object):
+    def __init__(self):
+        self.gan, self.l1, self.gn, self.predA, self.predB, self.enc = [], [], [], [], [], []
+
+
+def run_ref_step(m, rec, A, B, z, aug):
+    """Run the reference's train_instance; it completes ALL compute then raises IndexError at
+    its PyTorch-0.3 reporting line (`loss.data[0]`, model.py:518 / 193) — caught here."""
+    try:
+        m.train_instance(torch.from_numpy(A.copy()), torch.from_numpy(B.copy()), torch.from_numpy(z.copy()))
+        raise RuntimeError("reference unexpectedly returned")
+    except IndexError:
+        pass
+
+
+def step_case(name, aug, opt_kw, N, S, steps=2, seed=0, flavour="rich"):
+    opt = ref_opt(**opt_kw)
+    rec = Recorder()
+    # recorders around the reference's own loss / clip functions
+    orig_l1, orig_clip = rmodel.F.l1_loss, torch.nn.utils.clip_grad_norm
+    orig_crit = rmodel.criterion_GAN
+
+    def l1(a, b, *k, **kw):
+        v = orig_l1(a, b, *k, **kw); rec.l1.append(float(v)); return v
+
+    def crit(pred, real, use_sigmoid=True):
+        v = orig_crit(pred, real, use_sigmoid=use_sigmoid); rec.gan.append(float(v)); return v
+
+    def clip(params, max_norm, *k, **kw):
+        v = orig_clip(params, max_norm, *k, **kw); rec.gn.append(float(v)); return v
+
+    rmodel.F.l1_loss, rmodel.criterion_GAN, torch.nn.utils.clip_grad_norm = l1, crit, clip
+    try:
+        m = rmodel.AugmentedCycleGAN(opt, testing=True) if aug else rmodel.StochCycleGAN(opt, testing=True)
+    finally:
+        pass
+    names = ["netG_A_B", "netG_B_A", "netD_A", "netD_B"] + (["netE_B", "netD_z_B"] if aug else [])
+    for n in names:
+        load_recipe(getattr(m, n), n, seed, flavour)
+    pre = {n: {k: p.detach().numpy().copy() for k, p in unique_named_parameters(getattr(m, n)).items()} for n in names}
+
+    def wrap_forward(net, sink, fn):
+        f = net.forward
+
+        def g(*a):
+            o = f(*a); sink.append(fn(o)); return o
+        net.forward = g
+
+    wrap_forward(m.netD_A, rec.predA, lambda o: float(o.mean()))
+    wrap_forward(m.netD_B, rec.predB, lambda o: float(o.mean()))
+    if aug:
+        wrap_forward(m.netE_B, rec.enc, lambda o: (o[0].detach().numpy().copy(), o[1].detach().numpy().copy()))
+
+    arr = {}
+    try:
+        for st in range(steps):
+            A, B, z = recipe.inputs(seed + st, N, opt.input_nc, opt.output_nc, S, opt.nlatent)
+            arr["s%d/real_A" % st], arr["s%d/real_B" % st], arr["s%d/prior_z_B" % st] = A, B, z
+            # visuals: recompute pre-step with the same weights (harness-side, forward only)
+            with torch.no_grad():
+                tA, tB, tz = torch.from_numpy(A), torch.from_numpy(B), torch.from_numpy(z)
+                fake_B = m.netG_A_B.model(tA, tz); fake_A = m.netG_B_A.model(tB)
+                arr["s%d/fake_B" % st], arr["s%d/fake_A" % st] = fake_B.numpy().copy(), fake_A.numpy().copy()
+            for lst in (rec.gan, rec.l1, rec.gn, rec.predA, rec.predB, rec.enc):
+                del lst[:]
+            run_ref_step(m, rec, A, B, z, aug)
+            if aug:
+                # call order (model.py:423-464): D_A f/t, D_B f/t, D_z post/prior, G_A, G_B, G_z
+                g = rec.gan
+                mu = rec.enc[0][0]
+                losses = OrderedDict([("D_A", 0.5 * (g[0] + g[1])), ("G_A", g[6]), ("Cyc_A", rec.l1[0]),
+                                      ("Cyc_z_B", rec.l1[1]), ("KLD_z_B", float((0.5 * (mu.astype(np.float64) ** 2).sum(1)).mean())),
+                                      ("D_B", 0.5 * (g[2] + g[3])), ("G_B", g[7]), ("Cyc_B", rec.l1[2]),
+                                      ("D_z_B", 0.5 * (g[4] + g[5])),
+                                      ("P_t_A", rec.predA[1]), ("P_f_A", rec.predA[2]),
+                                      ("P_t_B", rec.predB[1]), ("P_f_B", rec.predB[2])])
+                # clip order model.py:447-449, 510-512
+                gn = OrderedDict([("gnorm_G_A_B", rec.gn[3]), ("gnorm_G_B_A", rec.gn[4]), ("gnorm_E_B", rec.gn[5]),
+                                  ("gnorm_D_B", rec.gn[1]), ("gnorm_D_z_B", rec.gn[2]), ("gnorm_D_A", rec.gn[0]),
+                                  ("mu_min", float(mu.min())), ("mu_max", float(mu.max())),
+                                  ("logvar_min", 0.0), ("logvar_max", 0.0)])
+                arr["s%d/mu_z_realB" % st] = mu
+            else:
+                g = rec.gan  # D_A f/t, D_B f/t, G_A, G_B (model.py:139-171)
+                losses = OrderedDict([("D_A", 0.5 * (g[0] + g[1])), ("G_A", g[4]), ("Cyc_A", rec.l1[0]),
+                                      ("D_B", 0.5 * (g[2] + g[3])), ("G_B", g[5]), ("Cyc_B", rec.l1[1]),
+                                      ("P_t_A", rec.predA[1]), ("P_f_A", rec.predA[2]),
+                                      ("P_t_B", rec.predB[1]), ("P_f_B", rec.predB[2])])
+                gn = OrderedDict([("gnorm_G_A_B", rec.gn[2]), ("gnorm_G_B_A", rec.gn[3]),
+                                  ("gnorm_D_B", rec.gn[1]), ("gnorm_D_A", rec.gn[0])])
+            arr["s%d/losses" % st] = np.array(list(losses.values()), np.float64)
+            arr["s%d/gnorms" % st] = np.array(list(gn.values()), np.float64)
+            loss_keys, gn_keys = list(losses.keys()), list(gn.keys())
+            # post-step update digests (post - pre), per tensor, and refresh `pre`
+            for n in names:
+                for k, p in unique_named_parameters(getattr(m, n)).items():
+                    post = p.detach().numpy()
+                    # .grad after the step: G nets = clipped G-phase grads; D nets = clipped D-phase grads
+                    # plus the (unused) G-phase accumulation on top (model.py:509 — no zero_grad for D there)
+                    arr["s%d/grad/%s/%s" % (st, n, k)] = digest(p.grad.detach().numpy() if p.grad is not None else np.zeros(tuple(p.shape)))
+                    arr["s%d/upd/%s/%s" % (st, n, k)] = digest(post.astype(np.float64) - pre[n][k].astype(np.float64))
+                    pre[n][k] = post.copy()
+        if aug:
+            for n in ("netE_B", "netD_z_B"):
+                for k, b in getattr(m, n).named_buffers():
+                    arr["final/buf/%s/%s" % (n, k)] = b.detach().numpy().copy()
+    finally:
+        rmodel.F.l1_loss, rmodel.criterion_GAN, torch.nn.utils.clip_grad_norm = orig_l1, orig_crit, orig_clip
+    save(name, arr, kind="step", aug=bool(aug), seed=seed, flavour=flavour, N=N, S=S, steps=steps,
+         opt={k: v for k, v in opt_kw.items()}, loss_keys=loss_keys, gnorm_keys=gn_keys)
+
+
+def make_step_goldens():
+    small = dict(input_nc=3, output_nc=3, ngf=8, nef=8, ndf=8, nlatent=4)
+    step_case("step_aug_small_s64", True, small, N=2, S=64, steps=2, flavour="rich")
+    step_case("step_aug_small_s64_init", True, small, N=3, S=64, steps=2, flavour="init")
+    step_case("step_stoch_small_s64", False, dict(small, input_nc=3, output_nc=1), N=2, S=64, steps=2, flavour="rich")
+    # BASELINE config 1 at full reference widths (64x64x1, batch 4, reference-faithful 3 blocks)
+    step_case("step_aug_cfg1_full", True, dict(input_nc=1, output_nc=1), N=4, S=64, steps=1, flavour="init")
+
+
+if __name__ == "__main__":
+    make_net_goldens()
+    make_step_goldens()
