@@ -1,0 +1,571 @@
+// Convolution entry points of the C ABI: geometry -> tap lists -> kernel launches, plus the
+// small support kernels (weight packing, reflection-pad fold, split-K reduction, bias gradient)
+// and the naive "direct" kernels kept as an on-device cross-check of the MFMA path.
+#include "conv_internal.h"
+
+int g_acg_conv_impl = ACG_IMPL_MFMA;
+extern "C" int acg_set_conv_impl(int impl)
+{
+    ACG_REQUIRE(impl == ACG_IMPL_MFMA || impl == ACG_IMPL_DIRECT, "acg_set_conv_impl: unknown impl %d", impl);
+    g_acg_conv_impl = impl;
+    return ACG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing: OIHW (real Or x Ir) -> wf [tap][Ci/8][CoP][8], wb [tap][Co/8][CiP][8]
+// ------------------------------------------------------------------------------------------
+__global__ void pack_weight_kernel(const float *__restrict__ w, int Or, int Ir, int K, int Ci, int Co, int CoP,
+                                   int CiP, float *__restrict__ wf, float *__restrict__ wb)
+{
+    const int KK = K * K;
+    const long long nf = (long long)KK * (Ci / 8) * CoP * 8;
+    const long long nb = (long long)KK * (Co / 8) * CiP * 8;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nf + nb;
+         i += (long long)gridDim.x * blockDim.x) {
+        if (i < nf) {
+            if (wf == nullptr) continue;
+            long long r = i;
+            const int c8 = (int)(r % 8); r /= 8;
+            const int co = (int)(r % CoP); r /= CoP;
+            const int cb = (int)(r % (Ci / 8)); r /= (Ci / 8);
+            const int tap = (int)r;
+            const int ci = cb * 8 + c8;
+            wf[i] = (co < Or && ci < Ir) ? w[((long long)co * Ir + ci) * KK + tap] : 0.f;
+        } else {
+            if (wb == nullptr) continue;
+            long long r = i - nf;
+            const int c8 = (int)(r % 8); r /= 8;
+            const int ci = (int)(r % CiP); r /= CiP;
+            const int cb = (int)(r % (Co / 8)); r /= (Co / 8);
+            const int tap = (int)r;
+            const int co = cb * 8 + c8;
+            wb[i - nf] = (co < Or && ci < Ir) ? w[((long long)co * Ir + ci) * KK + tap] : 0.f;
+        }
+    }
+}
+
+extern "C" size_t acg_packed_wf_elems(int K, int Ci, int Co) { return (size_t)K * K * (Ci / 8) * acg_ncols_pad(Co) * 8; }
+extern "C" size_t acg_packed_wb_elems(int K, int Ci, int Co) { return (size_t)K * K * (Co / 8) * acg_ncols_pad(Ci) * 8; }
+
+extern "C" int acg_pack_conv_weight(const float *w, int Or, int Ir, int K, int Ci, int Co, float *wf, float *wb,
+                                    void *stream)
+{
+    ACG_REQUIRE(Ci % 16 == 0 && Co % 16 == 0 && Or <= Co && Ir <= Ci && K >= 1 && K <= 7,
+                "acg_pack_conv_weight: bad dims Or=%d Ir=%d K=%d Ci=%d Co=%d", Or, Ir, K, Ci, Co);
+    const long long n = (long long)acg_packed_wf_elems(K, Ci, Co) + (long long)acg_packed_wb_elems(K, Ci, Co);
+    const int blocks = acg_cdiv(n, 256) > 2048 ? 2048 : acg_cdiv(n, 256);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Or, Ir, K, Ci, Co,
+                       acg_ncols_pad(Co), acg_ncols_pad(Ci), wf, wb);
+    ACG_CHECK_LAUNCH("pack_weight_kernel");
+    return ACG_OK;
+}
+
+__global__ void pad_vector_kernel(const float *__restrict__ s, int n, float *__restrict__ d, int np)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < np) d[i] = i < n ? s[i] : 0.f;
+}
+extern "C" int acg_pad_vector(const float *src, int n, float *dst, int np, void *stream)
+{
+    hipLaunchKernelGGL(pad_vector_kernel, dim3(acg_cdiv(np, 256)), dim3(256), 0, (hipStream_t)stream, src, n, dst, np);
+    ACG_CHECK_LAUNCH("pad_vector_kernel");
+    return ACG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// reflection-pad adjoint: dxp[N][H+2p][W+2p][C] -> dx[N][H][W][C], folding mirrored borders
+// (torch reflection_pad2d_backward).  float4 over channels.
+// ------------------------------------------------------------------------------------------
+__global__ void reflect_fold_kernel(const float *__restrict__ dxp, float *__restrict__ dx, int N, int H, int W, int C,
+                                    int p)
+{
+    const int C4 = C / 4;
+    const long long total = (long long)N * H * W * C4;
+    const int Hp = H + 2 * p, Wp = W + 2 * p;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long r = i;
+        const int c4 = (int)(r % C4); r /= C4;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H); r /= H;
+        const int n = (int)r;
+        // padded rows that read input row y: y+p, plus mirrors p-y (1<=y<=p) and 2(H-1)-y+p (H-1-p<=y<=H-2)
+        int ys[3], xs[3], ny = 0, nx = 0;
+        ys[ny++] = y + p;
+        if (y >= 1 && y <= p) ys[ny++] = p - y;
+        if (y >= H - 1 - p && y <= H - 2) ys[ny++] = 2 * (H - 1) - y + p;
+        xs[nx++] = x + p;
+        if (x >= 1 && x <= p) xs[nx++] = p - x;
+        if (x >= W - 1 - p && x <= W - 2) xs[nx++] = 2 * (W - 1) - x + p;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b)
+                acc += *(const f32x4 *)(dxp + (((long long)n * Hp + ys[a]) * Wp + xs[b]) * C + c4 * 4);
+        *(f32x4 *)(dx + i * 4) = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// column sums (bias gradient): dy[M][C] -> db[c] (first Cr columns), two deterministic stages
+// ------------------------------------------------------------------------------------------
+#define COLSUM_ROWS 2048
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ dy, long long M, int C,
+                                                             float *__restrict__ part)
+{
+    __shared__ float red[256 * 4];
+    const int C4 = C / 4;             // <= 256
+    const int lanes_per_row = C4;     // threads covering one row
+    const int rows_par = 256 / lanes_per_row;
+    const int c4 = threadIdx.x % lanes_per_row, rl = threadIdx.x / lanes_per_row;
+    const long long r0 = (long long)blockIdx.x * COLSUM_ROWS;
+    long long r1 = r0 + COLSUM_ROWS;
+    if (r1 > M) r1 = M;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (rl < rows_par)
+        for (long long r = r0 + rl; r < r1; r += rows_par) acc += *(const f32x4 *)(dy + r * C + c4 * 4);
+    *(f32x4 *)&red[threadIdx.x * 4] = acc;
+    __syncthreads();
+    if (threadIdx.x < lanes_per_row) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < rows_par; ++k) s += *(const f32x4 *)&red[(k * lanes_per_row + threadIdx.x) * 4];
+        *(f32x4 *)(part + (long long)blockIdx.x * C + threadIdx.x * 4) = s;
+    }
+}
+__global__ void colsum_final_kernel(const float *__restrict__ part, int nblk, int C, int Cr, float *__restrict__ db)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cr) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(long long)b * C + c];
+    db[c] = s;
+}
+static size_t colsum_ws_bytes(long long M, int C) { return (size_t)acg_cdiv(M, COLSUM_ROWS) * C * sizeof(float); }
+static int colsum_launch(const float *dy, long long M, int C, int Cr, float *db, float *ws, hipStream_t st)
+{
+    ACG_REQUIRE(C % 4 == 0 && C / 4 <= 256, "colsum: C=%d unsupported", C);
+    const int nblk = acg_cdiv(M, COLSUM_ROWS);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, st, dy, M, C, ws);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(acg_cdiv(Cr, 64)), dim3(64), 0, st, ws, nblk, C, Cr, db);
+    ACG_CHECK_LAUNCH("colsum");
+    return ACG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// split-K reduction of weight-gradient partials -> torch OIHW (real Or x Ir)
+// part[nsplit][KK][CiP][CoP]
+// ------------------------------------------------------------------------------------------
+__global__ void wgrad_reduce_kernel(const float *__restrict__ part, int nsplit, int KK, int CiP, int CoP, int Or,
+                                    int Ir, float *__restrict__ dw)
+{
+    const long long total = (long long)KK * Ir * Or;
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    long long r = i;
+    const int o = (int)(r % Or); r /= Or;
+    const int ci = (int)(r % Ir); r /= Ir;
+    const int tap = (int)r;
+    float s = 0.f;
+    const long long stride = (long long)KK * CiP * CoP;
+    const float *p = part + ((long long)tap * CiP + ci) * CoP + o;
+    for (int k = 0; k < nsplit; ++k) s += p[k * stride];
+    dw[((long long)o * Ir + ci) * KK + tap] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// naive direct kernels (cross-check path, ACG_IMPL_DIRECT): one thread per output element,
+// geometry taken straight from the descriptor (independent of the tap-list machinery).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect_idx(int i, int n)
+{
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * (n - 1) - i : i;
+}
+
+__global__ void direct_fwd_kernel(acg_conv_desc d, const float *__restrict__ x, const float *__restrict__ wf,
+                                  const float *__restrict__ bias, float *__restrict__ y, int act, int CoP)
+{
+    const long long total = (long long)d.N * d.Ho * d.Wo * d.Co;
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    long long r = i;
+    const int co = (int)(r % d.Co); r /= d.Co;
+    const int ox = (int)(r % d.Wo); r /= d.Wo;
+    const int oy = (int)(r % d.Ho); r /= d.Ho;
+    const int n = (int)r;
+    float acc = bias ? bias[co] : 0.f;
+    for (int kh = 0; kh < d.K; ++kh)
+        for (int kw = 0; kw < d.K; ++kw) {
+            int iy = oy * d.stride + kh - d.pad, ix = ox * d.stride + kw - d.pad;
+            if (d.pad_mode == ACG_PAD_REFLECT) {
+                iy = reflect_idx(iy, d.Hi);
+                ix = reflect_idx(ix, d.Wi);
+            } else if (iy < 0 || iy >= d.Hi || ix < 0 || ix >= d.Wi)
+                continue;
+            const float *xp = x + (((long long)n * d.Hi + iy) * d.Wi + ix) * d.Ci;
+            const int tap = kh * d.K + kw;
+            for (int ci = 0; ci < d.Ci; ++ci)
+                acc += xp[ci] * wf[(((long long)tap * (d.Ci / 8) + ci / 8) * CoP + co) * 8 + (ci & 7)];
+        }
+    y[i] = acg_apply_act(acc, act);
+}
+
+// dx[n,iy,ix,ci] = sum over padded preimages (py,px), taps, co.  Also used (with bias/act) as the
+// ConvTranspose2d forward.
+__global__ void direct_dgrad_kernel(acg_conv_desc d, const float *__restrict__ dy, const float *__restrict__ wb,
+                                    const float *__restrict__ bias, float *__restrict__ dx, int act, int CiP)
+{
+    const long long total = (long long)d.N * d.Hi * d.Wi * d.Ci;
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    long long r = i;
+    const int ci = (int)(r % d.Ci); r /= d.Ci;
+    const int ix = (int)(r % d.Wi); r /= d.Wi;
+    const int iy = (int)(r % d.Hi); r /= d.Hi;
+    const int n = (int)r;
+    const int p = d.pad;
+    int ys[3], xs[3], ny = 0, nx = 0;
+    ys[ny++] = iy + p;
+    xs[nx++] = ix + p;
+    if (d.pad_mode == ACG_PAD_REFLECT) {
+        if (iy >= 1 && iy <= p) ys[ny++] = p - iy;
+        if (iy >= d.Hi - 1 - p && iy <= d.Hi - 2) ys[ny++] = 2 * (d.Hi - 1) - iy + p;
+        if (ix >= 1 && ix <= p) xs[nx++] = p - ix;
+        if (ix >= d.Wi - 1 - p && ix <= d.Wi - 2) xs[nx++] = 2 * (d.Wi - 1) - ix + p;
+    }
+    float acc = bias ? bias[ci] : 0.f;
+    for (int a = 0; a < ny; ++a)
+        for (int b = 0; b < nx; ++b)
+            for (int kh = 0; kh < d.K; ++kh)
+                for (int kw = 0; kw < d.K; ++kw) {
+                    const int ty = ys[a] - kh, tx = xs[b] - kw;
+                    if (ty < 0 || tx < 0 || ty % d.stride || tx % d.stride) continue;
+                    const int oy = ty / d.stride, ox = tx / d.stride;
+                    if (oy >= d.Ho || ox >= d.Wo) continue;
+                    const float *gp = dy + (((long long)n * d.Ho + oy) * d.Wo + ox) * d.Co;
+                    const int tap = kh * d.K + kw;
+                    for (int co = 0; co < d.Co; ++co)
+                        acc += gp[co] * wb[(((long long)tap * (d.Co / 8) + co / 8) * CiP + ci) * 8 + (co & 7)];
+                }
+    dx[i] = acg_apply_act(acc, act);
+}
+
+// dw[o][i][kh][kw] (real Or x Ir), one thread per weight, serial over all pixels (tests only)
+__global__ void direct_wgrad_kernel(acg_conv_desc d, const float *__restrict__ x, const float *__restrict__ dy,
+                                    float *__restrict__ dw, int Or, int Ir)
+{
+    const int KK = d.K * d.K;
+    const long long total = (long long)Or * Ir * KK;
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    long long r = i;
+    const int tap = (int)(r % KK); r /= KK;
+    const int ci = (int)(r % Ir); r /= Ir;
+    const int co = (int)r;
+    const int kh = tap / d.K, kw = tap % d.K;
+    float acc = 0.f;
+    for (int n = 0; n < d.N; ++n)
+        for (int oy = 0; oy < d.Ho; ++oy)
+            for (int ox = 0; ox < d.Wo; ++ox) {
+                int iy = oy * d.stride + kh - d.pad, ix = ox * d.stride + kw - d.pad;
+                if (d.pad_mode == ACG_PAD_REFLECT) {
+                    iy = reflect_idx(iy, d.Hi);
+                    ix = reflect_idx(ix, d.Wi);
+                } else if (iy < 0 || iy >= d.Hi || ix < 0 || ix >= d.Wi)
+                    continue;
+                acc += x[(((long long)n * d.Hi + iy) * d.Wi + ix) * d.Ci + ci] *
+                       dy[(((long long)n * d.Ho + oy) * d.Wo + ox) * d.Co + co];
+            }
+    dw[i] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// descriptor checks + tap-list builders
+// ------------------------------------------------------------------------------------------
+static int check_desc(const acg_conv_desc *d, const char *who)
+{
+    ACG_REQUIRE(d != nullptr, "%s: null descriptor", who);
+    ACG_REQUIRE(d->N > 0 && d->Hi > 0 && d->Wi > 0 && d->Ho > 0 && d->Wo > 0, "%s: empty tensor", who);
+    ACG_REQUIRE(d->Ci % 16 == 0 && d->Co % 16 == 0 && d->Ci > 0 && d->Co > 0,
+                "%s: channels must be padded to 16 (Ci=%d Co=%d)", who, d->Ci, d->Co);
+    ACG_REQUIRE(d->K >= 1 && d->K <= 7 && (d->stride == 1 || d->stride == 2), "%s: K=%d stride=%d unsupported", who,
+                d->K, d->stride);
+    ACG_REQUIRE(d->pad >= 0 && d->pad < d->K, "%s: pad=%d", who, d->pad);
+    ACG_REQUIRE(d->Ho == (d->Hi + 2 * d->pad - d->K) / d->stride + 1 && d->Wo == (d->Wi + 2 * d->pad - d->K) / d->stride + 1,
+                "%s: output size %dx%d inconsistent with input %dx%d K=%d s=%d p=%d", who, d->Ho, d->Wo, d->Hi, d->Wi,
+                d->K, d->stride, d->pad);
+    if (d->pad_mode == ACG_PAD_REFLECT)
+        ACG_REQUIRE(d->stride == 1 && d->pad < d->Hi && d->pad < d->Wi, "%s: reflect pad needs stride 1 and pad < size", who);
+    return ACG_OK;
+}
+
+static void fwd_geom(const acg_conv_desc *d, Geom *g, Taps *t, int act)
+{
+    g->Hin = d->Hi; g->Win = d->Wi; g->Cin = d->Ci;
+    g->Hout = d->Ho; g->Wout = d->Wo; g->Cout = d->Co;
+    g->GH = d->Ho; g->GW = d->Wo; g->os = 1; g->oy0 = 0; g->ox0 = 0; g->is = d->stride;
+    g->reflect = d->pad_mode == ACG_PAD_REFLECT; g->act = act; g->ncols_pad = acg_ncols_pad(d->Co);
+    g->Mtot = (long long)d->N * d->Ho * d->Wo;
+    t->n = 0;
+    for (int kh = 0; kh < d->K; ++kh)
+        for (int kw = 0; kw < d->K; ++kw) {
+            t->dy[t->n] = (short)(kh - d->pad); t->dx[t->n] = (short)(kw - d->pad); t->w[t->n] = (short)(kh * d->K + kw);
+            t->n++;
+        }
+}
+
+// data gradient (and ConvTranspose forward): gathers from the conv-OUTPUT side tensor `src`
+// (N,Ho,Wo,Co) with packed wb, writes the conv-INPUT side tensor `dst` (N,Hi,Wi,Ci).
+static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb, const float *bias, float *dst,
+                       int act, void *ws, size_t ws_bytes, hipStream_t st)
+{
+    Geom g; Taps t;
+    g.Hin = d->Ho; g.Win = d->Wo; g.Cin = d->Co;
+    g.Cout = d->Ci; g.reflect = 0; g.act = act; g.ncols_pad = acg_ncols_pad(d->Ci); g.is = 1;
+    const int p = d->pad, K = d->K;
+    if (d->stride == 1) {
+        const bool refl = d->pad_mode == ACG_PAD_REFLECT && p > 0;
+        const int e = refl ? p : 0; // compute on the padded grid, then fold
+        float *out = dst;
+        if (refl) {
+            const size_t need = (size_t)d->N * (d->Hi + 2 * p) * (d->Wi + 2 * p) * d->Ci * sizeof(float);
+            if (ws == nullptr || ws_bytes < need) {
+                acg_set_error("acg_conv2d_bwd_data: workspace %zu < %zu", ws_bytes, need);
+                return ACG_ERR_WORKSPACE;
+            }
+            ACG_REQUIRE(bias == nullptr && act == ACG_ACT_NONE, "dgrad: reflect with epilogue unsupported");
+            out = (float *)ws;
+        }
+        g.Hout = d->Hi + 2 * e; g.Wout = d->Wi + 2 * e; g.GH = g.Hout; g.GW = g.Wout;
+        g.os = 1; g.oy0 = 0; g.ox0 = 0;
+        g.Mtot = (long long)d->N * g.GH * g.GW;
+        t.n = 0;
+        // zero pad: dy row = iy + p - kh ; reflect (padded grid): dy row = py - kh
+        const int base = refl ? 0 : p;
+        for (int kh = 0; kh < K; ++kh)
+            for (int kw = 0; kw < K; ++kw) {
+                t.dy[t.n] = (short)(base - kh); t.dx[t.n] = (short)(base - kw); t.w[t.n] = (short)(kh * K + kw);
+                t.n++;
+            }
+        int rc = acg_igemm_launch(src, wb, bias, out, g, t, st);
+        if (rc != ACG_OK) return rc;
+        if (refl) {
+            const long long total = (long long)d->N * d->Hi * d->Wi * (d->Ci / 4);
+            const int blocks = acg_cdiv(total, 256) > 4096 ? 4096 : acg_cdiv(total, 256);
+            hipLaunchKernelGGL(reflect_fold_kernel, dim3(blocks), dim3(256), 0, st, (const float *)ws, dst, d->N, d->Hi,
+                               d->Wi, d->Ci, p);
+            ACG_CHECK_LAUNCH("reflect_fold_kernel");
+        }
+        return ACG_OK;
+    }
+    // stride 2: four sub-pixel phases, each a dense small-tap convolution (no zero insertion)
+    ACG_REQUIRE(d->pad_mode == ACG_PAD_ZERO, "dgrad: stride 2 needs zero padding");
+    g.Hout = d->Hi; g.Wout = d->Wi; g.os = 2;
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            g.oy0 = py; g.ox0 = px;
+            g.GH = (d->Hi - py + 1) / 2; g.GW = (d->Wi - px + 1) / 2;
+            g.Mtot = (long long)d->N * g.GH * g.GW;
+            t.n = 0;
+            for (int kh = 0; kh < K; ++kh) {
+                if ((py + p - kh) & 1) continue;
+                for (int kw = 0; kw < K; ++kw) {
+                    if ((px + p - kw) & 1) continue;
+                    t.dy[t.n] = (short)((py + p - kh) / 2); t.dx[t.n] = (short)((px + p - kw) / 2);
+                    t.w[t.n] = (short)(kh * K + kw);
+                    t.n++;
+                }
+            }
+            ACG_REQUIRE(t.n > 0, "dgrad: empty phase (K=%d p=%d)", K, p);
+            int rc = acg_igemm_launch(src, wb, bias, dst, g, t, st);
+            if (rc != ACG_OK) return rc;
+        }
+    return ACG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" int acg_conv2d_fwd(const acg_conv_desc *d, const float *x, const float *wf, const float *bias, float *y,
+                              int act, void *stream)
+{
+    int rc = check_desc(d, "acg_conv2d_fwd");
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (g_acg_conv_impl == ACG_IMPL_DIRECT) {
+        const long long total = (long long)d->N * d->Ho * d->Wo * d->Co;
+        hipLaunchKernelGGL(direct_fwd_kernel, dim3(acg_cdiv(total, 256)), dim3(256), 0, st, *d, x, wf, bias, y, act,
+                           acg_ncols_pad(d->Co));
+        ACG_CHECK_LAUNCH("direct_fwd_kernel");
+        return ACG_OK;
+    }
+    Geom g; Taps t;
+    fwd_geom(d, &g, &t, act);
+    return acg_igemm_launch(x, wf, bias, y, g, t, st);
+}
+
+extern "C" size_t acg_conv2d_bwd_data_workspace_bytes(const acg_conv_desc *d)
+{
+    if (d == nullptr || d->pad_mode != ACG_PAD_REFLECT || d->pad == 0) return 0;
+    return (size_t)d->N * (d->Hi + 2 * d->pad) * (d->Wi + 2 * d->pad) * d->Ci * sizeof(float);
+}
+
+extern "C" int acg_conv2d_bwd_data(const acg_conv_desc *d, const float *dy, const float *wb, float *dx, void *ws,
+                                   size_t ws_bytes, void *stream)
+{
+    int rc = check_desc(d, "acg_conv2d_bwd_data");
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (g_acg_conv_impl == ACG_IMPL_DIRECT) {
+        const long long total = (long long)d->N * d->Hi * d->Wi * d->Ci;
+        hipLaunchKernelGGL(direct_dgrad_kernel, dim3(acg_cdiv(total, 256)), dim3(256), 0, st, *d, dy, wb,
+                           (const float *)nullptr, dx, (int)ACG_ACT_NONE, acg_ncols_pad(d->Ci));
+        ACG_CHECK_LAUNCH("direct_dgrad_kernel");
+        return ACG_OK;
+    }
+    return dgrad_igemm(d, dy, wb, nullptr, dx, ACG_ACT_NONE, ws, ws_bytes, st);
+}
+
+// split-K plan shared by the workspace query and the launch
+static void wgrad_plan(const acg_conv_desc *d, int Cx, int Cg, long long Mtot, int *CiP, int *CoP, int *nsplit,
+                       long long *mps)
+{
+    int bci, bco;
+    acg_wgrad_tiles(Cx, Cg, &bci, &bco);
+    *CiP = (Cx + bci - 1) / bci * bci;
+    *CoP = (Cg + bco - 1) / bco * bco;
+    const int KP = bci == 32 ? 128 : 32;
+    const long long base = (long long)d->K * d->K * (*CiP / bci) * (*CoP / bco);
+    long long ns = 1536 / base;
+    const long long cap = Mtot / (KP * 4);
+    if (ns > cap) ns = cap;
+    if (ns > 512) ns = 512;
+    if (ns < 1) ns = 1;
+    long long per = (Mtot + ns - 1) / ns;
+    per = (per + KP - 1) / KP * KP;
+    ns = (Mtot + per - 1) / per;
+    *nsplit = (int)ns;
+    *mps = per;
+}
+
+static size_t wgrad_ws_bytes(const acg_conv_desc *d, int Cx, int Cg, long long Mtot)
+{
+    int CiP, CoP, ns; long long mps;
+    wgrad_plan(d, Cx, Cg, Mtot, &CiP, &CoP, &ns, &mps);
+    const size_t part = (size_t)ns * d->K * d->K * CiP * CoP * sizeof(float);
+    const int Cmax = d->Ci > d->Co ? d->Ci : d->Co;
+    const long long Mbig = (long long)d->N * (d->Hi > d->Ho ? d->Hi : d->Ho) * (d->Wi > d->Wo ? d->Wi : d->Wo);
+    return acg_round_up(part, 256) + acg_round_up(colsum_ws_bytes(Mbig, Cmax), 256);
+}
+
+extern "C" size_t acg_conv2d_bwd_weight_workspace_bytes(const acg_conv_desc *d)
+{
+    if (d == nullptr) return 0;
+    // covers both orientations (Conv2d and ConvTranspose2d use of the same descriptor)
+    const size_t a = wgrad_ws_bytes(d, d->Ci, d->Co, (long long)d->N * d->Ho * d->Wo);
+    return a;
+}
+
+// x_side: conv-input-side tensor (N,Hi,Wi,Ci); g_side: conv-output-side tensor (N,Ho,Wo,Co)
+static int wgrad_common(const acg_conv_desc *d, const float *x_side, const float *g_side, float *dw, int Or, int Ir,
+                        void *ws, size_t ws_bytes, hipStream_t st)
+{
+    ACG_REQUIRE(Or <= d->Co && Ir <= d->Ci, "wgrad: Or=%d Ir=%d exceed padded dims", Or, Ir);
+    if (g_acg_conv_impl == ACG_IMPL_DIRECT) {
+        const long long total = (long long)Or * Ir * d->K * d->K;
+        hipLaunchKernelGGL(direct_wgrad_kernel, dim3(acg_cdiv(total, 64)), dim3(64), 0, st, *d, x_side, g_side, dw, Or, Ir);
+        ACG_CHECK_LAUNCH("direct_wgrad_kernel");
+        return ACG_OK;
+    }
+    WGeom g; Taps t; Geom gf;
+    fwd_geom(d, &gf, &t, 0);
+    g.Hin = d->Hi; g.Win = d->Wi; g.Cin = d->Ci; g.Hg = d->Ho; g.Wg = d->Wo; g.Cg = d->Co;
+    g.is = d->stride; g.reflect = d->pad_mode == ACG_PAD_REFLECT;
+    g.Mtot = (long long)d->N * d->Ho * d->Wo;
+    wgrad_plan(d, d->Ci, d->Co, g.Mtot, &g.CiP, &g.CoP, &g.nsplit, &g.m_per_split);
+    const size_t need = (size_t)g.nsplit * t.n * g.CiP * g.CoP * sizeof(float);
+    if (ws == nullptr || ws_bytes < need) {
+        acg_set_error("acg_conv2d_bwd_weight: workspace %zu < %zu", ws_bytes, need);
+        return ACG_ERR_WORKSPACE;
+    }
+    int rc = acg_wgrad_launch(x_side, g_side, (float *)ws, g, t, st);
+    if (rc) return rc;
+    const long long total = (long long)t.n * Ir * Or;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(acg_cdiv(total, 256)), dim3(256), 0, st, (const float *)ws, g.nsplit,
+                       t.n, g.CiP, g.CoP, Or, Ir, dw);
+    ACG_CHECK_LAUNCH("wgrad_reduce_kernel");
+    return ACG_OK;
+}
+
+static float *colsum_area(const acg_conv_desc *d, void *ws, size_t ws_bytes, size_t *avail)
+{
+    int CiP, CoP, ns; long long mps;
+    wgrad_plan(d, d->Ci, d->Co, (long long)d->N * d->Ho * d->Wo, &CiP, &CoP, &ns, &mps);
+    const size_t part = acg_round_up((size_t)ns * d->K * d->K * CiP * CoP * sizeof(float), 256);
+    *avail = ws_bytes > part ? ws_bytes - part : 0;
+    return (float *)((char *)ws + part);
+}
+
+extern "C" int acg_conv2d_bwd_weight(const acg_conv_desc *d, const float *x, const float *dy, float *dw, float *db,
+                                     int Or, int Ir, void *ws, size_t ws_bytes, void *stream)
+{
+    int rc = check_desc(d, "acg_conv2d_bwd_weight");
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    ACG_REQUIRE(ws != nullptr && ws_bytes >= acg_conv2d_bwd_weight_workspace_bytes(d), "acg_conv2d_bwd_weight: workspace too small");
+    if (dw != nullptr) {
+        rc = wgrad_common(d, x, dy, dw, Or, Ir, ws, ws_bytes, st);
+        if (rc) return rc;
+    }
+    if (db != nullptr) {
+        size_t avail; float *cw = colsum_area(d, ws, ws_bytes, &avail);
+        const long long M = (long long)d->N * d->Ho * d->Wo;
+        ACG_REQUIRE(avail >= colsum_ws_bytes(M, d->Co), "acg_conv2d_bwd_weight: colsum workspace");
+        rc = colsum_launch(dy, M, d->Co, Or, db, cw, st);
+    }
+    return rc;
+}
+
+extern "C" int acg_conv_transpose2d_fwd(const acg_conv_desc *d, const float *x, const float *wb, const float *bias,
+                                        float *y, int act, void *stream)
+{
+    int rc = check_desc(d, "acg_conv_transpose2d_fwd");
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (g_acg_conv_impl == ACG_IMPL_DIRECT) {
+        const long long total = (long long)d->N * d->Hi * d->Wi * d->Ci;
+        hipLaunchKernelGGL(direct_dgrad_kernel, dim3(acg_cdiv(total, 256)), dim3(256), 0, st, *d, x, wb, bias, y, act,
+                           acg_ncols_pad(d->Ci));
+        ACG_CHECK_LAUNCH("direct_dgrad_kernel");
+        return ACG_OK;
+    }
+    return dgrad_igemm(d, x, wb, bias, y, act, nullptr, 0, st);
+}
+
+extern "C" int acg_conv_transpose2d_bwd_data(const acg_conv_desc *d, const float *dy, const float *wf, float *dx,
+                                             void *stream)
+{
+    // adjoint of the adjoint: the plain forward convolution, no bias / activation
+    return acg_conv2d_fwd(d, dy, wf, nullptr, dx, ACG_ACT_NONE, stream);
+}
+
+extern "C" int acg_conv_transpose2d_bwd_weight(const acg_conv_desc *d, const float *x, const float *dy, float *dw,
+                                               float *db, int Or, int Ir, void *ws, size_t ws_bytes, void *stream)
+{
+    // underlying Conv2d: input side = ConvTranspose OUTPUT gradient dy (N,Hi,Wi,Ci), output side = x (N,Ho,Wo,Co);
+    // weight (Cin_T, Cout_T, k, k) == OIHW of that Conv2d.  Bias gradient sums dy over pixels (Cout_T = Ir).
+    int rc = check_desc(d, "acg_conv_transpose2d_bwd_weight");
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    ACG_REQUIRE(ws != nullptr && ws_bytes >= acg_conv2d_bwd_weight_workspace_bytes(d), "acg_conv_transpose2d_bwd_weight: workspace too small");
+    if (dw != nullptr) {
+        rc = wgrad_common(d, dy, x, dw, Or, Ir, ws, ws_bytes, st);
+        if (rc) return rc;
+    }
+    if (db != nullptr) {
+        size_t avail; float *cw = colsum_area(d, ws, ws_bytes, &avail);
+        const long long M = (long long)d->N * d->Hi * d->Wi;
+        ACG_REQUIRE(avail >= colsum_ws_bytes(M, d->Ci), "acg_conv_transpose2d_bwd_weight: colsum workspace");
+        rc = colsum_launch(dy, M, d->Ci, Ir, db, cw, st);
+    }
+    return rc;
+}

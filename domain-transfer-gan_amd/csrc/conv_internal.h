@@ -1,0 +1,41 @@
+// Internal geometry shared by the convolution kernels (not part of the C ABI).
+#pragma once
+#include "common.h"
+
+#define ACG_KC 16 // K-channels per implicit-GEMM stage
+
+struct Taps {
+    int n;
+    short dy[64];
+    short dx[64];
+    short w[64];
+};
+
+struct Geom {
+    int Hin, Win, Cin;    // gathered tensor (K-channels = Cin, multiple of 16)
+    int Hout, Wout, Cout; // written tensor; columns >= Cout are masked
+    int GH, GW;           // grid of output positions per image covered by this launch
+    int os, oy0, ox0;     // output pixel = (gy*os + oy0, gx*os + ox0)
+    int is;               // gathered pixel = (gy*is + dy[t], gx*is + dx[t])
+    int reflect;          // 1: mirror out-of-range coordinates (ReflectionPad2d), 0: zeros
+    int act;
+    int ncols_pad;        // packed-weight column count (multiple of the N tile)
+    long long Mtot;       // N*GH*GW
+};
+
+int acg_igemm_launch(const float *in, const float *wp, const float *bias, float *out, const Geom &g, const Taps &t,
+                     hipStream_t st);
+
+// weight-gradient implicit GEMM: dw_part[split][tap][CiP][CoP] partial sums over pixel ranges
+struct WGeom {
+    int Hin, Win, Cin;    // gathered (conv-input side) tensor
+    int Hg, Wg, Cg;       // gradient (conv-output side) tensor, one row per GEMM-K pixel
+    int is;               // gathered pixel = (gy*is + dy[t], gx*is + dx[t]) for gradient pixel (gy, gx)
+    int reflect;
+    int CiP, CoP;         // padded dims of the partial buffer
+    int nsplit;
+    long long Mtot;       // N*Hg*Wg
+    long long m_per_split;
+};
+int acg_wgrad_launch(const float *x, const float *dy, float *part, const WGeom &g, const Taps &t, hipStream_t st);
+void acg_wgrad_tiles(int Ci, int Co, int *bci, int *bco);

@@ -1,0 +1,169 @@
+// Weight-gradient implicit GEMM for gfx950 (v_mfma_f32_32x32x2_f32, exact fp32).
+//
+//   dW[tap][ci][co] = sum_m  x[pix(m, tap), ci] * dy[m, co]        (GEMM: M'=ci, N'=co, K'=pixels)
+//
+// NHWC makes both operands K-major rows ([pixel][channel]), which is exactly the natural LDS
+// image for the MFMA A/B fragments (lane l: A[ci = l&31][k = l>>5] -> consecutive lanes read
+// consecutive floats, conflict-free ds_read_b32).  The pixel reduction is split over the grid
+// (deterministic split-K): each block writes its partial tile, a second kernel sums the
+// partials in a fixed order and scatters into torch's OIHW layout — no float atomics, so
+// results are bitwise reproducible run to run.
+#include "conv_internal.h"
+
+template <int BCI, int BCO, int WI, int WJ, int WK, int KP>
+__global__ __launch_bounds__(256) void wgrad_f32(const float *__restrict__ x, const float *__restrict__ dy,
+                                                 float *__restrict__ part, WGeom g, Taps taps)
+{
+    constexpr int TI = BCI / WI, TJ = BCO / WJ, MI = TI / 32, MJ = TJ / 32;
+    constexpr int XCH = KP * BCI / 4, DCH = KP * BCO / 4;
+    constexpr int XL = XCH / 256, DL = DCH / 256;
+    constexpr int KW = KP / WK; // pixels of a stage handled by one wave
+    static_assert(WI * WJ * WK == 4 && XL >= 1 && DL >= 1 && MI >= 1 && MJ >= 1, "tile config");
+
+    __shared__ __attribute__((aligned(16))) float Xs[KP * BCI];
+    __shared__ __attribute__((aligned(16))) float Ds[KP * BCO];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave % WK, wj = (wave / WK) % WJ, wi = wave / (WK * WJ);
+
+    const int tiles_ci = g.CiP / BCI, tiles_co = g.CoP / BCO;
+    int b = blockIdx.x;
+    const int tco = b % tiles_co; b /= tiles_co;
+    const int tci = b % tiles_ci; b /= tiles_ci;
+    const int tap = b % taps.n;
+    const int split = b / taps.n;
+    const int ci0 = tci * BCI, co0 = tco * BCO;
+    const int ty = taps.dy[tap], tx = taps.dx[tap];
+    const long long mbeg = (long long)split * g.m_per_split;
+    long long mend = mbeg + g.m_per_split;
+    if (mend > g.Mtot) mend = g.Mtot;
+    const int GHW = g.Hg * g.Wg;
+
+    f32x16 acc[MI][MJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 rx[XL], rd[DL];
+    auto load_stage = [&](long long k0) {
+#pragma unroll
+        for (int j = 0; j < XL; ++j) {
+            const int idx = tid + 256 * j;
+            const int r = idx / (BCI / 4), c4 = idx - r * (BCI / 4);
+            const long long m = k0 + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const int ci = ci0 + c4 * 4;
+            if (m < mend && ci < g.Cin) {
+                const int n = (int)(m / GHW);
+                const int rr = (int)(m - (long long)n * GHW);
+                const int gy = rr / g.Wg, gx = rr - gy * g.Wg;
+                int iy = gy * g.is + ty, ix = gx * g.is + tx;
+                bool ok = true;
+                if (g.reflect) {
+                    iy = iy < 0 ? -iy : iy;
+                    iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
+                    ix = ix < 0 ? -ix : ix;
+                    ix = ix >= g.Win ? 2 * (g.Win - 1) - ix : ix;
+                } else {
+                    ok = iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win;
+                }
+                if (ok) v = *(const f32x4 *)(x + (((long long)n * g.Hin + iy) * g.Win + ix) * g.Cin + ci);
+            }
+            rx[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < DL; ++j) {
+            const int idx = tid + 256 * j;
+            const int r = idx / (BCO / 4), c4 = idx - r * (BCO / 4);
+            const long long m = k0 + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const int co = co0 + c4 * 4;
+            if (m < mend && co < g.Cg) v = *(const f32x4 *)(dy + m * g.Cg + co);
+            rd[j] = v;
+        }
+    };
+
+    if (mbeg < mend) load_stage(mbeg);
+    for (long long k0 = mbeg; k0 < mend; k0 += KP) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < XL; ++j) *(f32x4 *)&Xs[(tid + 256 * j) * 4] = rx[j];
+#pragma unroll
+        for (int j = 0; j < DL; ++j) *(f32x4 *)&Ds[(tid + 256 * j) * 4] = rd[j];
+        __syncthreads();
+        if (k0 + KP < mend) load_stage(k0 + KP);
+#pragma unroll 4
+        for (int kk = wk * KW; kk < (wk + 1) * KW; kk += 2) {
+            float a[MI], bb[MJ];
+            const int row = kk + (lane >> 5);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = Xs[row * BCI + wi * TI + i * 32 + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < MJ; ++j) bb[j] = Ds[row * BCO + wj * TJ + j * 32 + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < MJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    if (WK > 1) {
+        // waves hold partial sums of the SAME output tile: fold them through LDS in wave order
+        static_assert(WK == 1 || (MI == 1 && MJ == 1), "split-K-in-block only for 32x32 tiles");
+        __syncthreads();
+        float *red = Xs; // >= 3*1024 floats
+        if (wk > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wk - 1) * 16 + r) * 64 + lane] = acc[0][0][r];
+        }
+        __syncthreads();
+        if (wk == 0) {
+#pragma unroll
+            for (int w = 0; w < WK - 1; ++w)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][0][r] += red[(w * 16 + r) * 64 + lane];
+        }
+        if (wk != 0) return;
+    }
+
+    float *o = part + ((long long)split * taps.n + tap) * g.CiP * g.CoP;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + wi * TI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int co = co0 + wj * TJ + j * 32 + (lane & 31);
+                o[(long long)ci * g.CoP + co] = acc[i][j][r];
+            }
+}
+
+void acg_wgrad_tiles(int Ci, int Co, int *bci, int *bco)
+{
+    // one square tile size per layer: 128 for the dense 128/256-channel layers, 64 mid, 32 for thin ones
+    const int mn = Ci < Co ? Ci : Co;
+    const int t = mn >= 128 ? 128 : (mn >= 64 ? 64 : 32);
+    *bci = t;
+    *bco = t;
+}
+
+int acg_wgrad_launch(const float *x, const float *dy, float *part, const WGeom &g, const Taps &t, hipStream_t st)
+{
+    int bci, bco;
+    acg_wgrad_tiles(g.Cin, g.Cg, &bci, &bco);
+    const int blocks = g.nsplit * t.n * (g.CiP / bci) * (g.CoP / bco);
+    dim3 grid(blocks), block(256);
+    if (bci == 128)
+        hipLaunchKernelGGL((wgrad_f32<128, 128, 2, 2, 1, 32>), grid, block, 0, st, x, dy, part, g, t);
+    else if (bci == 64)
+        hipLaunchKernelGGL((wgrad_f32<64, 64, 2, 2, 1, 32>), grid, block, 0, st, x, dy, part, g, t);
+    else
+        hipLaunchKernelGGL((wgrad_f32<32, 32, 1, 1, 4, 128>), grid, block, 0, st, x, dy, part, g, t);
+    ACG_CHECK_LAUNCH("wgrad_f32");
+    return ACG_OK;
+}

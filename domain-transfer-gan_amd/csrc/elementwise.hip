@@ -1,0 +1,400 @@
+// Elementwise / reduction / small-dense kernels (all HBM- or latency-bound) and the optimiser.
+#include <math.h>
+#include "common.h"
+
+static int ew_blocks(long long total, int per = 256)
+{
+    long long b = (total + per - 1) / per;
+    return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+#define GRID_STRIDE(i, total) \
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < (total); i += (long long)gridDim.x * blockDim.x)
+
+// ---------------------------------------------------------------- error plumbing / version
+static thread_local char g_err[512] = "";
+void acg_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *acg_last_error(void) { return g_err; }
+extern "C" int acg_version(void) { return ACG_VERSION; }
+
+// ---------------------------------------------------------------- activation backward / add
+__global__ void act_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, float *__restrict__ dx,
+                               long long n4, int act)
+{
+    GRID_STRIDE(i, n4) {
+        f32x4 g = *(const f32x4 *)(dy + i * 4);
+        const f32x4 yy = *(const f32x4 *)(y + i * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] *= acg_act_grad_from_y(yy[k], act);
+        *(f32x4 *)(dx + i * 4) = g;
+    }
+}
+extern "C" int acg_act_bwd(const float *dy, const float *y, float *dx, size_t n, int act, void *stream)
+{
+    ACG_REQUIRE(n % 4 == 0, "acg_act_bwd: n %% 4 != 0");
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, y, dx,
+                       (long long)(n / 4), act);
+    ACG_CHECK_LAUNCH("act_bwd_kernel");
+    return ACG_OK;
+}
+
+__global__ void add_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ o, long long n4)
+{
+    GRID_STRIDE(i, n4) { *(f32x4 *)(o + i * 4) = *(const f32x4 *)(a + i * 4) + *(const f32x4 *)(b + i * 4); }
+}
+extern "C" int acg_add(const float *a, const float *b, float *out, size_t n, void *stream)
+{
+    ACG_REQUIRE(n % 4 == 0, "acg_add: n %% 4 != 0");
+    hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long long)(n / 4));
+    ACG_CHECK_LAUNCH("add_kernel");
+    return ACG_OK;
+}
+
+// ---------------------------------------------------------------- layout at the API edge
+// NCHW (C real) -> NHWC with Cp channels (zeros beyond C).  One thread per (n, h, w) pixel-channel-quad.
+__global__ void nchw_to_nhwc_kernel(const float *__restrict__ s, float *__restrict__ d, int N, int C, int H, int W, int Cp)
+{
+    const long long HW = (long long)H * W;
+    const long long total = (long long)N * HW * Cp;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % Cp);
+        const long long p = i / Cp;
+        const long long n = p / HW, hw = p - n * HW;
+        d[i] = c < C ? s[(n * C + c) * HW + hw] : 0.f;
+    }
+}
+__global__ void nhwc_to_nchw_kernel(const float *__restrict__ s, float *__restrict__ d, int N, int C, int H, int W, int Cp)
+{
+    const long long HW = (long long)H * W;
+    const long long total = (long long)N * C * HW;
+    GRID_STRIDE(i, total) {
+        const long long hw = i % HW;
+        const long long nc = i / HW;
+        const long long n = nc / C;
+        const int c = (int)(nc - n * C);
+        d[i] = s[(n * HW + hw) * Cp + c];
+    }
+}
+extern "C" int acg_nchw_to_nhwc16(const float *src, float *dst, int N, int C, int H, int W, int Cp, void *stream)
+{
+    ACG_REQUIRE(Cp >= C && Cp % 4 == 0, "acg_nchw_to_nhwc16: Cp=%d C=%d", Cp, C);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_blocks((long long)N * H * W * Cp)), dim3(256), 0, (hipStream_t)stream,
+                       src, dst, N, C, H, W, Cp);
+    ACG_CHECK_LAUNCH("nchw_to_nhwc_kernel");
+    return ACG_OK;
+}
+extern "C" int acg_nhwc16_to_nchw(const float *src, float *dst, int N, int C, int H, int W, int Cp, void *stream)
+{
+    ACG_REQUIRE(Cp >= C, "acg_nhwc16_to_nchw: Cp=%d C=%d", Cp, C);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_blocks((long long)N * H * W * C)), dim3(256), 0, (hipStream_t)stream,
+                       src, dst, N, C, H, W, Cp);
+    ACG_CHECK_LAUNCH("nhwc_to_nchw_kernel");
+    return ACG_OK;
+}
+
+__global__ void concat_kernel(const float *__restrict__ a, int Ca, int Cap, const float *__restrict__ b, int Cb, int Cbp,
+                              float *__restrict__ d, int Cdp, long long npix)
+{
+    const long long total = npix * Cdp;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % Cdp);
+        const long long p = i / Cdp;
+        float v = 0.f;
+        if (c < Ca) v = a[p * Cap + c];
+        else if (c < Ca + Cb) v = b[p * Cbp + (c - Ca)];
+        d[i] = v;
+    }
+}
+extern "C" int acg_concat_channels(const float *a, int Ca, int Cap, const float *b, int Cb, int Cbp, float *dst, int Cdp,
+                                   size_t npix, void *stream)
+{
+    ACG_REQUIRE(Ca + Cb <= Cdp, "acg_concat_channels: %d+%d > %d", Ca, Cb, Cdp);
+    hipLaunchKernelGGL(concat_kernel, dim3(ew_blocks((long long)npix * Cdp)), dim3(256), 0, (hipStream_t)stream, a, Ca,
+                       Cap, b, Cb, Cbp, dst, Cdp, (long long)npix);
+    ACG_CHECK_LAUNCH("concat_kernel");
+    return ACG_OK;
+}
+__global__ void split_kernel(const float *__restrict__ g, int Cdp, float *__restrict__ ga, int Ca, int Cap,
+                             float *__restrict__ gb, int Cb, int Cbp, long long npix)
+{
+    const int Cm = Cap > Cbp ? Cap : Cbp;
+    const long long total = npix * Cm;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % Cm);
+        const long long p = i / Cm;
+        if (ga != nullptr && c < Cap) ga[p * Cap + c] = c < Ca ? g[p * Cdp + c] : 0.f;
+        if (gb != nullptr && c < Cbp) gb[p * Cbp + c] = c < Cb ? g[p * Cdp + Ca + c] : 0.f;
+    }
+}
+extern "C" int acg_split_channels(const float *gdst, int Cdp, float *ga, int Ca, int Cap, float *gb, int Cb, int Cbp,
+                                  size_t npix, void *stream)
+{
+    ACG_REQUIRE(Ca + Cb <= Cdp, "acg_split_channels: %d+%d > %d", Ca, Cb, Cdp);
+    const int Cm = Cap > Cbp ? Cap : Cbp;
+    hipLaunchKernelGGL(split_kernel, dim3(ew_blocks((long long)npix * Cm)), dim3(256), 0, (hipStream_t)stream, gdst, Cdp,
+                       ga, Ca, Cap, gb, Cb, Cbp, (long long)npix);
+    ACG_CHECK_LAUNCH("split_kernel");
+    return ACG_OK;
+}
+
+// ---------------------------------------------------------------- small dense layers
+__global__ void linear_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b,
+                                  float *__restrict__ y, int N, int I, int ldx, int O, int Op, int act)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * Op) return;
+    const int n = i / Op, o = i - n * Op;
+    float acc = 0.f;
+    if (o < O) {
+        acc = b ? b[o] : 0.f;
+        for (int k = 0; k < I; ++k) acc += x[(long long)n * ldx + k] * w[(long long)o * I + k];
+        acc = acg_apply_act(acc, act);
+    }
+    y[i] = acc;
+}
+extern "C" int acg_linear_fwd(const float *x, const float *w, const float *b, float *y, int N, int I, int ldx, int O,
+                              int Op, int act, void *stream)
+{
+    ACG_REQUIRE(N > 0 && I > 0 && O > 0 && Op >= O && ldx >= I, "acg_linear_fwd: bad dims");
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3(acg_cdiv((long)N * Op, 128)), dim3(128), 0, (hipStream_t)stream, x, w, b, y,
+                       N, I, ldx, O, Op, act);
+    ACG_CHECK_LAUNCH("linear_fwd_kernel");
+    return ACG_OK;
+}
+// mode 0: dx[n][i] = sum_o g*w[o][i]   (threads over N*I)
+// mode 1: dw[o][i] = sum_n g*x[n][i]   (threads over O*I) ; db[o] = sum_n g (threads with i == 0)
+__global__ void linear_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, const float *__restrict__ x,
+                                  const float *__restrict__ w, float *__restrict__ dx, float *__restrict__ dw,
+                                  float *__restrict__ db, int N, int I, int ldx, int O, int Op, int act, int mode)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (mode == 0) {
+        if (t >= N * I) return;
+        const int n = t / I, i = t - n * I;
+        float acc = 0.f;
+        for (int o = 0; o < O; ++o) {
+            const float g = dy[(long long)n * Op + o] * acg_act_grad_from_y(y[(long long)n * Op + o], act);
+            acc += g * w[(long long)o * I + i];
+        }
+        dx[(long long)n * ldx + i] = acc;
+    } else {
+        if (t >= O * I) return;
+        const int o = t / I, i = t - o * I;
+        float acc = 0.f, bs = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const float g = dy[(long long)n * Op + o] * acg_act_grad_from_y(y[(long long)n * Op + o], act);
+            acc += g * x[(long long)n * ldx + i];
+            bs += g;
+        }
+        if (dw) dw[t] = acc;
+        if (db && i == 0) db[o] = bs;
+    }
+}
+extern "C" int acg_linear_bwd(const float *dy, const float *y, const float *x, const float *w, float *dx, float *dw,
+                              float *db, int N, int I, int ldx, int O, int Op, int act, void *stream)
+{
+    ACG_REQUIRE(N > 0 && I > 0 && O > 0 && Op >= O && ldx >= I, "acg_linear_bwd: bad dims");
+    hipStream_t st = (hipStream_t)stream;
+    if (dx != nullptr)
+        hipLaunchKernelGGL(linear_bwd_kernel, dim3(acg_cdiv((long)N * I, 128)), dim3(128), 0, st, dy, y, x, w, dx, dw, db, N,
+                           I, ldx, O, Op, act, 0);
+    if (dw != nullptr || db != nullptr)
+        hipLaunchKernelGGL(linear_bwd_kernel, dim3(acg_cdiv((long)O * I, 128)), dim3(128), 0, st, dy, y, x, w, dx, dw, db, N,
+                           I, ldx, O, Op, act, 1);
+    ACG_CHECK_LAUNCH("linear_bwd_kernel");
+    return ACG_OK;
+}
+
+// ---------------------------------------------------------------- spatial mean [N][P][Cp] -> [N][Cp]
+__global__ void spatial_mean_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, long long P, int Cp)
+{
+    __shared__ float red[256];
+    const int n = blockIdx.x, c = blockIdx.y;
+    float s = 0.f;
+    for (long long p = threadIdx.x; p < P; p += blockDim.x) s += x[((long long)n * P + p) * Cp + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) y[(long long)n * Cp + c] = red[0] / (float)P;
+}
+__global__ void spatial_mean_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dx, long long P, int Cp, long long total)
+{
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % Cp);
+        const long long n = i / ((long long)P * Cp);
+        dx[i] = dy[n * Cp + c] / (float)P;
+    }
+}
+extern "C" int acg_spatial_mean_fwd(const float *x, float *y, int N, size_t P, int Cp, void *stream)
+{
+    hipLaunchKernelGGL(spatial_mean_fwd_kernel, dim3(N, Cp), dim3(256), 0, (hipStream_t)stream, x, y, (long long)P, Cp);
+    ACG_CHECK_LAUNCH("spatial_mean_fwd_kernel");
+    return ACG_OK;
+}
+extern "C" int acg_spatial_mean_bwd(const float *dy, float *dx, int N, size_t P, int Cp, void *stream)
+{
+    const long long total = (long long)N * P * Cp;
+    hipLaunchKernelGGL(spatial_mean_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dy, dx,
+                       (long long)P, Cp, total);
+    ACG_CHECK_LAUNCH("spatial_mean_bwd_kernel");
+    return ACG_OK;
+}
+
+// ---------------------------------------------------------------- reductions to a device scalar
+// mode: 0 = sum((p-t)^2) ; 1 = sum(|a-b|) ; 2 = sum(p) ; 3 = sum(p^2) (no channel mask)
+#define RED_BLOCKS 1024
+template <int MODE>
+__global__ __launch_bounds__(256) void reduce_partial_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                             long long total, int C, int Cp, float target,
+                                                             float *__restrict__ part)
+{
+    __shared__ float red[256];
+    float s = 0.f;
+    GRID_STRIDE(i, total) {
+        if (MODE != 3 && (int)(i % Cp) >= C) continue;
+        const float v = a[i];
+        if (MODE == 0) { const float d = v - target; s += d * d; }
+        else if (MODE == 1) s += fabsf(v - b[i]);
+        else if (MODE == 2) s += v;
+        else s += v * v;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void reduce_final_kernel(const float *__restrict__ part, int nb, float scale,
+                                                           float *__restrict__ out)
+{
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) s += part[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0] * scale;
+}
+extern "C" size_t acg_reduce_workspace_bytes(size_t n) { (void)n; return RED_BLOCKS * sizeof(float); }
+
+template <int MODE>
+static int reduce_launch(const float *a, const float *b, long long total, int C, int Cp, float target, float scale,
+                         float *out, void *ws, size_t ws_bytes, hipStream_t st, const char *who)
+{
+    if (ws == nullptr || ws_bytes < RED_BLOCKS * sizeof(float)) {
+        acg_set_error("%s: workspace too small", who);
+        return ACG_ERR_WORKSPACE;
+    }
+    long long nbl = (total + 2047) / 2048;
+    const int nb = (int)(nbl > RED_BLOCKS ? RED_BLOCKS : (nbl < 1 ? 1 : nbl));
+    hipLaunchKernelGGL((reduce_partial_kernel<MODE>), dim3(nb), dim3(256), 0, st, a, b, total, C, Cp, target, (float *)ws);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, st, (const float *)ws, nb, scale, out);
+    ACG_CHECK_LAUNCH(who);
+    return ACG_OK;
+}
+extern "C" int acg_mse_const_fwd(const float *p, size_t npix, int C, int Cp, float target, float *out, void *ws,
+                                 size_t ws_bytes, void *stream)
+{
+    return reduce_launch<0>(p, nullptr, (long long)npix * Cp, C, Cp, target, 1.f / ((float)npix * C), out, ws, ws_bytes,
+                            (hipStream_t)stream, "acg_mse_const_fwd");
+}
+extern "C" int acg_l1_fwd(const float *a, const float *b, size_t npix, int C, int Cp, float *out, void *ws,
+                          size_t ws_bytes, void *stream)
+{
+    return reduce_launch<1>(a, b, (long long)npix * Cp, C, Cp, 0.f, 1.f / ((float)npix * C), out, ws, ws_bytes,
+                            (hipStream_t)stream, "acg_l1_fwd");
+}
+extern "C" int acg_mean_fwd(const float *x, size_t npix, int C, int Cp, float *out, void *ws, size_t ws_bytes,
+                            void *stream)
+{
+    return reduce_launch<2>(x, nullptr, (long long)npix * Cp, C, Cp, 0.f, 1.f / ((float)npix * C), out, ws, ws_bytes,
+                            (hipStream_t)stream, "acg_mean_fwd");
+}
+extern "C" int acg_sumsq(const float *g, size_t n, float *out, void *ws, size_t ws_bytes, void *stream)
+{
+    return reduce_launch<3>(g, nullptr, (long long)n, 1, 1, 0.f, 1.f, out, ws, ws_bytes, (hipStream_t)stream, "acg_sumsq");
+}
+
+__global__ void mse_const_bwd_kernel(const float *__restrict__ p, long long total, int C, int Cp, float target,
+                                     float k, const float *__restrict__ gout, float *__restrict__ dp)
+{
+    const float g = gout[0] * k;
+    GRID_STRIDE(i, total) { dp[i] = (int)(i % Cp) < C ? g * (p[i] - target) : 0.f; }
+}
+extern "C" int acg_mse_const_bwd(const float *p, size_t npix, int C, int Cp, float target, const float *gout, float *dp,
+                                 void *stream)
+{
+    const long long total = (long long)npix * Cp;
+    hipLaunchKernelGGL(mse_const_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, p, total, C, Cp,
+                       target, 2.f / ((float)npix * C), gout, dp);
+    ACG_CHECK_LAUNCH("mse_const_bwd_kernel");
+    return ACG_OK;
+}
+__global__ void l1_bwd_kernel(const float *__restrict__ a, const float *__restrict__ b, long long total, int C, int Cp,
+                              float k, const float *__restrict__ gout, float *__restrict__ da, float *__restrict__ db)
+{
+    const float g = gout[0] * k;
+    GRID_STRIDE(i, total) {
+        float v = 0.f;
+        if ((int)(i % Cp) < C) {
+            const float d = a[i] - b[i];
+            v = d > 0.f ? g : (d < 0.f ? -g : 0.f); // sign(0) = 0, as torch
+        }
+        if (da) da[i] = v;
+        if (db) db[i] = -v;
+    }
+}
+extern "C" int acg_l1_bwd(const float *a, const float *b, size_t npix, int C, int Cp, const float *gout, float *da,
+                          float *db, void *stream)
+{
+    const long long total = (long long)npix * Cp;
+    hipLaunchKernelGGL(l1_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, a, b, total, C, Cp,
+                       1.f / ((float)npix * C), gout, da, db);
+    ACG_CHECK_LAUNCH("l1_bwd_kernel");
+    return ACG_OK;
+}
+
+// ---------------------------------------------------------------- clip + Adam on a flat buffer
+__global__ void adam_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                            long long n, const float *__restrict__ sumsq, float max_norm, float step_size, float beta1,
+                            float beta2, float inv_bc2_sqrt, float eps, int scale_grads)
+{
+    float coef = 1.f;
+    if (sumsq != nullptr) {
+        coef = max_norm / (sqrtf(sumsq[0]) + 1e-6f);
+        coef = coef < 1.f ? coef : 1.f;
+    }
+    GRID_STRIDE(i, n) {
+        const float gi = g[i] * coef;
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * mi / (sqrtf(vi) * inv_bc2_sqrt + eps);
+        if (scale_grads) g[i] = gi;
+    }
+}
+extern "C" int acg_adam_step(float *p, float *g, float *m, float *v, size_t n, const float *sumsq, float max_norm,
+                             float lr, float beta1, float beta2, float eps, int step, int scale_grads, void *stream)
+{
+    ACG_REQUIRE(step >= 1, "acg_adam_step: step must be >= 1");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks((long long)n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                       (long long)n, sumsq, max_norm, (float)(lr / bc1), beta1, beta2, (float)(1.0 / sqrt(bc2)), eps,
+                       scale_grads);
+    ACG_CHECK_LAUNCH("adam_kernel");
+    return ACG_OK;
+}

@@ -1,0 +1,321 @@
+// Normalisation kernels (HBM-bound): InstanceNorm / CondInstanceNorm / BatchNorm(train) over an
+// NHWC tensor viewed as [G groups][P pixels][C channels] (IN/CIN: G=N, P=H*W; BN: G=1, P=N*H*W).
+//
+// Statistics: one read of x.  Each thread keeps plain sums over <=256 rows, converts them to
+// (mean, M2) and all further merging (threads -> block -> chunks) uses Chan's parallel update,
+// which is well conditioned — the reference computes mean((x-mean)^2) in two passes
+// (modules.py:86-88); this matches it to fp32 rounding without the second read.
+// All access is float4 over channels, consecutive lanes on consecutive channels (coalesced).
+#include "common.h"
+
+#define NORM_ROWS 1024 // pixels per block
+
+__device__ __forceinline__ void chan_merge(float &na, float &ma, float &sa, float nb, float mb, float sb)
+{
+    if (nb == 0.f) return;
+    const float n = na + nb;
+    const float d = mb - ma;
+    ma += d * (nb / n);
+    sa += sb + d * d * (na * nb / n);
+    na = n;
+}
+
+// partial layout: part[((g*nchunks + chunk)*2 + {0:mean,1:M2})*C + c]; the chunk's row count is implied
+__global__ __launch_bounds__(256) void norm_stats_partial(const float *__restrict__ x, long long P, int C,
+                                                          int nchunks, float *__restrict__ part)
+{
+    __shared__ float sm[256 * 4], sq[256 * 4], sn[256];
+    const int C4 = C / 4;
+    const int rows_par = 256 / C4;
+    const int c4 = threadIdx.x % C4, rl = threadIdx.x / C4;
+    const int g = blockIdx.y, chunk = blockIdx.x;
+    const long long r0 = (long long)chunk * NORM_ROWS;
+    long long r1 = r0 + NORM_ROWS;
+    if (r1 > P) r1 = P;
+    const float *xg = x + (long long)g * P * C;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    float cnt = 0.f;
+    if (rl < rows_par)
+        for (long long r = r0 + rl; r < r1; r += rows_par) {
+            const f32x4 v = *(const f32x4 *)(xg + r * C + c4 * 4);
+            s1 += v;
+            s2 += v * v;
+            cnt += 1.f;
+        }
+    f32x4 mean = {0.f, 0.f, 0.f, 0.f}, m2 = {0.f, 0.f, 0.f, 0.f};
+    if (cnt > 0.f) {
+        mean = s1 / cnt;
+        m2 = s2 - s1 * mean;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m2[k] = m2[k] < 0.f ? 0.f : m2[k];
+    }
+    *(f32x4 *)&sm[threadIdx.x * 4] = mean;
+    *(f32x4 *)&sq[threadIdx.x * 4] = m2;
+    sn[threadIdx.x] = cnt;
+    __syncthreads();
+    if (threadIdx.x < C4) {
+        float n[4], m[4], s[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { n[k] = 0.f; m[k] = 0.f; s[k] = 0.f; }
+        for (int j = 0; j < rows_par; ++j) {
+            const int t = j * C4 + threadIdx.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) chan_merge(n[k], m[k], s[k], sn[t], sm[t * 4 + k], sq[t * 4 + k]);
+        }
+        float *o = part + ((long long)(g * nchunks + chunk) * 2) * C + threadIdx.x * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[k] = m[k]; o[C + k] = s[k]; }
+    }
+}
+
+__global__ void norm_stats_final(const float *__restrict__ part, int G, long long P, int C, int nchunks, float eps,
+                                 int unbiased, float *__restrict__ mean, float *__restrict__ rstd,
+                                 float *__restrict__ run_mean, float *__restrict__ run_var, float momentum)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G * C) return;
+    const int g = i / C, c = i - g * C;
+    float n = 0.f, m = 0.f, s = 0.f;
+    for (int k = 0; k < nchunks; ++k) {
+        long long rows = P - (long long)k * NORM_ROWS;
+        if (rows > NORM_ROWS) rows = NORM_ROWS;
+        const float *p = part + ((long long)(g * nchunks + k) * 2) * C + c;
+        chan_merge(n, m, s, (float)rows, p[0], p[C]);
+    }
+    const float denom = unbiased ? (float)(P - 1) : (float)P;
+    mean[i] = m;
+    rstd[i] = rsqrtf(s / denom + eps);
+    if (run_mean != nullptr) { // BatchNorm (G == 1): running_var takes the unbiased estimate
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * m;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (s / (float)(P > 1 ? P - 1 : 1));
+    }
+}
+
+__global__ __launch_bounds__(256) void norm_apply_kernel(const float *__restrict__ x, const float *__restrict__ mean,
+                                                         const float *__restrict__ rstd,
+                                                         const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta, int gstride,
+                                                         const float *__restrict__ res, float *__restrict__ y,
+                                                         long long P, int C, int act)
+{
+    const int C4 = C / 4;
+    const int g = blockIdx.y;
+    const long long total = P * C4;
+    const long long base = (long long)g * P * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const f32x4 v = *(const f32x4 *)(x + base + i * 4);
+        const f32x4 mu = *(const f32x4 *)(mean + g * C + c);
+        const f32x4 rs = *(const f32x4 *)(rstd + g * C + c);
+        const f32x4 ga = *(const f32x4 *)(gamma + g * gstride + c);
+        const f32x4 be = *(const f32x4 *)(beta + g * gstride + c);
+        f32x4 o = (v - mu) * rs * ga + be;
+        if (res != nullptr) o += *(const f32x4 *)(res + base + i * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = acg_apply_act(o[k], act);
+        *(f32x4 *)(y + base + i * 4) = o;
+    }
+}
+
+// backward pass 1: per (group, chunk) partial sums of gy and gy*xhat, gy = dy*act'(y)
+// part[((g*nchunks + chunk)*2 + {0:S1,1:S2})*C + c]
+__global__ __launch_bounds__(256) void norm_bwd_partial(const float *__restrict__ dy, const float *__restrict__ y,
+                                                        const float *__restrict__ x, const float *__restrict__ mean,
+                                                        const float *__restrict__ rstd, long long P, int C,
+                                                        int nchunks, int act, float *__restrict__ part)
+{
+    __shared__ float sa[256 * 4], sb[256 * 4];
+    const int C4 = C / 4;
+    const int rows_par = 256 / C4;
+    const int c4 = threadIdx.x % C4, rl = threadIdx.x / C4;
+    const int g = blockIdx.y, chunk = blockIdx.x;
+    const long long r0 = (long long)chunk * NORM_ROWS;
+    long long r1 = r0 + NORM_ROWS;
+    if (r1 > P) r1 = P;
+    const long long base = (long long)g * P * C;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    if (rl < rows_par) {
+        const f32x4 mu = *(const f32x4 *)(mean + g * C + c4 * 4);
+        const f32x4 rs = *(const f32x4 *)(rstd + g * C + c4 * 4);
+        for (long long r = r0 + rl; r < r1; r += rows_par) {
+            const long long o = base + r * C + c4 * 4;
+            f32x4 gy = *(const f32x4 *)(dy + o);
+            if (act != ACG_ACT_NONE) {
+                const f32x4 yy = *(const f32x4 *)(y + o);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gy[k] *= acg_act_grad_from_y(yy[k], act);
+            }
+            const f32x4 xh = (*(const f32x4 *)(x + o) - mu) * rs;
+            s1 += gy;
+            s2 += gy * xh;
+        }
+    }
+    *(f32x4 *)&sa[threadIdx.x * 4] = s1;
+    *(f32x4 *)&sb[threadIdx.x * 4] = s2;
+    __syncthreads();
+    if (threadIdx.x < C4) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < rows_par; ++j) {
+            a += *(const f32x4 *)&sa[(j * C4 + threadIdx.x) * 4];
+            b += *(const f32x4 *)&sb[(j * C4 + threadIdx.x) * 4];
+        }
+        float *o = part + ((long long)(g * nchunks + chunk) * 2) * C + threadIdx.x * 4;
+        *(f32x4 *)o = a;
+        *(f32x4 *)(o + C) = b;
+    }
+}
+
+// sums[(g*2 + {0,1})*C + c] = sum over chunks (fixed order)
+__global__ void norm_bwd_final(const float *__restrict__ part, int G, int C, int nchunks, float *__restrict__ sums)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G * C) return;
+    const int g = i / C, c = i - g * C;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < nchunks; ++k) {
+        const float *p = part + ((long long)(g * nchunks + k) * 2) * C + c;
+        a += p[0];
+        b += p[C];
+    }
+    sums[(g * 2) * C + c] = a;
+    sums[(g * 2 + 1) * C + c] = b;
+}
+
+// parameter gradients: gstride==0 -> dgamma[c] = sum_g S2, dbeta[c] = sum_g S1 ; else per (g,c)
+__global__ void norm_bwd_params(const float *__restrict__ sums, int G, int C, int gstride, float *__restrict__ dgamma,
+                                float *__restrict__ dbeta)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gstride == 0) {
+        if (i >= C) return;
+        float a = 0.f, b = 0.f;
+        for (int g = 0; g < G; ++g) { a += sums[(g * 2) * C + i]; b += sums[(g * 2 + 1) * C + i]; }
+        if (dbeta) dbeta[i] = a;
+        if (dgamma) dgamma[i] = b;
+    } else {
+        if (i >= G * C) return;
+        const int g = i / C, c = i - g * C;
+        if (dbeta) dbeta[g * gstride + c] = sums[(g * 2) * C + c];
+        if (dgamma) dgamma[g * gstride + c] = sums[(g * 2 + 1) * C + c];
+    }
+}
+
+// backward pass 2: dx = gamma*rstd*(gy - S1/P - xhat*S2/D) ; dres = gy
+__global__ __launch_bounds__(256) void norm_bwd_apply(const float *__restrict__ dy, const float *__restrict__ y,
+                                                      const float *__restrict__ x, const float *__restrict__ mean,
+                                                      const float *__restrict__ rstd,
+                                                      const float *__restrict__ gamma, int gstride,
+                                                      const float *__restrict__ sums, float *__restrict__ dx,
+                                                      float *__restrict__ dres, long long P, int C, int act,
+                                                      float invP, float invD)
+{
+    const int C4 = C / 4;
+    const int g = blockIdx.y;
+    const long long total = P * C4;
+    const long long base = (long long)g * P * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const long long o = base + i * 4;
+        f32x4 gy = *(const f32x4 *)(dy + o);
+        if (act != ACG_ACT_NONE) {
+            const f32x4 yy = *(const f32x4 *)(y + o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gy[k] *= acg_act_grad_from_y(yy[k], act);
+        }
+        const f32x4 mu = *(const f32x4 *)(mean + g * C + c);
+        const f32x4 rs = *(const f32x4 *)(rstd + g * C + c);
+        const f32x4 ga = *(const f32x4 *)(gamma + g * gstride + c);
+        const f32x4 s1 = *(const f32x4 *)(sums + (g * 2) * C + c);
+        const f32x4 s2 = *(const f32x4 *)(sums + (g * 2 + 1) * C + c);
+        const f32x4 xh = (*(const f32x4 *)(x + o) - mu) * rs;
+        *(f32x4 *)(dx + o) = ga * rs * (gy - s1 * invP - xh * (s2 * invD));
+        if (dres != nullptr) *(f32x4 *)(dres + o) = gy;
+    }
+}
+
+static int nchunks_of(size_t P) { return (int)((P + NORM_ROWS - 1) / NORM_ROWS); }
+
+extern "C" size_t acg_norm_workspace_bytes(int G, size_t P, int C)
+{
+    return ((size_t)G * nchunks_of(P) * 2 * C + (size_t)G * 2 * C) * sizeof(float);
+}
+
+static int check_norm(int G, size_t P, int C, const char *who)
+{
+    ACG_REQUIRE(G > 0 && P > 0 && C > 0 && C % 4 == 0 && C <= 1024, "%s: bad shape G=%d P=%zu C=%d", who, G, P, C);
+    ACG_REQUIRE(G <= 65535, "%s: G=%d exceeds grid.y", who, G);
+    return ACG_OK;
+}
+
+extern "C" int acg_norm_stats(const float *x, int G, size_t P, int C, float eps, int unbiased, float *mean,
+                              float *rstd, float *run_mean, float *run_var, float momentum, void *ws, size_t ws_bytes,
+                              void *stream)
+{
+    int rc = check_norm(G, P, C, "acg_norm_stats");
+    if (rc) return rc;
+    ACG_REQUIRE(!(unbiased && P < 2), "acg_norm_stats: unbiased variance needs P >= 2");
+    ACG_REQUIRE(run_mean == nullptr || G == 1, "acg_norm_stats: running stats need G == 1");
+    if (ws == nullptr || ws_bytes < acg_norm_workspace_bytes(G, P, C)) {
+        acg_set_error("acg_norm_stats: workspace too small");
+        return ACG_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = nchunks_of(P);
+    hipLaunchKernelGGL(norm_stats_partial, dim3(nch, G), dim3(256), 0, st, x, (long long)P, C, nch, (float *)ws);
+    hipLaunchKernelGGL(norm_stats_final, dim3(acg_cdiv((long)G * C, 256)), dim3(256), 0, st, (const float *)ws, G,
+                       (long long)P, C, nch, eps, unbiased, mean, rstd, run_mean, run_var, momentum);
+    ACG_CHECK_LAUNCH("norm_stats");
+    return ACG_OK;
+}
+
+static int ew_blocks(long long total)
+{
+    long long b = (total + 255) / 256;
+    return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+extern "C" int acg_norm_apply(const float *x, const float *mean, const float *rstd, const float *gamma,
+                              const float *beta, int gstride, const float *res, float *y, int G, size_t P, int C,
+                              int act, void *stream)
+{
+    int rc = check_norm(G, P, C, "acg_norm_apply");
+    if (rc) return rc;
+    ACG_REQUIRE(gstride == 0 || gstride == C, "acg_norm_apply: gstride must be 0 or C");
+    hipLaunchKernelGGL(norm_apply_kernel, dim3(ew_blocks((long long)P * (C / 4)), G), dim3(256), 0, (hipStream_t)stream,
+                       x, mean, rstd, gamma, beta, gstride, res, y, (long long)P, C, act);
+    ACG_CHECK_LAUNCH("norm_apply_kernel");
+    return ACG_OK;
+}
+
+extern "C" int acg_norm_bwd(const float *dy, const float *y, const float *x, const float *mean, const float *rstd,
+                            const float *gamma, int gstride, float *dx, float *dres, float *dgamma, float *dbeta,
+                            int G, size_t P, int C, int act, int unbiased, void *ws, size_t ws_bytes, void *stream)
+{
+    int rc = check_norm(G, P, C, "acg_norm_bwd");
+    if (rc) return rc;
+    ACG_REQUIRE(gstride == 0 || gstride == C, "acg_norm_bwd: gstride must be 0 or C");
+    ACG_REQUIRE(act == ACG_ACT_NONE || act == ACG_ACT_RELU || act == ACG_ACT_LRELU, "acg_norm_bwd: act %d", act);
+    if (ws == nullptr || ws_bytes < acg_norm_workspace_bytes(G, P, C)) {
+        acg_set_error("acg_norm_bwd: workspace too small");
+        return ACG_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = nchunks_of(P);
+    float *part = (float *)ws;
+    float *sums = part + (size_t)G * nch * 2 * C;
+    hipLaunchKernelGGL(norm_bwd_partial, dim3(nch, G), dim3(256), 0, st, dy, y, x, mean, rstd, (long long)P, C, nch, act,
+                       part);
+    hipLaunchKernelGGL(norm_bwd_final, dim3(acg_cdiv((long)G * C, 256)), dim3(256), 0, st, (const float *)part, G, C,
+                       nch, sums);
+    if (dgamma != nullptr || dbeta != nullptr)
+        hipLaunchKernelGGL(norm_bwd_params, dim3(acg_cdiv((long)G * C, 256)), dim3(256), 0, st, (const float *)sums, G, C,
+                           gstride, dgamma, dbeta);
+    const float invP = 1.f / (float)P;
+    const float invD = unbiased ? 1.f / (float)(P - 1) : invP;
+    hipLaunchKernelGGL(norm_bwd_apply, dim3(ew_blocks((long long)P * (C / 4)), G), dim3(256), 0, st, dy, y, x, mean, rstd,
+                       gamma, gstride, (const float *)sums, dx, dres, (long long)P, C, act, invP, invD);
+    ACG_CHECK_LAUNCH("norm_bwd");
+    return ACG_OK;
+}

@@ -1,0 +1,164 @@
+/*
+ * acgan_hip.h — C ABI of libacgan_hip.so: the MI355X (gfx950) kernels behind the
+ * Augmented CycleGAN training step of adrianalbert/domain-transfer-GAN.
+ *
+ * The reference has NO native layer: its hot path reaches the
+ * device through torch.nn modules.  Each entry point below therefore cites the
+ * reference call site(s) whose arithmetic it replaces (paths relative to
+ * /root/reference/augmented_cyclegan/).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *  - plain C: pointers + ints, no torch types.  All pointers are DEVICE pointers
+ *    owned by the caller; the library never allocates device memory, never
+ *    synchronises, and only enqueues on `stream` (a hipStream_t passed as void*).
+ *  - return 0 on success, a negative acg_status otherwise; acg_last_error()
+ *    returns a thread-local message for the last failure on this thread.
+ *  - activations are fp32 NHWC with the channel count padded to a multiple of 16
+ *    ("C16"); padded channels hold zeros.  Weights are passed in the packed forms
+ *    produced by acg_pack_conv_weight().
+ */
+#ifndef ACGAN_HIP_H
+#define ACGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACG_VERSION 100
+
+typedef enum {
+    ACG_OK = 0,
+    ACG_ERR_INVALID = -1,   /* bad argument / unsupported shape */
+    ACG_ERR_WORKSPACE = -2, /* workspace too small */
+    ACG_ERR_LAUNCH = -3     /* hip launch error */
+} acg_status;
+
+typedef enum { ACG_ACT_NONE = 0, ACG_ACT_RELU = 1, ACG_ACT_LRELU = 2 /* slope 0.2 */, ACG_ACT_TANH = 3 } acg_act;
+typedef enum { ACG_PAD_ZERO = 0, ACG_PAD_REFLECT = 1 } acg_pad_mode;
+typedef enum { ACG_IMPL_MFMA = 0, ACG_IMPL_DIRECT = 1 } acg_conv_impl;
+
+/* Geometry of one nn.Conv2d (or of the Conv2d whose adjoint an nn.ConvTranspose2d is).
+ * Ci / Co are the STORED (padded-to-16) channel counts of the NHWC tensors. */
+typedef struct {
+    int N, Hi, Wi, Ci;
+    int Ho, Wo, Co;
+    int K, stride, pad, pad_mode;
+} acg_conv_desc;
+
+int acg_version(void);
+const char *acg_last_error(void);
+/* selects the convolution implementation for subsequent calls on this process
+ * (MFMA implicit GEMM = product path; DIRECT = naive one-thread-per-output kernels kept
+ * as an on-device cross-check).  Both are HIP kernels; there is no CPU path. */
+int acg_set_conv_impl(int impl);
+
+/* ---- layout at the API edge (reference tensors are NCHW: dataloader.py:26, model.py:404) ---- */
+int acg_nchw_to_nhwc16(const float *src, float *dst, int N, int C, int H, int W, int Cp, void *stream);
+int acg_nhwc16_to_nchw(const float *src, float *dst, int N, int C, int H, int W, int Cp, void *stream);
+/* torch.cat((a, b), 1) on C16 tensors — model.py:410, 472 */
+int acg_concat_channels(const float *a, int Ca, int Cap, const float *b, int Cb, int Cbp, float *dst, int Cdp,
+                        size_t npix, void *stream);
+/* adjoint of the above: splits d(dst) into d(a), d(b) (either may be NULL) */
+int acg_split_channels(const float *gdst, int Cdp, float *ga, int Ca, int Cap, float *gb, int Cb, int Cbp,
+                       size_t npix, void *stream);
+
+/* ---- weights: OIHW (torch layout, real channel counts Or x Ir) -> packed, zero padded ----
+ * wf: [K*K][Ci/8][CoP][8]  (B operand of forward / ConvTranspose-backward GEMMs)
+ * wb: [K*K][Co/8][CiP][8]  (B operand of data-gradient / ConvTranspose-forward GEMMs)
+ * CoP = acg_ncols_pad(Co), CiP = acg_ncols_pad(Ci).  Either output may be NULL. */
+int acg_ncols_pad(int c);
+size_t acg_packed_wf_elems(int K, int Ci, int Co);
+size_t acg_packed_wb_elems(int K, int Ci, int Co);
+int acg_pack_conv_weight(const float *w_oihw, int Or, int Ir, int K, int Ci, int Co, float *wf, float *wb, void *stream);
+int acg_pad_vector(const float *src, int n, float *dst, int np, void *stream); /* bias -> C16 */
+
+/* ---- nn.Conv2d forward (+bias, + fused activation) — networks.py:159-188, 211-243, 321-338,
+ *      365-382, 445-471; modules.py:162,180,211,227 (reflection pad folded into the loader). */
+int acg_conv2d_fwd(const acg_conv_desc *d, const float *x, const float *wf, const float *bias, float *y, int act,
+                   void *stream);
+/* data gradient of the above (autograd of nn.Conv2d / ReflectionPad2d): dy -> dx.
+ * Reflect padding needs a workspace for the padded gradient image. */
+size_t acg_conv2d_bwd_data_workspace_bytes(const acg_conv_desc *d);
+int acg_conv2d_bwd_data(const acg_conv_desc *d, const float *dy, const float *wb, float *dx, void *workspace,
+                        size_t ws_bytes, void *stream);
+/* weight (+bias) gradient: x, dy -> dw in torch OIHW layout (Or x Ir real channels), db[Or] (may be NULL).
+ * Deterministic split-K over pixels with a second-stage reduction (no atomics). */
+size_t acg_conv2d_bwd_weight_workspace_bytes(const acg_conv_desc *d);
+int acg_conv2d_bwd_weight(const acg_conv_desc *d, const float *x, const float *dy, float *dw_oihw, float *db,
+                          int Or, int Ir, void *workspace, size_t ws_bytes, void *stream);
+
+/* ---- nn.ConvTranspose2d(k3,s2,p1,op1) — networks.py:178-179, 231-234.  `d` describes the
+ *      Conv2d it is the adjoint of (Hi,Wi,Ci = the LARGE side = ConvTranspose output). ---- */
+int acg_conv_transpose2d_fwd(const acg_conv_desc *d, const float *x, const float *wb, const float *bias, float *y,
+                             int act, void *stream);
+int acg_conv_transpose2d_bwd_data(const acg_conv_desc *d, const float *dy, const float *wf, float *dx, void *stream);
+int acg_conv_transpose2d_bwd_weight(const acg_conv_desc *d, const float *x, const float *dy, float *dw_oihw,
+                                    float *db, int Or, int Ir, void *workspace, size_t ws_bytes, void *stream);
+
+/* ---- normalisation: InstanceNorm (modules.py:64-97, biased var), CondInstanceNorm
+ *      (modules.py:104-132, UNBIASED var, per-sample affine), BatchNorm2d/1d train mode
+ *      (networks.py:407-415, 450-466).  Tensor viewed as [G groups][P pixels][C]:
+ *      IN/CIN: G=N, P=H*W;  BN: G=1, P=N*H*W. ---- */
+size_t acg_norm_workspace_bytes(int G, size_t P, int C);
+/* mean[G*C], rstd[G*C]; unbiased!=0 selects var*P/(P-1).  If run_mean/run_var are non-NULL
+ * (BatchNorm) they are updated with momentum (running_var takes the unbiased variance). */
+int acg_norm_stats(const float *x, int G, size_t P, int C, float eps, int unbiased, float *mean, float *rstd,
+                   float *run_mean, float *run_var, float momentum, void *workspace, size_t ws_bytes, void *stream);
+/* y = act((x-mean)*rstd*gamma + beta [+ res]); gamma/beta indexed [g*gstride + c] (gstride 0 or C) */
+int acg_norm_apply(const float *x, const float *mean, const float *rstd, const float *gamma, const float *beta,
+                   int gstride, const float *res, float *y, int G, size_t P, int C, int act, void *stream);
+/* backward: dy (w.r.t. y), y, x -> dx, dres (if has_res; = dy*act'(y)), dgamma/dbeta
+ * ([C] summed over groups when gstride==0, else [G*C]). unbiased as in acg_norm_stats. */
+int acg_norm_bwd(const float *dy, const float *y, const float *x, const float *mean, const float *rstd,
+                 const float *gamma, int gstride, float *dx, float *dres, float *dgamma, float *dbeta, int G,
+                 size_t P, int C, int act, int unbiased, void *workspace, size_t ws_bytes, void *stream);
+
+/* ---- elementwise ---- */
+int acg_act_bwd(const float *dy, const float *y, float *dx, size_t n, int act, void *stream); /* dx = dy*act'(y) */
+int acg_add(const float *a, const float *b, float *out, size_t n, void *stream);
+
+/* ---- small dense layers: nn.Linear (networks.py:406-418), the 1x1 convs on the (N,nl,1,1) latent
+ *      inside CondInstanceNorm (modules.py:111-118).  y[N][Op] = act(x[N][I] W[O][I]^T + b); columns
+ *      O..Op-1 are written as zeros. ---- */
+int acg_linear_fwd(const float *x, const float *w, const float *b, float *y, int N, int I, int ldx, int O, int Op,
+                   int act, void *stream);
+/* g = dy*act'(y) is applied inside; dx may be NULL; dw[O][I], db[O] are overwritten */
+int acg_linear_bwd(const float *dy, const float *y, const float *x, const float *w, float *dx, float *dw, float *db,
+                   int N, int I, int ldx, int O, int Op, int act, void *stream);
+
+/* ---- spatial mean over H*W of a C16 map -> [N][Cp] (LatentEncoder extension for S != 64,
+ *      identity at the reference's 1x1 map — networks.py:482) ---- */
+int acg_spatial_mean_fwd(const float *x, float *y, int N, size_t P, int Cp, void *stream);
+int acg_spatial_mean_bwd(const float *dy, float *dx, int N, size_t P, int Cp, void *stream);
+
+/* ---- losses: results are written to device scalars (no host sync) ----
+ * tensors are C16; only channels < C count.  out[0] = mean((p-target)^2)  (model.py:65-70) */
+size_t acg_reduce_workspace_bytes(size_t n);
+int acg_mse_const_fwd(const float *p, size_t npix, int C, int Cp, float target, float *out, void *workspace,
+                      size_t ws_bytes, void *stream);
+int acg_mse_const_bwd(const float *p, size_t npix, int C, int Cp, float target, const float *gout, float *dp,
+                      void *stream);
+/* out[0] = mean(|a-b|) (F.l1_loss, model.py:391,468,486,494) */
+int acg_l1_fwd(const float *a, const float *b, size_t npix, int C, int Cp, float *out, void *workspace,
+               size_t ws_bytes, void *stream);
+int acg_l1_bwd(const float *a, const float *b, size_t npix, int C, int Cp, const float *gout, float *da, float *db,
+               void *stream);
+/* out[0] = mean(x) over valid channels (P_t_A ... monitors, model.py:522-523) */
+int acg_mean_fwd(const float *x, size_t npix, int C, int Cp, float *out, void *workspace, size_t ws_bytes,
+                 void *stream);
+
+/* ---- optimiser: torch.nn.utils.clip_grad_norm + torch.optim.Adam.step (model.py:447-452, 510-515)
+ *      on one flat fp32 buffer per network. ---- */
+int acg_sumsq(const float *g, size_t n, float *out, void *workspace, size_t ws_bytes, void *stream);
+/* coef = min(1, max_norm/(sqrt(*sumsq)+1e-6)) read on device; p,m,v updated in place; g is NOT modified
+ * unless scale_grads != 0 (then g *= coef, matching the reference's in-place clip). */
+int acg_adam_step(float *p, float *g, float *m, float *v, size_t n, const float *sumsq, float max_norm, float lr,
+                  float beta1, float beta2, float eps, int step, int scale_grads, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACGAN_HIP_H */
