@@ -1,0 +1,105 @@
+"""ctypes binding of libacgan_hip.so (C ABI declared in include/acgan_hip.h).
+
+The shared object is built in-tree (csrc/Makefile, `__graft_entry__.build()`); there is
+no CPU or eager fallback: if the library is missing or a kernel call fails, this module
+raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libacgan_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+PAD_ZERO, PAD_REFLECT = 0, 1
+IMPL_MFMA, IMPL_DIRECT = 0, 1
+
+c_int, c_float, c_size_t, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
+
+
+class ConvDesc(ctypes.Structure):
+    """acg_conv_desc (include/acgan_hip.h)."""
+    _fields_ = [(k, c_int) for k in ("N", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "K", "stride", "pad", "pad_mode")]
+
+
+_P = c_void_p
+_D = ctypes.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); every symbol the header declares
+SIGNATURES = {
+    "acg_version": (c_int, []),
+    "acg_last_error": (ctypes.c_char_p, []),
+    "acg_set_conv_impl": (c_int, [c_int]),
+    "acg_nchw_to_nhwc16": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "acg_nhwc16_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "acg_concat_channels": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_size_t, _P]),
+    "acg_split_channels": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, c_int, c_size_t, _P]),
+    "acg_ncols_pad": (c_int, [c_int]),
+    "acg_packed_wf_elems": (c_size_t, [c_int, c_int, c_int]),
+    "acg_packed_wb_elems": (c_size_t, [c_int, c_int, c_int]),
+    "acg_pack_conv_weight": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "acg_pad_vector": (c_int, [_P, c_int, _P, c_int, _P]),
+    "acg_conv2d_fwd": (c_int, [_D, _P, _P, _P, _P, c_int, _P]),
+    "acg_conv2d_bwd_data_workspace_bytes": (c_size_t, [_D]),
+    "acg_conv2d_bwd_data": (c_int, [_D, _P, _P, _P, _P, c_size_t, _P]),
+    "acg_conv2d_bwd_weight_workspace_bytes": (c_size_t, [_D]),
+    "acg_conv2d_bwd_weight": (c_int, [_D, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
+    "acg_conv_transpose2d_fwd": (c_int, [_D, _P, _P, _P, _P, c_int, _P]),
+    "acg_conv_transpose2d_bwd_data": (c_int, [_D, _P, _P, _P, _P]),
+    "acg_conv_transpose2d_bwd_weight": (c_int, [_D, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
+    "acg_norm_workspace_bytes": (c_size_t, [c_int, c_size_t, c_int]),
+    "acg_norm_stats": (c_int, [_P, c_int, c_size_t, c_int, c_float, c_int, _P, _P, _P, _P, c_float, _P, c_size_t, _P]),
+    "acg_norm_apply": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_size_t, c_int, c_int, _P]),
+    "acg_norm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_size_t, c_int, c_int, c_int,
+                             _P, c_size_t, _P]),
+    "acg_act_bwd": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
+    "acg_add": (c_int, [_P, _P, _P, c_size_t, _P]),
+    "acg_linear_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "acg_linear_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "acg_spatial_mean_fwd": (c_int, [_P, _P, c_int, c_size_t, c_int, _P]),
+    "acg_spatial_mean_bwd": (c_int, [_P, _P, c_int, c_size_t, c_int, _P]),
+    "acg_reduce_workspace_bytes": (c_size_t, [c_size_t]),
+    "acg_mse_const_fwd": (c_int, [_P, c_size_t, c_int, c_int, c_float, _P, _P, c_size_t, _P]),
+    "acg_mse_const_bwd": (c_int, [_P, c_size_t, c_int, c_int, c_float, _P, _P, _P]),
+    "acg_l1_fwd": (c_int, [_P, _P, c_size_t, c_int, c_int, _P, _P, c_size_t, _P]),
+    "acg_l1_bwd": (c_int, [_P, _P, c_size_t, c_int, c_int, _P, _P, _P, _P]),
+    "acg_mean_fwd": (c_int, [_P, c_size_t, c_int, c_int, _P, _P, c_size_t, _P]),
+    "acg_sumsq": (c_int, [_P, c_size_t, _P, _P, c_size_t, _P]),
+    "acg_adam_step": (c_int, [_P, _P, _P, _P, c_size_t, _P, c_float, c_float, c_float, c_float, c_float, c_int,
+                              c_int, _P]),
+}
+
+_lib = None
+
+
+class AcgError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libacgan_hip.so and bind every declared symbol.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AcgError("libacgan_hip.so not found at %s — build it with `make -C %s` "
+                       "(or __graft_entry__.build()); there is no fallback path." % (LIB_PATH, os.path.join(_HERE, "csrc")))
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; negative status -> AcgError(acg_last_error())."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise AcgError("%s failed (%d): %s" % (name, rc, lib.acg_last_error().decode()))
+
+
+def query(name, *args):
+    """Invoke a value-returning entry point (sizes, versions)."""
+    return getattr(load(), name)(*args)

@@ -1,0 +1,686 @@
+"""Training-step orchestration — the API surface of /root/reference/augmented_cyclegan/model.py
+(StochCycleGAN, AugmentedCycleGAN with train_instance / supervised_train_instance / generate_* /
+predict_* / save / load / update_learning_rate / eval / train, plus the loss helpers), running on
+the HIP kernels of libacgan_hip.so.
+
+What differs from the reference, by design:
+  * train_instance returns python floats exactly like the reference, but gathers all 13 losses and
+    the monitors with ONE device->host copy per step instead of 19 syncs;
+  * per-network clip_grad_norm + Adam are one fused kernel per network on flat buffers, the clip
+    coefficient is read on the device;
+  * in the G phase the discriminators' (discarded) weight gradients are not computed;
+  * multi-GPU = one process per GPU, gradients averaged by RCCL all-reduce before clipping (dist.py).
+Aliases for the north-star names: AugmentedCycleGAN_Model, .optimize_parameters(), .set_input().
+"""
+import functools  # noqa: F401
+import math
+import os
+from collections import OrderedDict
+
+import numpy as np  # noqa: F401
+import torch
+
+from . import dist as acg_dist
+from . import networks, ops
+from .modules import as_latent, mark_dirty
+from .ops import cpad
+
+
+# ------------------------------------------------------------------------------------------------
+# loss helpers (model.py:15-72) — tensor functions, autograd-capable, device-agnostic
+# ------------------------------------------------------------------------------------------------
+def gauss_reparametrize(mu, logvar, n_sample=1):
+    """model.py:15-22"""
+    std = logvar.mul(0.5).exp()
+    size = std.size()
+    eps = std.new_empty((size[0], n_sample, size[1])).normal_()
+    z = eps.mul(std[:, None, :]).add(mu[:, None, :])
+    z = torch.clamp(z, -4., 4.)
+    return z.view(z.size(0) * z.size(1), z.size(2), 1, 1)
+
+
+def log_prob_laplace(z, mu, log_var):
+    """model.py:24-28"""
+    sd = torch.exp(0.5 * log_var)
+    res = - 0.5 * log_var - (torch.abs(z - mu) / sd)
+    return res + (-math.log(2))
+
+
+def log_prob_gaussian(z, mu, log_var):
+    """model.py:31-34"""
+    res = - 0.5 * log_var - ((z - mu) ** 2.0 / (2.0 * torch.exp(log_var)))
+    return res - 0.5 * math.log(2 * math.pi)
+
+
+def kld_std_guss(mu, log_var):
+    """model.py:45-53"""
+    return -0.5 * torch.sum(log_var + 1. - mu ** 2 - torch.exp(log_var), dim=1)
+
+
+def criterion_GAN(pred, target_is_real, use_sigmoid=True):
+    """model.py:56-72.  `pred` is an NCHW / (N,1) tensor (public API form)."""
+    if use_sigmoid:
+        raise NotImplementedError("use_sigmoid (--no_lsgan): the reference's BCE branch builds a Long target and fails "
+                                  "on modern torch (model.py:59-63); only LSGAN is implemented")
+    t = 1.0 if target_is_real else 0.0
+    p = pred.reshape(-1, 1).contiguous()
+    return ops.MseConst.apply(_pad_cols(p, 4), 1, t)
+
+
+def _pad_cols(p, Cp):
+    out = p.new_zeros((p.shape[0], Cp))
+    out[:, :p.shape[1]] = p
+    return out
+
+
+def _gan_loss(pred_c16, target_is_real):
+    """LSGAN on an internal C16 prediction map (1 valid channel)."""
+    return ops.MseConst.apply(pred_c16, 1, 1.0 if target_is_real else 0.0)
+
+
+# ------------------------------------------------------------------------------------------------
+# flat parameter storage + fused clip/Adam
+# ------------------------------------------------------------------------------------------------
+class FlatNet(object):
+    """All parameters (and their .grad) of one network as views into single flat fp32 buffers —
+    what the fused l2-norm / clip / Adam kernels and the RCCL all-reduce operate on."""
+
+    def __init__(self, net):
+        self.net = net
+        self.params = [p for p in net.parameters()]
+        dev = self.params[0].device
+        offs, n = [], 0
+        for p in self.params:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        self.n = n
+        self.p = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.g = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.m = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.v = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.offs = offs
+        with torch.no_grad():
+            for p, o in zip(self.params, offs):
+                self.p[o:o + p.numel()].copy_(p.reshape(-1))
+                p.data = self.p[o:o + p.numel()].view(p.shape)
+                p.grad = self.g[o:o + p.numel()].view(p.shape)
+        self.sumsq = torch.zeros((), device=dev, dtype=torch.float32)
+        mark_dirty(net)
+
+    def check(self):
+        p0 = self.params[0]
+        if p0.data_ptr() != self.p.data_ptr() or p0.grad is None or p0.grad.data_ptr() != self.g.data_ptr():
+            raise RuntimeError("network parameters were re-allocated after the model was built (e.g. .cuda()/.to()); "
+                               "build the model on its final device")
+
+    def zero_grad(self):
+        self.g.zero_()
+
+    def set_requires_grad(self, flag):
+        for p in self.params:
+            p.requires_grad_(flag)
+
+
+class FusedAdam(object):
+    """torch.optim.Adam(lr, betas=(beta1, 0.999)) over one or more FlatNets, with the reference's
+    per-network clip_grad_norm folded in (model.py:379-389, 447-452, 510-515).
+    Exposes `param_groups` (update_learning_rate mutates 'lr') and torch-compatible state dicts."""
+
+    def __init__(self, flats, lr, betas, eps=1e-8):
+        self.flats = list(flats)
+        self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False)]
+        self.t = 0
+
+    def zero_grad(self):
+        for f in self.flats:
+            f.zero_grad()
+
+    def clip_and_step(self, max_norm):
+        """per network: sumsq -> (device) clip coefficient -> Adam.  Returns the sumsq scalars."""
+        g = self.param_groups[0]
+        self.t += 1
+        out = []
+        for f in self.flats:
+            ops.sumsq(f.g, f.sumsq)
+            out.append(f.sumsq)
+        for f in self.flats:
+            ops.adam_step(f.p, f.g, f.m, f.v, f.sumsq, max_norm, g['lr'], g['betas'][0], g['betas'][1], g['eps'], self.t)
+            mark_dirty(f.net)
+        return out
+
+    def state_dict(self):
+        state, idx = {}, 0
+        for f in self.flats:
+            for p, o in zip(f.params, f.offs):
+                n = p.numel()
+                state[idx] = dict(step=torch.tensor(float(self.t)), exp_avg=f.m[o:o + n].view(p.shape).clone(),
+                                  exp_avg_sq=f.v[o:o + n].view(p.shape).clone())
+                idx += 1
+        pg = dict(self.param_groups[0])
+        pg['params'] = list(range(idx))
+        return dict(state=state, param_groups=[pg])
+
+    def load_state_dict(self, sd):
+        idx = 0
+        for f in self.flats:
+            for p, o in zip(f.params, f.offs):
+                st = sd['state'].get(idx)
+                if st is not None:
+                    n = p.numel()
+                    f.m[o:o + n].copy_(st['exp_avg'].reshape(-1))
+                    f.v[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
+                    self.t = int(float(st['step']))
+                idx += 1
+        self.param_groups[0]['lr'] = sd['param_groups'][0]['lr']
+
+
+def _finish_scalars(names, tensors):
+    """one D2H copy for every reported scalar"""
+    vals = torch.stack([t.detach().reshape(()).float() for t in tensors]).tolist()
+    return OrderedDict(zip(names, vals))
+
+
+class _Base(object):
+    def _dev(self):
+        return next(self.netG_A_B.parameters()).device
+
+    def _nchw(self, x, C):
+        return ops.ToNCHW.apply(x, C).detach()
+
+    def _allreduce(self, flats):
+        if acg_dist.world_size() > 1:
+            acg_dist.allreduce_mean_([f.g for f in flats])
+
+    # ---- north-star aliases -----------------------------------------------------
+    def set_input(self, data, prior_z_B=None):
+        self._input = (data['A'], data['B'], prior_z_B)
+
+    def optimize_parameters(self):
+        A, B, z = self._input
+        if z is None:
+            z = torch.randn(A.size(0), self.opt.nlatent, 1, 1, device=A.device)
+        self._last = self.train_instance(A, B, z)
+        return self._last
+
+    def eval(self):
+        for n in self._nets():
+            n.eval()
+
+    def train(self):
+        for n in self._nets():
+            n.train()
+
+
+def _n_blocks(opt):
+    return int(getattr(opt, 'n_blocks', 3))
+
+
+class StochCycleGAN(_Base):
+    """Stochastic cycle gan — model.py:75-325"""
+
+    def __init__(self, opt, ignore_noise=False, testing=False):
+        self.ignore_noise = ignore_noise
+        self.old_lr = opt.lr
+        opt.use_sigmoid = opt.no_lsgan
+        self.opt = opt
+        nb = _n_blocks(opt)
+        self.netG_A_B = networks.define_stochastic_G(nlatent=opt.nlatent, input_nc=opt.input_nc, output_nc=opt.output_nc,
+                                                     ngf=opt.ngf, which_model_netG=opt.which_model_netG, norm=opt.norm,
+                                                     use_dropout=opt.use_dropout, gpu_ids=opt.gpu_ids, n_blocks=nb)
+        self.netG_B_A = networks.define_G(input_nc=opt.output_nc, output_nc=opt.input_nc, ngf=opt.ngf,
+                                          which_model_netG=opt.which_model_netG, norm=opt.norm,
+                                          use_dropout=opt.use_dropout, gpu_ids=opt.gpu_ids, n_blocks=nb)
+        self.netD_A = networks.define_D_A(input_nc=opt.input_nc, ndf=32, which_model_netD=opt.which_model_netD,
+                                          norm=opt.norm, use_sigmoid=opt.use_sigmoid, gpu_ids=opt.gpu_ids)
+        self.netD_B = networks.define_D_B(input_nc=opt.output_nc, ndf=opt.ndf, which_model_netD=opt.which_model_netD,
+                                          norm=opt.norm, use_sigmoid=opt.use_sigmoid, gpu_ids=opt.gpu_ids)
+        self._build_optimizers()
+        self.criterionGAN = functools.partial(criterion_GAN, use_sigmoid=opt.use_sigmoid)
+        self.criterionCycle = lambda a, b: ops.L1.apply(_as2d(a), _as2d(b), a.shape[1])
+        if not testing:
+            with open("%s/nets.txt" % opt.expr_dir, 'w') as nets_f:
+                for n in self._nets():
+                    networks.print_network(n, nets_f)
+
+    def _nets(self):
+        return [self.netG_A_B, self.netG_B_A, self.netD_A, self.netD_B]
+
+    def _build_optimizers(self):
+        o = self.opt
+        acg_dist.broadcast_params_(self._nets())
+        self.f_G_A_B, self.f_G_B_A = FlatNet(self.netG_A_B), FlatNet(self.netG_B_A)
+        self.f_D_A, self.f_D_B = FlatNet(self.netD_A), FlatNet(self.netD_B)
+        self.optimizer_G = FusedAdam([self.f_G_A_B, self.f_G_B_A], o.lr, (o.beta1, 0.999))      # model.py:109-111
+        self.optimizer_D = FusedAdam([self.f_D_A, self.f_D_B], o.lr / 5., (o.beta1, 0.999))     # model.py:112-114
+
+    def train_instance(self, real_A, real_B, prior_z_B):
+        o = self.opt
+        nA, nB = o.input_nc, o.output_nc
+        for f in (self.f_G_A_B, self.f_G_B_A, self.f_D_A, self.f_D_B):
+            f.check()
+        if self.ignore_noise:
+            prior_z_B = prior_z_B.mul(0.).add(1.)                                               # model.py:128-129
+        A, B, z = ops.ToNHWC.apply(real_A), ops.ToNHWC.apply(real_B), as_latent(prior_z_B)
+        fake_B = self.netG_A_B.forward_nhwc(A, z)
+        fake_A = self.netG_B_A.forward_nhwc(B)
+
+        # ---- D phase (model.py:139-162)
+        p_fA = self.netD_A.forward_nhwc(fake_A.detach()); l_fA = _gan_loss(p_fA, False)
+        p_tA = self.netD_A.forward_nhwc(A); l_tA = _gan_loss(p_tA, True)
+        p_fB = self.netD_B.forward_nhwc(fake_B.detach()); l_fB = _gan_loss(p_fB, False)
+        p_tB = self.netD_B.forward_nhwc(B); l_tB = _gan_loss(p_tB, True)
+        loss_D_A, loss_D_B = 0.5 * (l_fA + l_tA), 0.5 * (l_fB + l_tB)
+        loss_D = loss_D_A + loss_D_B
+        self.optimizer_D.zero_grad()
+        loss_D.backward()
+        self._allreduce(self.optimizer_D.flats)
+        ss_D_A, ss_D_B = self.optimizer_D.clip_and_step(o.max_gnorm)
+        ss_D_A, ss_D_B = ss_D_A.clone(), ss_D_B.clone()
+        m_tA, m_tB = ops.mean_valid(p_tA, 1), ops.mean_valid(p_tB, 1)
+
+        # ---- G phase with the UPDATED discriminators (model.py:167-190); D weight grads are not needed
+        self.f_D_A.set_requires_grad(False); self.f_D_B.set_requires_grad(False)
+        try:
+            p_fA = self.netD_A.forward_nhwc(fake_A); loss_G_A = _gan_loss(p_fA, True)
+            p_fB = self.netD_B.forward_nhwc(fake_B); loss_G_B = _gan_loss(p_fB, True)
+            rec_A = self.netG_B_A.forward_nhwc(fake_B); loss_cycle_A = ops.L1.apply(rec_A, A, nA)
+            rec_B = self.netG_A_B.forward_nhwc(fake_A, z); loss_cycle_B = ops.L1.apply(rec_B, B, nB)
+            loss_G = loss_G_A + loss_G_B + loss_cycle_A * o.lambda_A + loss_cycle_B * o.lambda_B
+            self.optimizer_G.zero_grad()
+            loss_G.backward()
+        finally:
+            self.f_D_A.set_requires_grad(True); self.f_D_B.set_requires_grad(True)
+        self._allreduce(self.optimizer_G.flats)
+        ss_G_A_B, ss_G_B_A = self.optimizer_G.clip_and_step(o.max_gnorm)
+
+        names = ['D_A', 'G_A', 'Cyc_A', 'D_B', 'G_B', 'Cyc_B', 'P_t_A', 'P_f_A', 'P_t_B', 'P_f_B',
+                 'gnorm_G_A_B', 'gnorm_G_B_A', 'gnorm_D_B', 'gnorm_D_A']
+        vals = _finish_scalars(names, [loss_D_A, loss_G_A, loss_cycle_A, loss_D_B, loss_G_B, loss_cycle_B,
+                                       m_tA, ops.mean_valid(p_fA, 1), m_tB, ops.mean_valid(p_fB, 1),
+                                       ss_G_A_B, ss_G_B_A, ss_D_B, ss_D_A])
+        vals = acg_dist.average_scalars(vals, sq_keys=names[10:])
+        losses = OrderedDict((k, vals[k]) for k in names[:10])                                   # model.py:193-196
+        visuals = OrderedDict([('real_A', real_A.detach()), ('fake_B', self._nchw(fake_B, nB)),
+                               ('rec_A', self._nchw(rec_A, nA)), ('real_B', real_B.detach()),
+                               ('fake_A', self._nchw(fake_A, nA)), ('rec_B', self._nchw(rec_B, nB))])
+        if o.monitor_gnorm:
+            gnorms = OrderedDict((k, math.sqrt(max(vals[k], 0.0))) for k in names[10:])          # model.py:202-205
+            return losses, visuals, gnorms
+        return losses, visuals
+
+    # ---- forward-only helpers (model.py:210-280) -------------------------------------------
+    def _z(self, z):
+        return z.mul(0.).add(1.) if self.ignore_noise else z
+
+    def generate_cycle(self, real_A, real_B, prior_z_B):
+        z = self._z(prior_z_B)
+        fake_B = self.netG_A_B.forward(real_A, z)
+        fake_A = self.netG_B_A.forward(real_B)
+        rec_A = self.netG_B_A.forward(fake_B)
+        rec_B = self.netG_A_B.forward(fake_A, z)
+        return OrderedDict([('real_A', real_A.data), ('fake_B', fake_B.data), ('rec_A', rec_A.data),
+                            ('real_B', real_B.data), ('fake_A', fake_A.data), ('rec_B', rec_B.data)])
+
+    def generate_multi_cycle(self, real_B, steps):
+        images = [real_B.data]
+        B = real_B
+        for i in range(steps):
+            A = self.netG_B_A.forward(B)
+            z_B = self._z(real_B.new_empty((real_B.size(0), self.opt.nlatent, 1, 1)).normal_(0, 1))
+            B = self.netG_A_B.forward(A, z_B)
+            images.extend([A.data, B.data])
+        return images
+
+    def generate_cycle_B_multi(self, real_B, multi_prior_z_B):
+        fake_A = self.netG_B_A.forward(real_B)
+        size = real_B.size()
+        num = multi_prior_z_B.size(0) // real_B.size(0)
+        multi_fake_A = fake_A.unsqueeze(1).repeat(1, num, 1, 1, 1).view(size[0] * num, size[1], size[2], size[3])
+        return fake_A, self.netG_A_B.forward(multi_fake_A, multi_prior_z_B)
+
+    def generate_noisy_cycle(self, real_B, std):
+        fake_A = self.netG_B_A.forward(real_B)
+        z_B = self._z(real_B.new_empty((real_B.size(0), self.opt.nlatent, 1, 1)).normal_(0, 1))
+        noisy = torch.clamp(fake_A + torch.empty_like(fake_A).normal_(0, std / 127.5), -1, 1)
+        return self.netG_A_B.forward(noisy, z_B)
+
+    def predict_A(self, real_B):
+        return self.netG_B_A.forward(real_B)
+
+    def predict_B(self, real_A, z_B):
+        return self.netG_A_B.forward(real_A, self._z(z_B))
+
+    def generate_multi(self, real_A, multi_prior_z_B):
+        multi_prior_z_B = self._z(multi_prior_z_B)
+        size = real_A.size()
+        num = multi_prior_z_B.size(0) // real_A.size(0)
+        multi_real_A = real_A.unsqueeze(1).repeat(1, num, 1, 1, 1).view(size[0] * num, size[1], size[2], size[3])
+        return self.netG_A_B.forward(multi_real_A, multi_prior_z_B)
+
+    def _optimizers(self):
+        return OrderedDict([('optimizer_D', self.optimizer_D), ('optimizer_G', self.optimizer_G)])
+
+    def _net_dict(self):
+        return OrderedDict([('netG_A_B', self.netG_A_B), ('netG_B_A', self.netG_B_A), ('netD_A', self.netD_A),
+                            ('netD_B', self.netD_B)])
+
+    def update_learning_rate(self):
+        """model.py:282-291 (also overwrites the discriminators' lr/5 — reference behaviour)"""
+        lrd = self.opt.lr / self.opt.niter_decay
+        lr = self.old_lr - lrd
+        for opt in self._optimizers().values():
+            for param_group in opt.param_groups:
+                param_group['lr'] = lr
+        print('update learning rate: %f -> %f' % (self.old_lr, lr))
+        self.old_lr = lr
+
+    def save(self, chk_name):
+        """model.py:293-303 / 750-764: same checkpoint keys, torch.load-able"""
+        chk_path = os.path.join(self.opt.expr_dir, chk_name)
+        checkpoint = {k: n.state_dict() for k, n in self._net_dict().items()}
+        checkpoint.update({k: o.state_dict() for k, o in self._optimizers().items()})
+        torch.save(checkpoint, chk_path)
+
+    def load(self, chk_path):
+        checkpoint = torch.load(chk_path, map_location=self._dev())
+        for k, n in self._net_dict().items():
+            n.load_state_dict(checkpoint[k])
+            mark_dirty(n)
+        for k, o in self._optimizers().items():
+            o.load_state_dict(checkpoint[k])
+
+
+def _as2d(t):
+    """public-API tensors (NCHW / (N,C)) -> (rows, Cp) C16 view for the loss kernels"""
+    if t.dim() == 4:
+        return ops.ToNHWC.apply(t).reshape(-1, cpad(t.shape[1]))
+    return t.reshape(t.shape[0], -1)
+
+
+def discriminate(net, crit, fake, real):
+    """model.py:327-334 (public-API form)"""
+    pred_fake = net(fake)
+    loss_fake = crit(pred_fake, False)
+    pred_true = net(real)
+    loss_true = crit(pred_true, True)
+    return loss_fake, loss_true, pred_fake, pred_true
+
+
+class AugmentedCycleGAN(_Base):
+    """Augmented cycle gan — model.py:337-794"""
+
+    def __init__(self, opt, testing=False):
+        self.old_lr = opt.lr
+        opt.use_sigmoid = opt.no_lsgan
+        self.opt = opt
+        nb = _n_blocks(opt)
+        self.netG_A_B = networks.define_stochastic_G(nlatent=opt.nlatent, input_nc=opt.input_nc, output_nc=opt.output_nc,
+                                                     ngf=opt.ngf, which_model_netG=opt.which_model_netG, norm=opt.norm,
+                                                     use_dropout=opt.use_dropout, gpu_ids=opt.gpu_ids, n_blocks=nb)
+        self.netG_B_A = networks.define_G(input_nc=opt.output_nc, output_nc=opt.input_nc, ngf=opt.ngf,
+                                          which_model_netG=opt.which_model_netG, norm=opt.norm,
+                                          use_dropout=opt.use_dropout, gpu_ids=opt.gpu_ids, n_blocks=nb)
+        enc_input_nc = opt.output_nc
+        if opt.enc_A_B:
+            enc_input_nc += opt.input_nc
+        self.netE_B = networks.define_E(nlatent=opt.nlatent, input_nc=enc_input_nc, nef=opt.nef, norm='batch',
+                                        gpu_ids=opt.gpu_ids)
+        self.netD_A = networks.define_D_A(input_nc=opt.input_nc, ndf=32, which_model_netD=opt.which_model_netD,
+                                          norm=opt.norm, use_sigmoid=opt.use_sigmoid, gpu_ids=opt.gpu_ids)
+        self.netD_B = networks.define_D_B(input_nc=opt.output_nc, ndf=opt.ndf, which_model_netD=opt.which_model_netD,
+                                          norm=opt.norm, use_sigmoid=opt.use_sigmoid, gpu_ids=opt.gpu_ids)
+        self.netD_z_B = networks.define_LAT_D(nlatent=opt.nlatent, ndf=opt.ndf, use_sigmoid=opt.use_sigmoid,
+                                              gpu_ids=opt.gpu_ids)
+        self._build_optimizers()
+        self.criterionGAN = functools.partial(criterion_GAN, use_sigmoid=opt.use_sigmoid)
+        self.criterionCycle = lambda a, b: ops.L1.apply(_as2d(a), _as2d(b), a.shape[1])
+        if not testing:
+            with open("%s/nets.txt" % opt.expr_dir, 'w') as nets_f:
+                for n in (self.netG_A_B, self.netG_B_A, self.netD_A, self.netD_B, self.netD_z_B, self.netE_B):
+                    networks.print_network(n, nets_f)                                           # model.py:393-400
+
+    def _nets(self):
+        return [self.netG_A_B, self.netG_B_A, self.netE_B, self.netD_A, self.netD_B, self.netD_z_B]
+
+    def _build_optimizers(self):
+        o = self.opt
+        acg_dist.broadcast_params_(self._nets())
+        self.f_G_A_B, self.f_G_B_A, self.f_E_B = FlatNet(self.netG_A_B), FlatNet(self.netG_B_A), FlatNet(self.netE_B)
+        self.f_D_A, self.f_D_B, self.f_D_z_B = FlatNet(self.netD_A), FlatNet(self.netD_B), FlatNet(self.netD_z_B)
+        b = (o.beta1, 0.999)
+        self.optimizer_G_A = FusedAdam([self.f_G_B_A], o.lr, b)                                 # model.py:379-380
+        self.optimizer_G_B = FusedAdam([self.f_G_A_B, self.f_E_B], o.lr, b)                     # model.py:381-383
+        self.optimizer_D_A = FusedAdam([self.f_D_A], o.lr / 5., b)                              # model.py:384-385
+        self.optimizer_D_B = FusedAdam([self.f_D_B, self.f_D_z_B], o.lr / 5., b)                # model.py:386-389
+
+    def _encode(self, a_or_fake_a, b):
+        """E_B on cat((A-side, B-side), 1) (A first: model.py:410, 472) -> (mu, logvar) (N, cpad(nl))"""
+        o = self.opt
+        x = ops.Concat.apply(a_or_fake_a, b, o.input_nc, o.output_nc) if o.enc_A_B else b
+        return self.netE_B.forward_nhwc(x)
+
+    def train_instance(self, real_A, real_B, prior_z_B):
+        o = self.opt
+        nA, nB, nl = o.input_nc, o.output_nc, o.nlatent
+        flats_D = [self.f_D_A, self.f_D_B, self.f_D_z_B]
+        for f in flats_D + [self.f_G_A_B, self.f_G_B_A, self.f_E_B]:
+            f.check()
+        A, B, z = ops.ToNHWC.apply(real_A), ops.ToNHWC.apply(real_B), as_latent(prior_z_B)
+        bs = z.shape[0]
+
+        fake_B = self.netG_A_B.forward_nhwc(A, z)                                               # model.py:404
+        fake_A = self.netG_B_A.forward_nhwc(B)                                                  # model.py:407
+        mu_rB, lv_rB = self._encode(fake_A, B)                                                  # model.py:409-413
+        if o.stoch_enc:
+            post_z = gauss_reparametrize(mu_rB[:, :nl], lv_rB[:, :nl]).view(bs, nl)             # model.py:416
+        else:
+            post_z = mu_rB                                                                      # model.py:418
+            lv_rB = lv_rB * 0.0                                                                 # model.py:419
+
+        # ---- D phase (model.py:423-452)
+        p_fA = self.netD_A.forward_nhwc(fake_A.detach()); l_fA = _gan_loss(p_fA, False)
+        p_tA = self.netD_A.forward_nhwc(A); l_tA = _gan_loss(p_tA, True)
+        p_fB = self.netD_B.forward_nhwc(fake_B.detach()); l_fB = _gan_loss(p_fB, False)
+        p_tB = self.netD_B.forward_nhwc(B); l_tB = _gan_loss(p_tB, True)
+        l_pz = _gan_loss(self.netD_z_B.forward_dense(post_z.detach()), False)
+        l_rz = _gan_loss(self.netD_z_B.forward_dense(z), True)
+        loss_D_A, loss_D_B, loss_D_z_B = 0.5 * (l_fA + l_tA), 0.5 * (l_fB + l_tB), 0.5 * (l_pz + l_rz)
+        loss_D = loss_D_A + loss_D_B
+        if o.z_gan and not o.stoch_enc:
+            loss_D = loss_D + loss_D_z_B
+        self.optimizer_D_A.zero_grad(); self.optimizer_D_B.zero_grad()
+        loss_D.backward()
+        self._allreduce(flats_D)
+        (ss_D_A,) = self.optimizer_D_A.clip_and_step(o.max_gnorm)
+        ss_D_B, ss_D_z = self.optimizer_D_B.clip_and_step(o.max_gnorm)
+        ss_D_A, ss_D_B, ss_D_z = ss_D_A.clone(), ss_D_B.clone(), ss_D_z.clone()
+        m_tA, m_tB = ops.mean_valid(p_tA, 1), ops.mean_valid(p_tB, 1)
+
+        # ---- G phase with the UPDATED discriminators (model.py:457-515)
+        for f in flats_D:
+            f.set_requires_grad(False)
+        try:
+            p_fA = self.netD_A.forward_nhwc(fake_A); loss_G_A = _gan_loss(p_fA, True)
+            p_fB = self.netD_B.forward_nhwc(fake_B); loss_G_B = _gan_loss(p_fB, True)
+            loss_G_z_B = _gan_loss(self.netD_z_B.forward_dense(post_z), True)
+            rec_A = self.netG_B_A.forward_nhwc(fake_B); loss_cycle_A = ops.L1.apply(rec_A, A, nA)
+            mu_fB, lv_fB = self._encode(A, fake_B)                                              # model.py:471-475
+            if o.stoch_enc:
+                lp = log_prob_gaussian(z, mu_fB[:, :nl], lv_fB[:, :nl])
+                loss_cycle_z_B = -1.0 * lp.mean(1).mean(0)                                      # model.py:480-484
+            else:
+                loss_cycle_z_B = ops.L1.apply(mu_fB, _pad_cols(z, mu_fB.shape[1]), nl)          # model.py:486-487
+            rec_B = self.netG_A_B.forward_nhwc(fake_A, post_z); loss_cycle_B = ops.L1.apply(rec_B, B, nB)
+            loss_G = loss_G_A + loss_G_B + loss_cycle_A * o.lambda_A + loss_cycle_B * o.lambda_B \
+                + loss_cycle_z_B * o.lambda_z_B
+            kld_z_B = kld_std_guss(mu_rB[:, :nl], lv_rB[:, :nl]).mean(0)                        # model.py:490
+            if o.stoch_enc:
+                loss_G = loss_G + kld_z_B * o.lambda_z_B
+            if o.z_gan and not o.stoch_enc:
+                loss_G = loss_G + loss_G_z_B
+            self.optimizer_G_A.zero_grad(); self.optimizer_G_B.zero_grad()
+            loss_G.backward()
+        finally:
+            for f in flats_D:
+                f.set_requires_grad(True)
+        self._allreduce([self.f_G_B_A, self.f_G_A_B, self.f_E_B])
+        (ss_G_B_A,) = self.optimizer_G_A.clip_and_step(o.max_gnorm)
+        ss_G_A_B, ss_E = self.optimizer_G_B.clip_and_step(o.max_gnorm)
+
+        mu_v, lv_v = mu_rB.detach()[:, :nl], lv_rB.detach()[:, :nl]
+        names = ['D_A', 'G_A', 'Cyc_A', 'Cyc_z_B', 'KLD_z_B', 'D_B', 'G_B', 'Cyc_B', 'D_z_B',
+                 'P_t_A', 'P_f_A', 'P_t_B', 'P_f_B',
+                 'gnorm_G_A_B', 'gnorm_G_B_A', 'gnorm_E_B', 'gnorm_D_B', 'gnorm_D_z_B', 'gnorm_D_A',
+                 'mu_min', 'mu_max', 'logvar_min', 'logvar_max']
+        vals = _finish_scalars(names, [loss_D_A, loss_G_A, loss_cycle_A, loss_cycle_z_B, kld_z_B, loss_D_B, loss_G_B,
+                                       loss_cycle_B, loss_D_z_B, m_tA, ops.mean_valid(p_fA, 1), m_tB,
+                                       ops.mean_valid(p_fB, 1), ss_G_A_B, ss_G_B_A, ss_E, ss_D_B, ss_D_z, ss_D_A,
+                                       mu_v.min(), mu_v.max(), lv_v.min(), lv_v.max()])
+        vals = acg_dist.average_scalars(vals, sq_keys=names[13:19], min_keys=['mu_min', 'logvar_min'],
+                                        max_keys=['mu_max', 'logvar_max'])
+        losses = OrderedDict((k, vals[k]) for k in names[:13])                                  # model.py:518-523
+        visuals = OrderedDict([('real_A', real_A.detach()), ('fake_B', self._nchw(fake_B, nB)),
+                               ('rec_A', self._nchw(rec_A, nA)), ('real_B', real_B.detach()),
+                               ('fake_A', self._nchw(fake_A, nA)), ('rec_B', self._nchw(rec_B, nB))])
+        if o.monitor_gnorm:
+            gnorms = OrderedDict((k, math.sqrt(max(vals[k], 0.0))) for k in names[13:19])       # model.py:527-533
+            for k in names[19:]:
+                gnorms[k] = vals[k]
+            return losses, visuals, gnorms
+        return losses, visuals
+
+    def supervised_train_instance(self, real_A, real_B, prior_z_B):
+        """model.py:541-604 (paired step; off by default, --supervised)"""
+        o = self.opt
+        nA, nB, nl = o.input_nc, o.output_nc, o.nlatent
+        A, B, z = ops.ToNHWC.apply(real_A), ops.ToNHWC.apply(real_B), as_latent(prior_z_B)
+        bs = z.shape[0]
+        mu, logvar = self._encode(A, B)
+        if o.stoch_enc:
+            post_z = gauss_reparametrize(mu[:, :nl], logvar[:, :nl]).view(bs, nl)
+        else:
+            post_z = mu
+            logvar = logvar * 0.0
+        l_pz = _gan_loss(self.netD_z_B.forward_dense(post_z.detach()), False)
+        l_rz = _gan_loss(self.netD_z_B.forward_dense(z), True)
+        loss_D_z_B = 0.5 * (l_pz + l_rz)
+        self.optimizer_D_B.zero_grad()
+        loss_D_z_B.backward()
+        self._allreduce([self.f_D_B, self.f_D_z_B])
+        _, ss_D_z = self.optimizer_D_B.clip_and_step(o.max_gnorm)
+        ss_D_z = ss_D_z.clone()
+        self.f_D_z_B.set_requires_grad(False)
+        try:
+            pred_B = self.netG_A_B.forward_nhwc(A, post_z)
+            pred_A = self.netG_B_A.forward_nhwc(B)
+            loss_sup_A = ops.L1.apply(pred_A, A, nA)
+            loss_sup_B = ops.L1.apply(pred_B, B, nB)
+            loss_G_z_B = _gan_loss(self.netD_z_B.forward_dense(post_z), True)
+            kld_z_B = kld_std_guss(mu[:, :nl], logvar[:, :nl]).mean(0)
+            loss_G = loss_sup_A * o.lambda_sup_A + loss_sup_B * o.lambda_sup_B
+            if o.stoch_enc:
+                loss_G = loss_G + kld_z_B * o.lambda_z_B
+            if o.z_gan and not o.stoch_enc:
+                loss_G = loss_G + loss_G_z_B
+            self.optimizer_G_A.zero_grad(); self.optimizer_G_B.zero_grad()
+            loss_G.backward()
+        finally:
+            self.f_D_z_B.set_requires_grad(True)
+        self._allreduce([self.f_G_B_A, self.f_G_A_B, self.f_E_B])
+        (ss_G_B_A,) = self.optimizer_G_A.clip_and_step(o.max_gnorm)
+        ss_G_A_B, ss_E = self.optimizer_G_B.clip_and_step(o.max_gnorm)
+        names = ['S_A', 'S_B', 'KLD_z_B', 'D_z_B', 'gnorm_G_A_B', 'gnorm_G_B_A', 'gnorm_E_B', 'gnorm_D_z_B']
+        vals = _finish_scalars(names, [loss_sup_A, loss_sup_B, kld_z_B, loss_D_z_B, ss_G_A_B, ss_G_B_A, ss_E, ss_D_z])
+        vals = acg_dist.average_scalars(vals, sq_keys=names[4:])
+        for k in names[4:]:
+            vals[k] = math.sqrt(max(vals[k], 0.0))
+        return vals                                                                             # model.py:596-604
+
+    # ---- forward-only helpers (model.py:606-733) -------------------------------------------
+    def _enc_public(self, a, b):
+        x = torch.cat((a, b), 1) if self.opt.enc_A_B else b
+        return self.netE_B.forward(x)
+
+    def _post_z(self, mu, logvar):
+        if self.opt.stoch_enc:
+            return gauss_reparametrize(mu, logvar)
+        return mu.reshape(mu.size(0), mu.size(1), 1, 1)
+
+    def generate_cycle(self, real_A, real_B, prior_z_B):
+        fake_B = self.netG_A_B.forward(real_A, prior_z_B)
+        fake_A = self.netG_B_A.forward(real_B)
+        rec_A = self.netG_B_A.forward(fake_B)
+        mu, logvar = self._enc_public(fake_A, real_B)
+        rec_B = self.netG_A_B.forward(fake_A, self._post_z(mu, logvar))
+        return OrderedDict([('real_A', real_A.data), ('fake_B', fake_B.data), ('rec_A', rec_A.data),
+                            ('real_B', real_B.data), ('fake_A', fake_A.data), ('rec_B', rec_B.data)])
+
+    def generate_noisy_cycle(self, real_B, std):
+        fake_A = self.netG_B_A.forward(real_B)
+        noisy = torch.clamp(fake_A + torch.empty_like(fake_A).normal_(0, std / 127.5), -1, 1)
+        mu, logvar = self._enc_public(fake_A, real_B)
+        return self.netG_A_B.forward(noisy, self._post_z(mu, logvar))
+
+    def predict_A(self, real_B):
+        return self.netG_B_A.forward(real_B)
+
+    def predict_B(self, real_A, z_B):
+        return self.netG_A_B.forward(real_A, z_B)
+
+    def predict_enc_params(self, real_A, real_B):
+        mu, logvar = self._enc_public(real_A, real_B)
+        if self.opt.stoch_enc:
+            return mu, logvar
+        return (mu,)
+
+    def generate_multi_cycle(self, real_B, steps, from_prior=True):
+        images = [real_B.data]
+        B = real_B
+        for i in range(steps):
+            A = self.netG_B_A.forward(B)
+            if from_prior:
+                z_B = real_B.new_empty((real_B.size(0), self.opt.nlatent, 1, 1)).normal_(0, 1)
+            else:
+                z_B = self._post_z(*self._enc_public(A, B))
+            B = self.netG_A_B.forward(A, z_B)
+            images.extend([A.data, B.data])
+        return images
+
+    def generate_multi(self, real_A, multi_prior_z_B):
+        size = real_A.size()
+        num = multi_prior_z_B.size(0) // real_A.size(0)
+        multi_real_A = real_A.unsqueeze(1).repeat(1, num, 1, 1, 1).view(size[0] * num, size[1], size[2], size[3])
+        return self.netG_A_B.forward(multi_real_A, multi_prior_z_B)
+
+    def generate_cycle_B_multi(self, real_B, multi_prior_z_B):
+        fake_A = self.netG_B_A.forward(real_B)
+        size = real_B.size()
+        num = multi_prior_z_B.size(0) // real_B.size(0)
+        multi_fake_A = fake_A.unsqueeze(1).repeat(1, num, 1, 1, 1).view(size[0] * num, size[1], size[2], size[3])
+        return fake_A, self.netG_A_B.forward(multi_fake_A, multi_prior_z_B)
+
+    def inference_multi(self, real_A, real_B):
+        size = real_A.size()
+        num = real_B.size(0)
+        multi_real_A = real_A.unsqueeze(1).repeat(1, num, 1, 1, 1).view(size[0] * num, size[1], size[2], size[3])
+        fake_A = self.netG_B_A.forward(real_B) if self.opt.enc_A_B else real_B
+        mu, logvar = self._enc_public(fake_A, real_B)
+        post_z_B = self._post_z(mu, logvar)
+        multi_post_z_B = post_z_B.data.repeat(size[0], 1, 1, 1)
+        return self.netG_A_B.forward(multi_real_A, multi_post_z_B)
+
+    def _optimizers(self):
+        return OrderedDict([('optimizer_D_A', self.optimizer_D_A), ('optimizer_G_A', self.optimizer_G_A),
+                            ('optimizer_D_B', self.optimizer_D_B), ('optimizer_G_B', self.optimizer_G_B)])
+
+    def _net_dict(self):
+        return OrderedDict([('netG_A_B', self.netG_A_B), ('netG_B_A', self.netG_B_A), ('netD_A', self.netD_A),
+                            ('netD_B', self.netD_B), ('netD_z_B', self.netD_z_B), ('netE_B', self.netE_B)])
+
+    update_learning_rate = StochCycleGAN.update_learning_rate                                    # model.py:735-748
+    save = StochCycleGAN.save                                                                    # model.py:750-764
+    load = StochCycleGAN.load                                                                    # model.py:766-778
+
+
+# north-star alias (BASELINE.json names the class AugmentedCycleGAN_Model)
+AugmentedCycleGAN_Model = AugmentedCycleGAN

@@ -1,0 +1,440 @@
+"""Building blocks — same names, constructor signatures and state_dict keys as the reference's
+/root/reference/augmented_cyclegan/modules.py, executed by the HIP kernels in libacgan_hip.so.
+
+Every layer class keeps the torch.nn parameter layout (OIHW weights, etc.) so reference
+checkpoints load unchanged; `forward` on NCHW tensors is provided for drop-in use of a single
+module, while the networks run the fused NHWC pipeline in `run_sequence` below (conv + bias +
+activation in one kernel; norm + activation (+ residual add) in one pass).
+"""
+import functools  # noqa: F401  (kept: reference modules export it implicitly via networks)
+
+import torch
+import torch.nn as nn
+from torch.nn.parameter import Parameter
+
+from . import ops
+from .ops import ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, PAD_ZERO, PAD_REFLECT, cpad
+
+USE_PYTORCH_IN = False  # modules.py:9
+
+
+def mark_dirty(net):
+    """Parameters of `net` changed outside torch's version counter (fused Adam kernel):
+    drop the cached packed weights / padded vectors of all its layers."""
+    for m in net.modules():
+        if hasattr(m, "_acg_cache"):
+            m._acg_cache = None
+
+
+class _Cached(object):
+    """Mixin: per-layer cache of device-side derived forms, keyed on the parameters' versions."""
+    _acg_cache = None
+
+    def _cache_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters(recurse=False))
+
+    def _cached(self, build):
+        key = self._cache_key()
+        c = self._acg_cache
+        if c is None or c[0] != key:
+            c = (key, build())
+            self._acg_cache = c
+        return c[1]
+
+
+def _padded_vec(v, npad):
+    out = torch.empty(npad, device=v.device, dtype=torch.float32)
+    ops._lib.call("acg_pad_vector", ops._ptr(v.detach().contiguous()), v.numel(), ops._ptr(out), npad, ops._stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter-holding layers (torch.nn layouts / reprs / state_dict keys; HIP forward)
+# ------------------------------------------------------------------------------------------------
+class Conv2d(nn.Conv2d, _Cached):
+    """nn.Conv2d executed by acg_conv2d_fwd (implicit-GEMM MFMA)."""
+
+    def packed(self):
+        return self._cached(lambda: ops.PackedConv(self.weight, self.bias, cpad(self.in_channels), cpad(self.out_channels)))
+
+    def forward_nhwc(self, x, act=ACT_NONE, reflect_pad=0):
+        if reflect_pad:
+            pad, mode = reflect_pad, PAD_REFLECT
+        else:
+            pad, mode = self.padding[0], PAD_ZERO
+        return ops.Conv2dFn.apply(x, self.weight, self.bias, self.packed(), self.stride[0], pad, mode, act)
+
+    def forward(self, input):
+        return ops.ToNCHW.apply(self.forward_nhwc(ops.ToNHWC.apply(input)), self.out_channels)
+
+
+class ConvTranspose2d(nn.ConvTranspose2d, _Cached):
+    """nn.ConvTranspose2d(k3,s2,p1,op1) executed as four sub-pixel phase convolutions."""
+
+    def packed(self):
+        # weight (Cin_T, Cout_T, k, k) == OIHW of the Conv2d(Cout_T -> Cin_T) it is the adjoint of
+        return self._cached(lambda: ops.PackedConv(self.weight, self.bias, cpad(self.out_channels), cpad(self.in_channels)))
+
+    def forward_nhwc(self, x, act=ACT_NONE):
+        return ops.ConvTranspose2dFn.apply(x, self.weight, self.bias, self.packed(), self.stride[0], self.padding[0],
+                                           self.output_padding[0], act)
+
+    def forward(self, input, output_size=None):
+        return ops.ToNCHW.apply(self.forward_nhwc(ops.ToNHWC.apply(input)), self.out_channels)
+
+
+class _BatchNormMixin(_Cached):
+    def _gb(self):
+        C = cpad(self.num_features) if self._pad16 else self.num_features
+        return self._cached(lambda: (_padded_vec(self.weight, C), _padded_vec(self.bias, C)))
+
+    def _run_buffers(self, C):
+        # running stats live in the (real-length) torch buffers; the kernel updates padded scratch copies
+        # that are written back, keeping state_dict identical to torch's BatchNorm.
+        return None
+
+    def forward_act(self, x, act=ACT_NONE):
+        if not self.training:
+            raise NotImplementedError("BatchNorm eval mode (running statistics) is not on the training hot path")
+        C = x.shape[-1]
+        g, b = self._gb()
+        rm = torch.zeros(C, device=x.device, dtype=torch.float32)
+        rv = torch.ones(C, device=x.device, dtype=torch.float32)
+        rm[:self.num_features].copy_(self.running_mean)
+        rv[:self.num_features].copy_(self.running_var)
+        y = ops.NormAct.apply(x, self.weight, self.bias, None, "bn", act, self.eps, g, b, rm, rv, self.momentum)
+        with torch.no_grad():
+            self.running_mean.copy_(rm[:self.num_features])
+            self.running_var.copy_(rv[:self.num_features])
+            self.num_batches_tracked += 1
+        return y
+
+
+class BatchNorm2d(nn.BatchNorm2d, _BatchNormMixin):
+    _pad16 = True
+
+    def forward(self, input):
+        return ops.ToNCHW.apply(self.forward_act(ops.ToNHWC.apply(input)), self.num_features)
+
+
+class BatchNorm1d(nn.BatchNorm1d, _BatchNormMixin):
+    _pad16 = False
+
+    def forward(self, input):
+        return self.forward_act(input)
+
+
+class Linear(nn.Linear):
+    def forward_act(self, x, act=ACT_NONE, out_cols=None):
+        return ops.LinearFn.apply(x, self.weight, self.bias, act, out_cols or self.out_features)
+
+    def forward(self, input):
+        return self.forward_act(input)
+
+
+######################################################################
+# Superclass of all Modules that take two inputs  (modules.py:15-17)
+######################################################################
+class TwoInputModule(nn.Module):
+    def forward(self, input1, input2):
+        raise NotImplementedError
+
+
+class MergeModule(TwoInputModule):
+    """o = module2(module1(x), z)  (modules.py:25-37)"""
+
+    def __init__(self, module1, module2):
+        super(MergeModule, self).__init__()
+        self.module1 = module1
+        self.module2 = module2
+
+    def forward(self, input1, input2):
+        return self.module2.forward(self.module1.forward(input1), input2)
+
+
+class TwoInputSequential(nn.Sequential, TwoInputModule):
+    """nn.Sequential that threads `input2` to every TwoInputModule child (modules.py:44-56)."""
+
+    def __init__(self, *args):
+        super(TwoInputSequential, self).__init__(*args)
+
+    def forward(self, input1, input2):
+        x = ops.ToNHWC.apply(input1)
+        y, C = run_sequence(list(self._modules.values()), x, input1.shape[1], as_latent(input2))
+        return ops.ToNCHW.apply(y, C)
+
+
+def as_latent(z):
+    """(N, nl, 1, 1) or (N, nl) -> contiguous (N, nl) (networks.py:427-428 does the same reshape)."""
+    if z is None:
+        return None
+    return z.reshape(z.shape[0], -1).contiguous()
+
+
+######################################################################
+# InstanceNorm  (modules.py:64-98): biased variance, learnable scale~N(0,0.02) / shift=0
+######################################################################
+class InstanceNorm(nn.Module, _Cached):
+    def __init__(self, num_features, affine=True, eps=1e-5):
+        super(InstanceNorm, self).__init__()
+        self.num_features = num_features
+        self.affine = affine
+        self.eps = eps
+        self.scale = Parameter(torch.Tensor(num_features))
+        self.shift = Parameter(torch.Tensor(num_features))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        if self.affine:
+            self.scale.data.normal_(mean=0., std=0.02)
+            self.shift.data.zero_()
+
+    def _gb(self):
+        C = cpad(self.num_features)
+        if self.affine:
+            return self._cached(lambda: (_padded_vec(self.scale, C), _padded_vec(self.shift, C)))
+        dev = self.scale.device
+        return torch.ones(C, device=dev), torch.zeros(C, device=dev)
+
+    def forward_act(self, x, act=ACT_NONE, res=None):
+        g, b = self._gb()
+        return ops.NormAct.apply(x, self.scale, self.shift, res, "in", act, self.eps, g, b, None, None, 0.0)
+
+    def forward(self, input):
+        return ops.ToNCHW.apply(self.forward_act(ops.ToNHWC.apply(input)), self.num_features)
+
+
+InstanceNorm2d = nn.InstanceNorm2d if USE_PYTORCH_IN else InstanceNorm
+
+
+######################################################################
+# CondInstanceNorm  (modules.py:104-132): scale/shift = ReLU(1x1 conv(z)); UNBIASED variance
+######################################################################
+class CondInstanceNorm(TwoInputModule):
+    def __init__(self, x_dim, z_dim, eps=1e-5):
+        super(CondInstanceNorm, self).__init__()
+        self.eps = eps
+        self.x_dim, self.z_dim = x_dim, z_dim
+        # torch.nn.Conv2d holders keep the reference's keys (shift_conv.0.weight (C, nl, 1, 1), ...); on a
+        # (N, nl, 1, 1) latent a 1x1 conv is a dense layer, run by acg_linear_fwd with the ReLU fused.
+        self.shift_conv = nn.Sequential(Conv2d(z_dim, x_dim, kernel_size=1, padding=0, bias=True), nn.ReLU(True))
+        self.scale_conv = nn.Sequential(Conv2d(z_dim, x_dim, kernel_size=1, padding=0, bias=True), nn.ReLU(True))
+
+    def forward_act(self, x, z, act=ACT_NONE):
+        Cp = x.shape[-1]
+        sh = ops.LinearFn.apply(z, self.shift_conv[0].weight, self.shift_conv[0].bias, ACT_RELU, Cp)
+        sc = ops.LinearFn.apply(z, self.scale_conv[0].weight, self.scale_conv[0].bias, ACT_RELU, Cp)
+        return ops.NormAct.apply(x, sc, sh, None, "cin", act, self.eps, None, None, None, None, 0.0)
+
+    def forward(self, input, noise):
+        y = self.forward_act(ops.ToNHWC.apply(input), as_latent(noise))
+        return ops.ToNCHW.apply(y, self.x_dim)
+
+
+_ACTS = {nn.ReLU: ACT_RELU, nn.LeakyReLU: ACT_LRELU, nn.Tanh: ACT_TANH}
+
+
+def _act_of(m):
+    for cls, a in _ACTS.items():
+        if isinstance(m, cls):
+            if cls is nn.LeakyReLU and abs(m.negative_slope - 0.2) > 1e-12:
+                raise NotImplementedError("LeakyReLU slope %g (kernels implement the reference's 0.2)" % m.negative_slope)
+            return a
+    return None
+
+
+def run_sequence(mods, x, C, z=None, res=None):
+    """Interpret a reference-style layer list on an NHWC C16 tensor with peephole fusion:
+         [ReflectionPad2d] Conv2d|ConvTranspose2d|MergeModule(conv, CondIN) [norm] [activation]
+    `res`: residual input folded into the LAST norm of the list together with a ReLU
+    (ResnetBlock / CINResnetBlock: out = ReLU(x + conv_block(x)), modules.py:185-188, 232-235).
+    Returns (tensor, real channel count)."""
+    i, n = 0, len(mods)
+    last_norm = max([k for k, m in enumerate(mods) if isinstance(m, (InstanceNorm, CondInstanceNorm, BatchNorm2d))
+                     or (isinstance(m, MergeModule))] + [-1]) if res is not None else -1
+    reflect = 0
+    while i < n:
+        m = mods[i]
+        if isinstance(m, nn.ReflectionPad2d):
+            reflect = m.padding[0]
+            i += 1
+            continue
+        if isinstance(m, (ResnetBlock, CINResnetBlock)):
+            x = m.forward_nhwc(x, z)
+            i += 1
+            continue
+        conv, norm = None, None
+        if isinstance(m, MergeModule):
+            conv, norm = m.module1, m.module2
+            i += 1
+        elif isinstance(m, (Conv2d, ConvTranspose2d)):
+            conv = m
+            i += 1
+            if i < n and isinstance(mods[i], (InstanceNorm, CondInstanceNorm, BatchNorm2d)):
+                norm = mods[i]
+                i += 1
+        elif isinstance(m, nn.Dropout):
+            raise NotImplementedError("use_dropout: Dropout is not implemented by the HIP path (reference default is off)")
+        elif isinstance(m, nn.Sigmoid):
+            raise NotImplementedError("use_sigmoid / --no_lsgan: the reference's BCE branch is broken (model.py:59-63); "
+                                      "only LSGAN is implemented")
+        else:
+            raise NotImplementedError("run_sequence: unexpected layer %s" % type(m).__name__)
+        norm_idx = i - 1
+        act = ACT_NONE
+        if i < n and _act_of(mods[i]) is not None:
+            act = _act_of(mods[i])
+            i += 1
+        # convolution (activation fused only when no norm follows)
+        cact = act if norm is None else ACT_NONE
+        if isinstance(conv, ConvTranspose2d):
+            if reflect:
+                raise NotImplementedError("reflection pad before ConvTranspose2d")
+            x = conv.forward_nhwc(x, cact)
+        else:
+            x = conv.forward_nhwc(x, cact, reflect)
+        reflect = 0
+        C = conv.out_channels
+        if norm is not None:
+            fuse_res = res is not None and norm_idx == last_norm
+            if fuse_res and act != ACT_NONE:
+                raise NotImplementedError("residual fusion expects the block to end with its norm")
+            if isinstance(norm, CondInstanceNorm):
+                if fuse_res:
+                    raise NotImplementedError("residual after CondInstanceNorm")
+                x = norm.forward_act(x, z, act)
+            elif isinstance(norm, InstanceNorm):
+                x = norm.forward_act(x, ACT_RELU if fuse_res else act, res if fuse_res else None)
+            else:
+                if fuse_res:
+                    raise NotImplementedError("residual after BatchNorm")
+                x = norm.forward_act(x, act)
+    return x, C
+
+
+######################################################################
+# CINResnetBlock  (modules.py:139-188)
+######################################################################
+class CINResnetBlock(TwoInputModule):
+    def __init__(self, x_dim, z_dim, padding_type, norm_layer, use_dropout, use_bias):
+        super(CINResnetBlock, self).__init__()
+        self.conv_block = self.build_conv_block(x_dim, z_dim, padding_type, norm_layer, use_dropout, use_bias)
+        self.relu = nn.ReLU(True)
+        # the reference re-registers each child under a numeric name (modules.py:145-146): the
+        # state_dict therefore carries aliased keys `model.1x.<j>.…`; reproduce them so that
+        # reference checkpoints load with strict=True.
+        for idx, module in enumerate(self.conv_block):
+            self.add_module(str(idx), module)
+
+    def build_conv_block(self, x_dim, z_dim, padding_type, norm_layer, use_dropout, use_bias):
+        conv_block = []
+        p = 0
+        if padding_type == 'reflect':
+            conv_block += [nn.ReflectionPad2d(1)]
+        elif padding_type == 'zero':
+            p = 1
+        else:
+            raise NotImplementedError('padding [%s] is not implemented' % padding_type)
+        conv_block += [MergeModule(Conv2d(x_dim, x_dim, kernel_size=3, padding=p, bias=use_bias),
+                                   norm_layer(x_dim, z_dim)),
+                       nn.ReLU(True)]
+        if use_dropout:
+            conv_block += [nn.Dropout(0.5)]
+        p = 0
+        if padding_type == 'reflect':
+            conv_block += [nn.ReflectionPad2d(1)]
+        elif padding_type == 'zero':
+            p = 1
+        else:
+            raise NotImplementedError('padding [%s] is not implemented' % padding_type)
+        conv_block += [Conv2d(x_dim, x_dim, kernel_size=3, padding=p, bias=use_bias),
+                       InstanceNorm2d(x_dim, affine=True)]
+        return TwoInputSequential(*conv_block)
+
+    def forward_nhwc(self, x, z):
+        y, _ = run_sequence(list(self.conv_block._modules.values()), x, None, z, res=x)
+        return y
+
+    def forward(self, x, noise):
+        C = x.shape[1]
+        return ops.ToNCHW.apply(self.forward_nhwc(ops.ToNHWC.apply(x), as_latent(noise)), C)
+
+
+######################################################################
+# ResnetBlock  (modules.py:193-235): pad-conv-ReLU-pad-conv-IN ; ReLU(x + out)
+######################################################################
+class ResnetBlock(nn.Module):
+    def __init__(self, dim, padding_type, norm_layer, use_dropout, use_bias):
+        super(ResnetBlock, self).__init__()
+        self.conv_block = self.build_conv_block(dim, padding_type, norm_layer, use_dropout, use_bias)
+        self.relu = nn.ReLU(True)
+
+    def build_conv_block(self, dim, padding_type, norm_layer, use_dropout, use_bias):
+        conv_block = []
+        p = 0
+        if padding_type == 'reflect':
+            conv_block += [nn.ReflectionPad2d(1)]
+        elif padding_type == 'zero':
+            p = 1
+        else:
+            raise NotImplementedError('padding [%s] is not implemented' % padding_type)
+        conv_block += [Conv2d(dim, dim, kernel_size=3, padding=p, bias=use_bias)]
+        conv_block += [nn.ReLU(True)]
+        if use_dropout:
+            conv_block += [nn.Dropout(0.5)]
+        p = 0
+        if padding_type == 'reflect':
+            conv_block += [nn.ReflectionPad2d(1)]
+        elif padding_type == 'zero':
+            p = 1
+        else:
+            raise NotImplementedError('padding [%s] is not implemented' % padding_type)
+        conv_block += [Conv2d(dim, dim, kernel_size=3, padding=p, bias=use_bias)]
+        conv_block += [norm_layer(dim)]
+        return Sequential(*conv_block)
+
+    def forward_nhwc(self, x, z=None):
+        y, _ = run_sequence(list(self.conv_block._modules.values()), x, None, None, res=x)
+        return y
+
+    def forward(self, x):
+        C = x.shape[1]
+        return ops.ToNCHW.apply(self.forward_nhwc(ops.ToNHWC.apply(x)), C)
+
+
+class Sequential(nn.Sequential):
+    """nn.Sequential whose forward (NCHW in / NCHW out) runs the fused HIP pipeline."""
+
+    def forward(self, input):
+        if input.dim() == 2:
+            return run_dense(list(self._modules.values()), input)
+        x = ops.ToNHWC.apply(input)
+        y, C = run_sequence(list(self._modules.values()), x, input.shape[1])
+        return ops.ToNCHW.apply(y, C)
+
+
+def run_dense(mods, x):
+    """Linear [BatchNorm1d] [LeakyReLU] chains on (N, C) activations (DiscriminatorLatent)."""
+    i, n = 0, len(mods)
+    while i < n:
+        m = mods[i]
+        if not isinstance(m, Linear):
+            if isinstance(m, nn.Sigmoid):
+                raise NotImplementedError("use_sigmoid: only LSGAN is implemented")
+            raise NotImplementedError("run_dense: unexpected layer %s" % type(m).__name__)
+        i += 1
+        bn = None
+        if i < n and isinstance(mods[i], BatchNorm1d):
+            bn = mods[i]
+            i += 1
+        act = ACT_NONE
+        if i < n and _act_of(mods[i]) is not None:
+            act = _act_of(mods[i])
+            i += 1
+        if bn is None:
+            x = m.forward_act(x, act, out_cols=(m.out_features + 3) // 4 * 4)
+        else:
+            if m.out_features % 4:
+                raise NotImplementedError("BatchNorm1d width must be a multiple of 4")
+            x = bn.forward_act(m.forward_act(x, ACT_NONE), act)
+    return x

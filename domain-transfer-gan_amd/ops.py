@@ -1,0 +1,501 @@
+"""torch.autograd.Function wrappers over the C ABI (libacgan_hip.so).
+
+PyTorch is plumbing here: it owns device memory (caching allocator), the stream and the
+autograd tape; every forward/backward computation on activations is a HIP kernel reached
+through ctypes.  Internal activation layout: fp32 NHWC with channels padded to 16 ("C16"),
+carried as torch tensors of shape (N, H, W, Cp) — or (N, Cp) for latent / MLP activations.
+
+There is no CPU path: tensors must live on a ROCm device and the library must load.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, PAD_ZERO, PAD_REFLECT, ConvDesc  # noqa: F401
+
+_VP = ctypes.c_void_p
+
+
+def cpad(c):
+    """stored channel count for `c` real channels"""
+    return (int(c) + 15) // 16 * 16
+
+
+def _ptr(t):
+    return None if t is None else _VP(t.data_ptr())
+
+
+def _stream():
+    return _VP(torch.cuda.current_stream().cuda_stream)
+
+
+def _check(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.AcgError("acgan_hip kernels need tensors on a ROCm device (got %s); there is no CPU path" % t.device)
+        if t.dtype != torch.float32:
+            raise _lib.AcgError("acgan_hip kernels are fp32 (got %s)" % t.dtype)
+        if not t.is_contiguous():
+            raise _lib.AcgError("non-contiguous tensor reached a kernel")
+
+
+_WS = {}
+
+
+def workspace(nbytes, slot=0):
+    """Stream-ordered scratch (one buffer per device/slot, grown on demand)."""
+    dev = torch.cuda.current_device()
+    buf = _WS.get((dev, slot))
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device="cuda")
+        _WS[(dev, slot)] = buf
+    return buf
+
+
+def set_conv_impl(name):
+    """'mfma' (product path) or 'direct' (naive HIP kernels, cross-check only)."""
+    _lib.call("acg_set_conv_impl", {"mfma": _lib.IMPL_MFMA, "direct": _lib.IMPL_DIRECT}[name])
+
+
+# ----------------------------------------------------------------------------------------------
+# layout
+# ----------------------------------------------------------------------------------------------
+class ToNHWC(torch.autograd.Function):
+    """(N,C,H,W) -> (N,H,W,Cp)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        _check(x)
+        N, C, H, W = x.shape
+        ctx.C = C
+        y = torch.empty((N, H, W, cpad(C)), device=x.device, dtype=torch.float32)
+        _lib.call("acg_nchw_to_nhwc16", _ptr(x), _ptr(y), N, C, H, W, cpad(C), _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        N, H, W, Cp = g.shape
+        d = torch.empty((N, ctx.C, H, W), device=g.device, dtype=torch.float32)
+        _lib.call("acg_nhwc16_to_nchw", _ptr(g), _ptr(d), N, ctx.C, H, W, Cp, _stream())
+        return d
+
+
+class ToNCHW(torch.autograd.Function):
+    """(N,H,W,Cp) -> (N,C,H,W)"""
+
+    @staticmethod
+    def forward(ctx, x, C):
+        x = x.contiguous()
+        _check(x)
+        N, H, W, Cp = x.shape
+        ctx.Cp = Cp
+        y = torch.empty((N, C, H, W), device=x.device, dtype=torch.float32)
+        _lib.call("acg_nhwc16_to_nchw", _ptr(x), _ptr(y), N, C, H, W, Cp, _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        N, C, H, W = g.shape
+        d = torch.empty((N, H, W, ctx.Cp), device=g.device, dtype=torch.float32)
+        _lib.call("acg_nchw_to_nhwc16", _ptr(g), _ptr(d), N, C, H, W, ctx.Cp, _stream())
+        return d, None
+
+
+class Concat(torch.autograd.Function):
+    """torch.cat((a, b), 1) on C16 tensors (model.py:410, 472)."""
+
+    @staticmethod
+    def forward(ctx, a, b, Ca, Cb):
+        a, b = a.contiguous(), b.contiguous()
+        _check(a, b)
+        N, H, W, Cap = a.shape
+        Cbp = b.shape[3]
+        Cdp = cpad(Ca + Cb)
+        ctx.dims = (Ca, Cap, Cb, Cbp, Cdp)
+        y = torch.empty((N, H, W, Cdp), device=a.device, dtype=torch.float32)
+        _lib.call("acg_concat_channels", _ptr(a), Ca, Cap, _ptr(b), Cb, Cbp, _ptr(y), Cdp, N * H * W, _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        Ca, Cap, Cb, Cbp, Cdp = ctx.dims
+        N, H, W, _ = g.shape
+        ga = torch.empty((N, H, W, Cap), device=g.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        gb = torch.empty((N, H, W, Cbp), device=g.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        if ga is not None or gb is not None:
+            _lib.call("acg_split_channels", _ptr(g), Cdp, _ptr(ga), Ca, Cap, _ptr(gb), Cb, Cbp, N * H * W, _stream())
+        return ga, gb, None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# convolutions
+# ----------------------------------------------------------------------------------------------
+class PackedConv(object):
+    """Device-side packed forms of one conv weight (+ padded bias); see acg_pack_conv_weight."""
+
+    def __init__(self, weight, bias, Ci, Co):
+        Or, Ir, K, _ = weight.shape
+        self.Or, self.Ir, self.K, self.Ci, self.Co = Or, Ir, K, Ci, Co
+        dev = weight.device
+        self.wf = torch.empty(_lib.query("acg_packed_wf_elems", K, Ci, Co), device=dev, dtype=torch.float32)
+        self.wb = torch.empty(_lib.query("acg_packed_wb_elems", K, Ci, Co), device=dev, dtype=torch.float32)
+        self.bias = None
+        self.refresh(weight, bias)
+
+    def refresh(self, weight, bias):
+        w = weight.detach().contiguous()
+        _check(w)
+        _lib.call("acg_pack_conv_weight", _ptr(w), self.Or, self.Ir, self.K, self.Ci, self.Co, _ptr(self.wf), _ptr(self.wb),
+                  _stream())
+        if bias is not None:
+            n = bias.numel()
+            npad = cpad(n)
+            if self.bias is None:
+                self.bias = torch.empty(npad, device=w.device, dtype=torch.float32)
+            _lib.call("acg_pad_vector", _ptr(bias.detach()), n, _ptr(self.bias), npad, _stream())
+
+
+class ConvTimer(object):
+    """bench.py hook: HIP events (on the launch stream) around the forward launches of ONE conv shape,
+    so the roofline numerator/denominator come from the live timed region."""
+
+    def __init__(self, match):
+        self.match, self.events = match, []
+
+    def ms(self):
+        return [a.elapsed_time(b) for a, b in self.events]
+
+
+CONV_TIMER = None
+
+
+def conv_desc(N, Hi, Wi, Ci, Co, K, stride, pad, pad_mode):
+    Ho = (Hi + 2 * pad - K) // stride + 1
+    Wo = (Wi + 2 * pad - K) // stride + 1
+    return ConvDesc(N, Hi, Wi, Ci, Ho, Wo, Co, K, stride, pad, pad_mode)
+
+
+class Conv2dFn(torch.autograd.Function):
+    """nn.Conv2d (+ preceding ReflectionPad2d) + bias + fused activation."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, packed, stride, pad, pad_mode, act):
+        x = x.contiguous()
+        _check(x)
+        N, Hi, Wi, Ci = x.shape
+        if Ci != packed.Ci:
+            raise _lib.AcgError("conv: input has %d stored channels, weight packed for %d" % (Ci, packed.Ci))
+        d = conv_desc(N, Hi, Wi, Ci, packed.Co, packed.K, stride, pad, pad_mode)
+        if d.Ho <= 0 or d.Wo <= 0:
+            raise _lib.AcgError("conv: input %dx%d too small for kernel %d" % (Hi, Wi, packed.K))
+        y = torch.empty((N, d.Ho, d.Wo, packed.Co), device=x.device, dtype=torch.float32)
+        timed = CONV_TIMER is not None and CONV_TIMER.match(d)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _lib.call("acg_conv2d_fwd", ctypes.byref(d), _ptr(x), _ptr(packed.wf), _ptr(packed.bias if bias is not None else None),
+                  _ptr(y), act, _stream())
+        if timed:
+            e1.record()
+            CONV_TIMER.events.append((e0, e1))
+        ctx.d, ctx.packed, ctx.act, ctx.has_bias = d, packed, act, bias is not None
+        ctx.save_for_backward(x, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        d, pk = ctx.d, ctx.packed
+        dy = dy.contiguous()
+        st = _stream()
+        if ctx.act != ACT_NONE:
+            g = torch.empty_like(dy)
+            _lib.call("acg_act_bwd", _ptr(dy), _ptr(y), _ptr(g), dy.numel(), ctx.act, st)
+        else:
+            g = dy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            nb = _lib.query("acg_conv2d_bwd_data_workspace_bytes", ctypes.byref(d))
+            ws = workspace(nb) if nb else None
+            _lib.call("acg_conv2d_bwd_data", ctypes.byref(d), _ptr(g), _ptr(pk.wb), _ptr(dx), _ptr(ws), nb, st)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((pk.Or, pk.Ir, pk.K, pk.K), device=x.device, dtype=torch.float32)
+            db = torch.empty(pk.Or, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+            nb = _lib.query("acg_conv2d_bwd_weight_workspace_bytes", ctypes.byref(d))
+            ws = workspace(nb)
+            _lib.call("acg_conv2d_bwd_weight", ctypes.byref(d), _ptr(x), _ptr(g), _ptr(dw), _ptr(db), pk.Or, pk.Ir, _ptr(ws),
+                      nb, st)
+        return dx, dw, db, None, None, None, None, None
+
+
+class ConvTranspose2dFn(torch.autograd.Function):
+    """nn.ConvTranspose2d(k3, s2, p1, op1) + bias + fused activation.  `packed` holds the weight
+    (Cin_T, Cout_T, k, k) packed as the OIHW weight of the Conv2d it is the adjoint of."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, packed, stride, pad, out_pad, act):
+        x = x.contiguous()
+        _check(x)
+        N, H, W, Cs = x.shape
+        K = packed.K
+        Hl = (H - 1) * stride - 2 * pad + K + out_pad
+        Wl = (W - 1) * stride - 2 * pad + K + out_pad
+        # underlying conv: large side (Hl, Wl, packed.Ci) -> small side (H, W, packed.Co)
+        if Cs != packed.Co:
+            raise _lib.AcgError("conv_transpose: input has %d stored channels, expected %d" % (Cs, packed.Co))
+        d = conv_desc(N, Hl, Wl, packed.Ci, packed.Co, K, stride, pad, PAD_ZERO)
+        if (d.Ho, d.Wo) != (H, W):
+            raise _lib.AcgError("conv_transpose: inconsistent geometry")
+        y = torch.empty((N, Hl, Wl, packed.Ci), device=x.device, dtype=torch.float32)
+        _lib.call("acg_conv_transpose2d_fwd", ctypes.byref(d), _ptr(x), _ptr(packed.wb),
+                  _ptr(packed.bias if bias is not None else None), _ptr(y), act, _stream())
+        ctx.d, ctx.packed, ctx.act, ctx.has_bias = d, packed, act, bias is not None
+        ctx.save_for_backward(x, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        d, pk = ctx.d, ctx.packed
+        dy = dy.contiguous()
+        st = _stream()
+        if ctx.act != ACT_NONE:
+            g = torch.empty_like(dy)
+            _lib.call("acg_act_bwd", _ptr(dy), _ptr(y), _ptr(g), dy.numel(), ctx.act, st)
+        else:
+            g = dy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.call("acg_conv_transpose2d_bwd_data", ctypes.byref(d), _ptr(g), _ptr(pk.wf), _ptr(dx), st)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((pk.Or, pk.Ir, pk.K, pk.K), device=x.device, dtype=torch.float32)
+            db = torch.empty(pk.Ir, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+            nb = _lib.query("acg_conv2d_bwd_weight_workspace_bytes", ctypes.byref(d))
+            ws = workspace(nb)
+            _lib.call("acg_conv_transpose2d_bwd_weight", ctypes.byref(d), _ptr(x), _ptr(g), _ptr(dw), _ptr(db), pk.Or,
+                      pk.Ir, _ptr(ws), nb, st)
+        return dx, dw, db, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# normalisation (+ fused activation / residual)
+# ----------------------------------------------------------------------------------------------
+class NormAct(torch.autograd.Function):
+    """y = act(norm(x) * gamma + beta [+ res]).
+
+    kind 'in'  : InstanceNorm      (modules.py:64-97)   gamma/beta (C,), biased variance
+    kind 'cin' : CondInstanceNorm  (modules.py:104-132) gamma/beta (N, Cp), UNBIASED variance
+    kind 'bn'  : BatchNorm2d/1d in train mode           gamma/beta (C,), biased; running stats updated
+    x: (N,H,W,Cp) or (N,Cp).  gamma_p / beta_p are the C16-padded device copies for 'in'/'bn'.
+    """
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, kind, act, eps, gamma_p, beta_p, run_mean, run_var, momentum):
+        x = x.contiguous()
+        _check(x)
+        C = x.shape[-1]
+        N = x.shape[0]
+        rows = x.numel() // C
+        if kind == "bn":
+            G, P = 1, rows
+        else:
+            G, P = N, rows // N
+        unbiased = 1 if kind == "cin" else 0
+        if kind == "cin":
+            gp, bp, gstride = gamma.contiguous(), beta.contiguous(), C
+            if gp.shape != (N, C):
+                raise _lib.AcgError("cin: scale/shift must be (N, Cp)")
+        else:
+            gp, bp, gstride = gamma_p, beta_p, 0
+        _check(gp, bp)
+        st = _stream()
+        mean = torch.empty(G * C, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(G * C, device=x.device, dtype=torch.float32)
+        nb = _lib.query("acg_norm_workspace_bytes", G, P, C)
+        ws = workspace(nb)
+        _lib.call("acg_norm_stats", _ptr(x), G, P, C, eps, unbiased, _ptr(mean), _ptr(rstd), _ptr(run_mean), _ptr(run_var),
+                  momentum, _ptr(ws), nb, st)
+        y = torch.empty_like(x)
+        if res is not None:
+            res = res.contiguous()
+        _lib.call("acg_norm_apply", _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gp), _ptr(bp), gstride, _ptr(res), _ptr(y), G, P, C,
+                  act, st)
+        ctx.cfg = (kind, act, G, P, C, unbiased, gstride, res is not None, gamma.shape)
+        ctx.save_for_backward(x, y if act != ACT_NONE else None, mean, rstd, gp)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, rstd, gp = ctx.saved_tensors
+        kind, act, G, P, C, unbiased, gstride, has_res, gshape = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res else None
+        npar = G * C if gstride else C
+        dgamma = torch.empty(npar, device=x.device, dtype=torch.float32)
+        dbeta = torch.empty(npar, device=x.device, dtype=torch.float32)
+        nb = _lib.query("acg_norm_workspace_bytes", G, P, C)
+        ws = workspace(nb)
+        _lib.call("acg_norm_bwd", _ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gp), gstride, _ptr(dx), _ptr(dres),
+                  _ptr(dgamma), _ptr(dbeta), G, P, C, act, unbiased, _ptr(ws), nb, _stream())
+        if kind == "cin":
+            dg, db = dgamma.view(G, C), dbeta.view(G, C)
+        else:
+            dg, db = dgamma[:gshape[0]], dbeta[:gshape[0]]
+        if has_res and act == ACT_NONE:
+            dres = dy
+        return dx, dg, db, dres, None, None, None, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# small dense layers
+# ----------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y[N, Op] = act(x[:, :I] @ w.T + b), zero in columns >= O."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, Op):
+        x = x.contiguous()
+        w = w.contiguous()
+        _check(x, w, b)
+        N, ldx = x.shape
+        O, I = w.shape[0], w.numel() // w.shape[0]
+        if I > ldx:
+            raise _lib.AcgError("linear: input has %d columns, weight expects %d" % (ldx, I))
+        y = torch.empty((N, Op), device=x.device, dtype=torch.float32)
+        _lib.call("acg_linear_fwd", _ptr(x), _ptr(w), _ptr(b), _ptr(y), N, I, ldx, O, Op, act, _stream())
+        ctx.cfg = (N, I, ldx, O, Op, act, w.shape)
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        N, I, ldx, O, Op, act, wshape = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty(wshape, device=x.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        db = torch.empty(O, device=x.device, dtype=torch.float32) if ctx.needs_input_grad[2] else None
+        _lib.call("acg_linear_bwd", _ptr(dy), _ptr(y), _ptr(x), _ptr(w), _ptr(dx), _ptr(dw), _ptr(db), N, I, ldx, O, Op, act,
+                  _stream())
+        return dx, dw, db, None, None
+
+
+class SpatialMean(torch.autograd.Function):
+    """(N,H,W,Cp) -> (N,Cp): mean over H*W (identity at 1x1; LatentEncoder extension)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        _check(x)
+        N, H, W, Cp = x.shape
+        ctx.shape = x.shape
+        y = torch.empty((N, Cp), device=x.device, dtype=torch.float32)
+        _lib.call("acg_spatial_mean_fwd", _ptr(x), _ptr(y), N, H * W, Cp, _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        N, H, W, Cp = ctx.shape
+        dx = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
+        _lib.call("acg_spatial_mean_bwd", _ptr(g), _ptr(dx), N, H * W, Cp, _stream())
+        return dx
+
+
+# ----------------------------------------------------------------------------------------------
+# losses (device scalars; no host sync)
+# ----------------------------------------------------------------------------------------------
+def _red_ws():
+    nb = _lib.query("acg_reduce_workspace_bytes", 0)
+    return workspace(nb, slot=1), nb
+
+
+class MseConst(torch.autograd.Function):
+    """F.mse_loss(pred, full_like(pred, target)) over the C valid channels (model.py:65-70)."""
+
+    @staticmethod
+    def forward(ctx, p, C, target):
+        p = p.contiguous()
+        _check(p)
+        Cp = p.shape[-1]
+        npix = p.numel() // Cp
+        out = torch.empty((), device=p.device, dtype=torch.float32)
+        ws, nb = _red_ws()
+        _lib.call("acg_mse_const_fwd", _ptr(p), npix, C, Cp, float(target), _ptr(out), _ptr(ws), nb, _stream())
+        ctx.cfg = (npix, C, Cp, float(target))
+        ctx.save_for_backward(p)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        npix, C, Cp, target = ctx.cfg
+        g = g.contiguous()
+        dp = torch.empty_like(p)
+        _lib.call("acg_mse_const_bwd", _ptr(p), npix, C, Cp, target, _ptr(g), _ptr(dp), _stream())
+        return dp, None, None
+
+
+class L1(torch.autograd.Function):
+    """F.l1_loss(a, b) (mean) over the C valid channels (model.py:391, 468, 486, 494)."""
+
+    @staticmethod
+    def forward(ctx, a, b, C):
+        a, b = a.contiguous(), b.contiguous()
+        _check(a, b)
+        Cp = a.shape[-1]
+        npix = a.numel() // Cp
+        out = torch.empty((), device=a.device, dtype=torch.float32)
+        ws, nb = _red_ws()
+        _lib.call("acg_l1_fwd", _ptr(a), _ptr(b), npix, C, Cp, _ptr(out), _ptr(ws), nb, _stream())
+        ctx.cfg = (npix, C, Cp)
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        npix, C, Cp = ctx.cfg
+        g = g.contiguous()
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        if da is not None or db is not None:
+            _lib.call("acg_l1_bwd", _ptr(a), _ptr(b), npix, C, Cp, _ptr(g), _ptr(da), _ptr(db), _stream())
+        return da, db, None
+
+
+def mean_valid(x, C, out=None):
+    """mean over the C valid channels of a C16 tensor -> device scalar (no grad)."""
+    x = x.detach().contiguous()
+    _check(x)
+    Cp = x.shape[-1]
+    if out is None:
+        out = torch.empty((), device=x.device, dtype=torch.float32)
+    ws, nb = _red_ws()
+    _lib.call("acg_mean_fwd", _ptr(x), x.numel() // Cp, C, Cp, _ptr(out), _ptr(ws), nb, _stream())
+    return out
+
+
+def sumsq(flat, out):
+    """out[0] = sum(flat^2) (first half of clip_grad_norm)."""
+    _check(flat)
+    ws, nb = _red_ws()
+    _lib.call("acg_sumsq", _ptr(flat), flat.numel(), _ptr(out), _ptr(ws), nb, _stream())
+    return out
+
+
+def adam_step(p, g, m, v, sumsq_t, max_norm, lr, beta1, beta2, eps, step, scale_grads=True):
+    """clip (coefficient from the device-side sum of squares) + Adam on one flat buffer."""
+    _check(p, g, m, v)
+    _lib.call("acg_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(sumsq_t), float(max_norm), float(lr),
+              float(beta1), float(beta2), float(eps), int(step), 1 if scale_grads else 0, _stream())

@@ -1,0 +1,286 @@
+"""GPU parity, op level: every HIP kernel family reached through the product's module API and the
+C ABI, compared with the fp64 oracle (oracle/ops.py) on the same seeded inputs.
+
+Tolerances (written per the north star: 1e-3 rel fp32 on activations): the MFMA path is an exact
+fp32 FMA chain, so we hold it to 2e-5 relative to the fp64 oracle (max-abs error / max-abs value);
+long pixel reductions (weight gradients, norm statistics) to 1e-4.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ops as oops  # noqa: E402
+from oracle.tape import T, backward, leaf  # noqa: E402
+
+CONV_CASES = [
+    # K, stride, pad, mode, Ci, Co, N, H, W
+    (3, 1, 1, "zero", 8, 8, 2, 12, 10),
+    (3, 1, 1, "reflect", 32, 32, 2, 9, 11),
+    (7, 1, 3, "reflect", 3, 8, 2, 16, 16),
+    (7, 1, 3, "zero", 8, 3, 2, 16, 16),
+    (3, 2, 1, "zero", 16, 32, 2, 16, 16),
+    (3, 2, 1, "zero", 16, 32, 1, 15, 13),
+    (4, 2, 1, "zero", 3, 16, 2, 16, 16),
+    (4, 1, 1, "zero", 32, 64, 2, 9, 9),
+    (4, 1, 0, "zero", 32, 1, 3, 6, 6),
+    (1, 1, 0, "zero", 64, 16, 2, 3, 3),
+    (3, 1, 1, "reflect", 128, 128, 1, 8, 8),
+    (4, 1, 1, "zero", 256, 256, 1, 6, 6),
+    (3, 2, 1, "zero", 64, 128, 1, 12, 12),
+    (3, 1, 1, "zero", 6, 40, 1, 20, 20),
+]
+
+
+def _conv_module(K, stride, pad, mode, Ci, Co):
+    from dtgan_amd import modules as M
+    if mode == "reflect":
+        return M.Sequential(nn.ReflectionPad2d(pad), M.Conv2d(Ci, Co, K, stride=stride, padding=0, bias=True)).cuda()
+    return M.Sequential(M.Conv2d(Ci, Co, K, stride=stride, padding=pad, bias=True)).cuda()
+
+
+@pytest.mark.parametrize("impl", ["mfma", "direct"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "k%ds%dp%d%s_%dto%d_%dx%dx%d" % c)
+def test_conv2d_fwd_bwd(case, impl):
+    from hip_util import t, n, rel
+    from dtgan_amd import ops
+    K, stride, pad, mode, Ci, Co, N, H, W = case
+    rs = np.random.RandomState(sum(c if isinstance(c, int) else len(c) for c in case))
+    x = rs.normal(0, 1, (N, Ci, H, W))
+    w = rs.normal(0, 0.3, (Co, Ci, K, K))
+    b = rs.normal(0, 0.5, (Co,))
+    ops.set_conv_impl(impl)
+    try:
+        m = _conv_module(K, stride, pad, mode, Ci, Co)
+        conv = [c for c in m.modules() if c.__class__.__name__ == "Conv2d"][0]
+        with torch.no_grad():
+            conv.weight.copy_(t(w)); conv.bias.copy_(t(b))
+        xt = t(x, grad=True)
+        y = m(xt)
+        X, Wt, Bt = leaf(x), leaf(w), leaf(b)
+        yo = oops.conv2d(X, Wt, Bt, stride=stride, pad=pad, pad_mode=mode)
+        assert y.shape == yo.v.shape
+        assert rel(n(y), yo.v) < 2e-5
+        r = rs.normal(0, 1, yo.v.shape)
+        y.backward(t(r))
+        backward(yo, seed=r)
+        assert rel(n(xt.grad), X.g) < 2e-5, "dgrad"
+        assert rel(n(conv.weight.grad), Wt.g) < 1e-4, "wgrad"
+        assert rel(n(conv.bias.grad), Bt.g) < 1e-4, "bias grad"
+    finally:
+        ops.set_conv_impl("mfma")
+
+
+@pytest.mark.parametrize("impl", ["mfma", "direct"])
+@pytest.mark.parametrize("dims", [(32, 16, 2, 5, 7), (128, 64, 1, 6, 6), (8, 8, 2, 4, 4)])
+def test_conv_transpose2d(dims, impl):
+    from hip_util import t, n, rel
+    from dtgan_amd import modules as M, ops
+    Ci, Co, N, H, W = dims
+    rs = np.random.RandomState(7 + Ci)
+    x = rs.normal(0, 1, (N, Ci, H, W)); w = rs.normal(0, 0.3, (Ci, Co, 3, 3)); b = rs.normal(0, 0.5, (Co,))
+    ops.set_conv_impl(impl)
+    try:
+        m = M.ConvTranspose2d(Ci, Co, 3, stride=2, padding=1, output_padding=1, bias=True).cuda()
+        with torch.no_grad():
+            m.weight.copy_(t(w)); m.bias.copy_(t(b))
+        xt = t(x, grad=True)
+        y = m(xt)
+        X, Wt, Bt = leaf(x), leaf(w), leaf(b)
+        yo = oops.conv_transpose2d(X, Wt, Bt)
+        assert y.shape == yo.v.shape == (N, Co, 2 * H, 2 * W)
+        assert rel(n(y), yo.v) < 2e-5
+        r = rs.normal(0, 1, yo.v.shape)
+        y.backward(t(r)); backward(yo, seed=r)
+        assert rel(n(xt.grad), X.g) < 2e-5
+        assert rel(n(m.weight.grad), Wt.g) < 1e-4
+        assert rel(n(m.bias.grad), Bt.g) < 1e-4
+    finally:
+        ops.set_conv_impl("mfma")
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 9, 7), (3, 32, 16, 16), (1, 128, 40, 40), (2, 20, 5, 5)])
+def test_instance_norm(shape):
+    from hip_util import t, n, rel
+    from dtgan_amd import modules as M
+    N, C, H, W = shape
+    rs = np.random.RandomState(C)
+    x = rs.normal(0.7, 1.5, shape); sc = rs.normal(1, 0.3, C); sh = rs.normal(0, 0.3, C)
+    m = M.InstanceNorm(C).cuda()
+    with torch.no_grad():
+        m.scale.copy_(t(sc)); m.shift.copy_(t(sh))
+    xt = t(x, grad=True)
+    y = m(xt)
+    X, S, B = leaf(x), leaf(sc), leaf(sh)
+    yo = oops.instance_norm(X, S, B)
+    assert rel(n(y), yo.v) < 2e-5
+    r = rs.normal(0, 1, shape)
+    y.backward(t(r)); backward(yo, seed=r)
+    assert rel(n(xt.grad), X.g) < 1e-4
+    assert rel(n(m.scale.grad), S.g) < 1e-4
+    assert rel(n(m.shift.grad), B.g) < 1e-4
+
+
+def test_instance_norm_large_mean_is_stable():
+    """|mean| >> std: the one-pass statistics (Chan merge) must still match the two-pass oracle"""
+    from hip_util import t, n, rel
+    from dtgan_amd import modules as M
+    rs = np.random.RandomState(3)
+    x = rs.normal(50.0, 1.0, (2, 16, 64, 64))
+    m = M.InstanceNorm(16).cuda()
+    with torch.no_grad():
+        m.scale.fill_(1.0); m.shift.fill_(0.0)
+    y = m(t(x))
+    yo = oops.instance_norm(leaf(x), leaf(np.ones(16)), leaf(np.zeros(16)))
+    assert rel(n(y), yo.v) < 1e-3
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 9, 7), (3, 32, 12, 12)])
+def test_cond_instance_norm(shape):
+    from hip_util import t, n, rel
+    from dtgan_amd import modules as M
+    N, C, H, W = shape
+    nl = 4
+    rs = np.random.RandomState(C + 1)
+    x = rs.normal(0.2, 1.3, shape); z = rs.normal(0, 1, (N, nl, 1, 1))
+    ws, bs_ = rs.normal(0, 0.5, (C, nl, 1, 1)), rs.normal(0.3, 0.3, C)
+    wc, bc = rs.normal(0, 0.5, (C, nl, 1, 1)), rs.normal(0.5, 0.3, C)
+    m = M.CondInstanceNorm(C, nl).cuda()
+    with torch.no_grad():
+        m.shift_conv[0].weight.copy_(t(ws)); m.shift_conv[0].bias.copy_(t(bs_))
+        m.scale_conv[0].weight.copy_(t(wc)); m.scale_conv[0].bias.copy_(t(bc))
+    xt, zt = t(x, grad=True), t(z, grad=True)
+    y = m(xt, zt)
+    X, Z = leaf(x), leaf(z)
+    Ws, Bs, Wc, Bc = leaf(ws), leaf(bs_), leaf(wc), leaf(bc)
+    sh = oops.relu(oops.conv2d(Z, Ws, Bs)); sc = oops.relu(oops.conv2d(Z, Wc, Bc))
+    yo = oops.cond_instance_norm(X, sc, sh)
+    assert rel(n(y), yo.v) < 2e-5
+    r = rs.normal(0, 1, shape)
+    y.backward(t(r)); backward(yo, seed=r)
+    assert rel(n(xt.grad), X.g) < 1e-4
+    assert rel(n(zt.grad), Z.g) < 1e-4
+    assert rel(n(m.shift_conv[0].weight.grad), Ws.g) < 1e-4
+    assert rel(n(m.scale_conv[0].weight.grad), Wc.g) < 1e-4
+    assert rel(n(m.scale_conv[0].bias.grad), Bc.g) < 1e-4
+
+
+def test_batch_norm2d_train():
+    from hip_util import t, n, rel
+    from dtgan_amd import modules as M
+    shape = (3, 24, 7, 5)
+    rs = np.random.RandomState(5)
+    x = rs.normal(0.4, 1.2, shape); w = rs.normal(1, 0.3, 24); b = rs.normal(0, 0.3, 24)
+    m = M.BatchNorm2d(24).cuda()
+    with torch.no_grad():
+        m.weight.copy_(t(w)); m.bias.copy_(t(b))
+    xt = t(x, grad=True)
+    y = m(xt)
+    X, Wt, Bt = leaf(x), leaf(w), leaf(b)
+    stats = dict(running_mean=np.zeros(24), running_var=np.ones(24), num_batches_tracked=np.zeros((), np.int64))
+    yo = oops.batch_norm(X, Wt, Bt, stats, True)
+    assert rel(n(y), yo.v) < 2e-5
+    assert rel(n(m.running_mean), stats["running_mean"]) < 1e-5
+    assert rel(n(m.running_var), stats["running_var"]) < 1e-5
+    assert int(m.num_batches_tracked) == 1
+    r = rs.normal(0, 1, shape)
+    y.backward(t(r)); backward(yo, seed=r)
+    assert rel(n(xt.grad), X.g) < 1e-4
+    assert rel(n(m.weight.grad), Wt.g) < 1e-4
+    assert rel(n(m.bias.grad), Bt.g) < 1e-4
+
+
+def test_residual_norm_relu_fusion():
+    """ResnetBlock tail: y = ReLU(x + IN(conv(...))) with the add + ReLU fused into the norm pass"""
+    from hip_util import t, n, rel
+    from dtgan_amd import modules as M
+    import functools
+    C, shape = 16, (2, 16, 10, 10)
+    rs = np.random.RandomState(11)
+    blk = M.ResnetBlock(C, "reflect", functools.partial(M.InstanceNorm2d, affine=True), False, True).cuda()
+    vals = {}
+    with torch.no_grad():
+        for k, p in blk.named_parameters():
+            vals[k] = rs.normal(1.0 if k.endswith("scale") else 0.0, 0.3, tuple(p.shape))
+            p.copy_(t(vals[k]))
+    x = rs.normal(0, 1, shape)
+    xt = t(x, grad=True)
+    y = blk(xt)
+    X = leaf(x)
+    P = {k: leaf(v) for k, v in vals.items()}
+    o = oops.relu(oops.conv2d(X, P["conv_block.1.weight"], P["conv_block.1.bias"], pad=1, pad_mode="reflect"))
+    o = oops.conv2d(o, P["conv_block.4.weight"], P["conv_block.4.bias"], pad=1, pad_mode="reflect")
+    o = oops.instance_norm(o, P["conv_block.5.scale"], P["conv_block.5.shift"])
+    yo = oops.relu(oops.add(X, o))
+    assert rel(n(y), yo.v) < 2e-5
+    r = rs.normal(0, 1, shape)
+    y.backward(t(r)); backward(yo, seed=r)
+    assert rel(n(xt.grad), X.g) < 1e-4
+    gmax = max(float(np.max(np.abs(v.g))) for v in P.values())
+    for k, p in blk.named_parameters():
+        # conv_block.4.bias feeds the InstanceNorm: analytically zero gradient -> absolute floor
+        assert np.max(np.abs(n(p.grad) - P[k].g)) < 2e-4 * np.max(np.abs(P[k].g)) + 2e-6 * gmax, k
+
+
+def test_losses_and_optimizer():
+    from hip_util import t, n
+    from dtgan_amd import ops
+    rs = np.random.RandomState(2)
+    # LSGAN + L1 on C16 tensors with 3 valid channels
+    a = np.zeros((2, 9, 9, 16), np.float32); b = np.zeros_like(a)
+    a[..., :3] = rs.normal(0, 1, (2, 9, 9, 3)); b[..., :3] = rs.normal(0, 1, (2, 9, 9, 3))
+    at, bt = t(a, grad=True), t(b, grad=True)
+    l = ops.MseConst.apply(at, 3, 1.0)
+    ref = ((a[..., :3] - 1.0) ** 2).mean()
+    assert abs(float(l) - ref) < 1e-5 * abs(ref)
+    (l * 0.5).backward()
+    g = np.zeros_like(a); g[..., :3] = 0.5 * 2 * (a[..., :3] - 1.0) / a[..., :3].size
+    assert np.allclose(n(at.grad), g, rtol=1e-5, atol=1e-9)
+    at.grad = None
+    l1 = ops.L1.apply(at, bt, 3)
+    ref = np.abs(a[..., :3] - b[..., :3]).mean()
+    assert abs(float(l1) - ref) < 1e-5 * ref
+    l1.backward()
+    g = np.zeros_like(a); g[..., :3] = np.sign(a[..., :3] - b[..., :3]) / a[..., :3].size
+    assert np.allclose(n(at.grad), g, atol=1e-9) and np.allclose(n(bt.grad), -g, atol=1e-9)
+    assert abs(float(ops.mean_valid(at, 3)) - a[..., :3].mean()) < 1e-6
+    # clip + Adam, two steps, against the oracle's Adam
+    from oracle.step import Adam, clip_grad_norm
+    from oracle.tape import leaf
+    p0 = rs.normal(0, 1, 1000).astype(np.float32)
+    P = leaf(p0.copy()); opt = Adam([P], 2e-4, 0.5)
+    pt = t(p0); gt = torch.zeros_like(pt); m = torch.zeros_like(pt); v = torch.zeros_like(pt)
+    ss = torch.zeros((), device="cuda")
+    for step in (1, 2):
+        g = rs.normal(0, 30 if step == 1 else 0.1, 1000).astype(np.float32)
+        P.g = g.copy(); norm = clip_grad_norm([P], 500.0); opt.step()
+        gt.copy_(t(g)); ops.sumsq(gt, ss)
+        ops.adam_step(pt, gt, m, v, ss, 500.0, 2e-4, 0.5, 0.999, 1e-8, step)
+        assert abs(float(ss) ** 0.5 - norm) < 1e-4 * norm
+        assert np.allclose(n(pt), P.v, rtol=0, atol=2e-7)
+        assert np.allclose(n(gt), P.g, rtol=1e-5, atol=1e-8)
+
+
+def test_linear_and_spatial_mean():
+    from hip_util import t, n, rel
+    from dtgan_amd import ops
+    rs = np.random.RandomState(9)
+    x = rs.normal(0, 1, (5, 16)); w = rs.normal(0, 0.5, (8, 6)); b = rs.normal(0, 0.5, 8)
+    xt, wt, bt = t(x, True), t(w, True), t(b, True)
+    y = ops.LinearFn.apply(xt, wt, bt, ops.ACT_LRELU, 8)
+    pre = x[:, :6] @ w.T + b
+    ref = np.where(pre > 0, pre, 0.2 * pre)
+    assert rel(n(y), ref) < 1e-5
+    r = rs.normal(0, 1, ref.shape)
+    y.backward(t(r))
+    g = r * np.where(pre > 0, 1, 0.2)
+    gx = np.zeros_like(x); gx[:, :6] = g @ w
+    assert rel(n(xt.grad), gx) < 1e-5 and rel(n(wt.grad), g.T @ x[:, :6]) < 1e-5 and rel(n(bt.grad), g.sum(0)) < 1e-5
+    a = rs.normal(0, 1, (2, 5, 3, 16))
+    at = t(a, True)
+    sm = ops.SpatialMean.apply(at)
+    assert rel(n(sm), a.mean(axis=(1, 2))) < 1e-5
+    sm.backward(t(np.ones((2, 16))))
+    assert np.allclose(n(at.grad), 1.0 / 15)

@@ -1,0 +1,85 @@
+"""GPU parity, step level: AugmentedCycleGAN / StochCycleGAN .train_instance on the HIP path against
+(a) the golden fixtures captured from the reference itself and (b) the fp32 oracle run on this box.
+
+Bar (BASELINE.json north star): generator activations and losses within 1e-3 relative of the reference
+CPU path.  Step 0 is a pure function of the inputs and is held to 2e-4 (losses) / 1e-3 (gradient norms) /
+1e-4 (images); later steps inherit Adam's amplification of rounding noise on ~zero-gradient tensors
+(see tests/test_oracle_golden.py) and are held to 1e-2 / 3e-2 / 5e-3.
+"""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from golden_util import load, names  # noqa: E402
+
+
+def make_opt(**kw):
+    d = dict(input_nc=3, output_nc=3, ngf=32, nef=32, ndf=64, nlatent=16, lr=2e-4, beta1=0.5, max_gnorm=500.0,
+             lambda_A=1.0, lambda_B=1.0, lambda_z_B=0.025, lambda_sup_A=0.1, lambda_sup_B=0.1, stoch_enc=False, z_gan=1,
+             enc_A_B=1, no_lsgan=False, norm="instance", use_dropout=False, which_model_netG="resnet",
+             which_model_netD="basic", gpu_ids=[0], monitor_gnorm=True, niter_decay=25, expr_dir="/tmp", n_blocks=3)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def build_model(meta):
+    from hip_util import load_recipe
+    from dtgan_amd import model as M
+    opt = make_opt(**meta["opt"])
+    m = M.AugmentedCycleGAN(opt, testing=True) if meta["aug"] else M.StochCycleGAN(opt, testing=True)
+    for k, net in m._net_dict().items():
+        load_recipe(net, k, meta["seed"], meta["flavour"])
+    return m
+
+
+@pytest.mark.parametrize("name", names("step"))
+def test_train_instance_matches_reference_golden(name):
+    from hip_util import t, n, rel
+    arr, meta = load(name)
+    m = build_model(meta)
+    for st in range(meta["steps"]):
+        A, B, z = (t(arr["s%d/%s" % (st, k)]) for k in ("real_A", "real_B", "prior_z_B"))
+        losses, visuals, gnorms = m.train_instance(A, B, z)
+        assert list(losses.keys()) == meta["loss_keys"]
+        assert list(gnorms.keys()) == meta["gnorm_keys"]
+        lt, gt, vt = (2e-4, 1e-3, 1e-4) if st == 0 else (1e-2, 3e-2, 5e-3)
+        got, ref = np.array(list(losses.values())), arr["s%d/losses" % st]
+        assert np.allclose(got, ref, rtol=lt, atol=2e-6), (st, dict(zip(meta["loss_keys"], zip(got, ref))))
+        gg, gr = np.array(list(gnorms.values())), arr["s%d/gnorms" % st]
+        assert np.allclose(gg, gr, rtol=gt, atol=1e-6), (st, dict(zip(meta["gnorm_keys"], zip(gg, gr))))
+        assert rel(n(visuals["fake_B"]), arr["s%d/fake_B" % st]) < vt
+        assert rel(n(visuals["fake_A"]), arr["s%d/fake_A" % st]) < vt
+        for k in ("real_A", "rec_A", "real_B", "rec_B"):
+            assert visuals[k].shape == visuals["real_A" if k.endswith("A") else "real_B"].shape
+
+
+def test_step_against_oracle_with_6_blocks():
+    """BASELINE config-1 shape with the north star's n_blocks=6 (the reference itself only builds 3):
+    HIP path vs the oracle run here, incl. post-step generator output (i.e. the applied update)."""
+    from hip_util import t, n, rel, load_recipe
+    from dtgan_amd import model as M
+    from oracle import recipe, step
+    kw = dict(input_nc=1, output_nc=1, ngf=8, nef=8, ndf=8, nlatent=4, n_blocks=6)
+    opt = make_opt(**kw)
+    m = M.AugmentedCycleGAN(opt, testing=True)
+    for k, net in m._net_dict().items():
+        load_recipe(net, k, 3, "rich")
+    o = step.AugStep(step.Opt(**kw))
+    o.load({k: recipe.values_for(net.shapes, k, 3, "rich") for k, net in o.nets().items()})
+    A, B, z = recipe.inputs(5, 2, 1, 1, 64, 4)
+    l1, v1, g1 = m.train_instance(t(A), t(B), t(z))
+    l0, v0, g0 = o.train_instance(A, B, z)
+    assert np.allclose(list(l1.values()), list(l0.values()), rtol=2e-4, atol=2e-6), (l1, l0)
+    assert np.allclose(list(g1.values()), list(g0.values()), rtol=1e-3, atol=1e-6), (g1, g0)
+    for k in ("fake_A", "fake_B", "rec_A", "rec_B"):
+        assert rel(n(v1[k]), v0[k]) < 1e-4, k
+    # weights after the step: compare the generators' outputs on a fresh batch
+    A2, B2, z2 = recipe.inputs(6, 2, 1, 1, 64, 4)
+    from oracle.tape import T
+    fb = n(m.predict_B(t(A2), t(z2)))
+    fbo = o.netG_A_B.forward(T(A2), T(z2)).v
+    assert rel(fb, fbo) < 5e-3

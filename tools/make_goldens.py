@@ -290,3 +290,16 @@ def make_step_goldens():
 if __name__ == "__main__":
     make_net_goldens()
     make_step_goldens()
+
+
+def make_key_fixture():
+    """state_dict keys + shapes of the reference's six networks at default widths."""
+    nets = dict(netG_A_B=rnet.define_stochastic_G(16, 3, 3, 32), netG_B_A=rnet.define_G(3, 3, 32),
+                netD_A=rnet.define_D_A(3, 32, "basic", "instance"), netD_B=rnet.define_D_B(3, 64, "basic", "instance"),
+                netD_z_B=rnet.define_LAT_D(16, 64), netE_B=rnet.define_E(16, 6, 32, "batch"))
+    keys = {k: [(a, list(b.shape)) for a, b in n.state_dict().items()] for k, n in nets.items()}
+    save("statedict_keys", dict(keys_json=np.frombuffer(json.dumps(keys).encode(), dtype=np.uint8)), kind="keys")
+
+
+if __name__ == "__main__":
+    make_key_fixture()
