@@ -95,7 +95,7 @@ def test_step_matches_reference(name):
         # step 0 is a pure function of the inputs: tight.  From step 1 on, the weights carry the
         # first Adam update, which turns fp32 rounding noise on ~zero-gradient tensors into +-lr
         # moves (see the note on Adam below) — in the reference as here — so later steps are looser.
-        lt, gt = (2e-4, 5e-4) if st == 0 else (1e-2, 3e-2)
+        lt, gt = (2e-4, 5e-4) if st == 0 else (1e-2, 6e-2)
         assert np.allclose(got, ref, rtol=lt, atol=2e-6), (st, dict(zip(meta["loss_keys"], zip(got, ref))))
         gg = np.array(list(gnorms.values()))
         gr = arr["s%d/gnorms" % st]
