@@ -38,9 +38,11 @@ def make_opt(a, local_rank):
 def cpu_baseline(a):
     """Oracle ("port": from-scratch C/NumPy restatement of the reference's networks.py/model.py path, pinned to the
     reference by tests/golden) timed on the host cores.  Bounded sample: ONE (A,B) pair of the same step."""
+    # the 1-GPU box's CPU share is 16 cores; pin the OpenMP pool BEFORE the C library loads
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(16, len(os.sched_getaffinity(0)))))
+    cores = int(os.environ["OMP_NUM_THREADS"])
     import numpy as np
     from oracle import recipe, step
-    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or len(os.sched_getaffinity(0))
     opt = step.Opt(input_nc=3, output_nc=3, n_blocks=a.blocks)
     m = step.AugStep(opt, dtype=np.float32)
     m.load({n: recipe.values_for(net.shapes, n, 0, "init") for n, net in m.nets().items()})
