@@ -44,6 +44,13 @@ def allreduce_mean_(bufs):
     ws = world_size()
     if ws <= 1:
         return
+    if td.get_backend() == "gloo" and bufs[0].is_cuda:
+        # test-only path (2 ranks sharing one GPU under gloo): stage through the host
+        for b in bufs:
+            h = b.cpu()
+            td.all_reduce(h, op=td.ReduceOp.SUM)
+            b.copy_(h.mul_(1.0 / ws))
+        return
     works = [td.all_reduce(b, op=td.ReduceOp.SUM, async_op=True) for b in bufs]
     for w in works:
         w.wait()
@@ -55,9 +62,15 @@ def broadcast_params_(nets):
     """Rank 0's initial parameters/buffers to every rank (replicas must start identical)."""
     if world_size() <= 1:
         return
+    stage = td.get_backend() == "gloo"
     for n in nets:
         for t in list(n.parameters()) + list(n.buffers()):
-            td.broadcast(t.data, src=0)
+            if stage and t.is_cuda:
+                h = t.data.cpu()
+                td.broadcast(h, src=0)
+                t.data.copy_(h)
+            else:
+                td.broadcast(t.data, src=0)
 
 
 def average_scalars(vals, sq_keys=(), min_keys=(), max_keys=()):

@@ -1,0 +1,49 @@
+"""GPU test of the data-parallel path: two ranks, each with half of the unpaired minibatch,
+gradients averaged by all-reduce BEFORE the per-network clip  ==  one rank on the whole minibatch.
+Both ranks share the box's single GPU, so the exchange runs over gloo here (RCCL needs one GPU per rank);
+the code path above the backend (flat gradient buckets, ordering w.r.t. clip/Adam, scalar averaging) is the
+one bench.py uses with backend "nccl".  StochCycleGAN has no BatchNorm, so the equality is exact up to fp32
+summation order; the AugmentedCycleGAN variant (per-rank BatchNorm statistics, as in the reference's own
+data_parallel) is checked for losses at step 0 only."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _run(tmp_path, ws, aug, port):
+    out = str(tmp_path / ("dp_ws%d_aug%d.npz" % (ws, aug)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(ws), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), out, str(aug)],
+                              env=dict(env, RANK=str(r), LOCAL_RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              text=True) for r in range(ws)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    return np.load(out)
+
+
+def test_two_ranks_equal_one_rank_stoch(tmp_path):
+    one = _run(tmp_path, 1, 0, 29541)
+    two = _run(tmp_path, 2, 0, 29542)
+    for st in range(2):
+        # losses are batch means -> rank average == global value; P_* monitors likewise
+        assert np.allclose(two["s%d/losses" % st], one["s%d/losses" % st], rtol=2e-4, atol=1e-6), st
+        # norms are taken AFTER the all-reduce -> identical on every rank and equal to the 1-rank norm
+        assert np.allclose(two["s%d/gnorms" % st], one["s%d/gnorms" % st], rtol=5e-4, atol=1e-6), st
+    for k in ("probe_fake_B", "probe_fake_A"):  # weights after two steps
+        assert np.max(np.abs(two[k] - one[k])) < 5e-3 * np.max(np.abs(one[k])), k
+
+
+def test_two_ranks_aug_step0_losses(tmp_path):
+    one = _run(tmp_path, 1, 1, 29543)
+    two = _run(tmp_path, 2, 1, 29544)
+    # generator / image-discriminator terms do not involve BatchNorm at step 0 -> equal; the latent terms
+    # (Cyc_z_B, KLD_z_B, Cyc_B, D_z_B at indices 3, 4, 7, 8) see per-rank BatchNorm statistics and are only finite.
+    idx = [0, 1, 2, 5, 6, 9, 10, 11, 12]  # Cyc_B (7) runs G_A_B on post_z = mu(E): BatchNorm-dependent too
+    assert np.allclose(two["s0/losses"][idx], one["s0/losses"][idx], rtol=2e-4, atol=1e-6)
+    assert np.all(np.isfinite(two["s1/losses"]))
