@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--blocks", type=int, default=9)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
+                    help="conv arithmetic: f32 = exact-fp32 MFMA (parity path, default); bf16 = bf16 operands, fp32 accumulate")
     a = ap.parse_args()
 
     import dtgan_amd
@@ -74,6 +76,7 @@ def main():
     assert ws == a.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, ws)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ops.set_precision(a.precision)
     torch.manual_seed(0)  # identical replicas by construction (and broadcast from rank 0 anyway)
     model = M.AugmentedCycleGAN(make_opt(a, local_rank), testing=True)
 
@@ -113,21 +116,23 @@ def main():
     kern_ms = sum(ms) / max(len(ms), 1)
     flops = 2.0 * N * (S // 2) * (S // 2) * 128 * 128 * 9
     achieved = flops / (kern_ms * 1e-3) / 1e12 if ms else None
+    peak = 157.3 if a.precision == "f32" else 2500.0   # dense MFMA peaks (MI355X_MICROARCH.md)
     traffic = None
     tj = os.path.join(ROOT, "profiles", "r01_resblock_conv_traffic.json")
-    if os.path.exists(tj) and (N, S) == (32, 256):
+    if os.path.exists(tj) and (N, S) == (32, 256) and a.precision == "f32":
         traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
     out = {
         "metric": "training images/sec, 256x256 Augmented CycleGAN step, 1/2/4/8 MI355X",
         "value": round(ws * N * a.steps / dt, 3), "unit": "images/s", "n_gpus": ws, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if a.precision == "f32" else "bf16 (MFMA operands; fp32 accumulate and fp32 tensors)", "data": "synthetic",
         "config": {"workload": "%dx%dx3 synthetic unpaired, %d-resblock G + latent encoder (full Augmented CycleGAN "
                                "train_instance), batch=%d per GPU (global %d)" % (S, S, a.blocks, N, N * ws),
                    "parallelism": "dp%d" % ws, "loss_G_A": round(losses["G_A"], 5)},
-        "roofline": {"bound": "mfma", "kernel": "igemm_conv_f32<128,128,2,2> (resblock 3x3 reflect 128->128 fwd)",
-                     "achieved": None if achieved is None else round(achieved, 2), "peak": 157.3, "unit": "TFLOP/s",
-                     "frac": None if achieved is None else round(achieved / 157.3, 4), "traffic": traffic,
+        "roofline": {"bound": "mfma", "kernel": "igemm_conv_%s<128,128,2,2> (resblock 3x3 reflect 128->128 fwd)" % a.precision,
+                     "achieved": None if achieved is None else round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                     "frac": None if achieved is None else round(achieved / peak, 4), "traffic": traffic,
                      "launches_timed": len(ms), "avg_launch_ms": round(kern_ms, 4), "flops_per_launch": flops},
     }
     if ws == 1 and not a.no_cpu_baseline:

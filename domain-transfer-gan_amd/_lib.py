@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libacgan_hip.so")
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 IMPL_MFMA, IMPL_DIRECT = 0, 1
+PREC_F32, PREC_BF16 = 0, 1
 
 c_int, c_float, c_size_t, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
 
@@ -30,6 +31,7 @@ SIGNATURES = {
     "acg_version": (c_int, []),
     "acg_last_error": (ctypes.c_char_p, []),
     "acg_set_conv_impl": (c_int, [c_int]),
+    "acg_set_conv_precision": (c_int, [c_int]),
     "acg_nchw_to_nhwc16": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "acg_nhwc16_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "acg_concat_channels": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_size_t, _P]),

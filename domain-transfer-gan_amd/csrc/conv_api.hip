@@ -4,6 +4,14 @@
 #include "conv_internal.h"
 
 int g_acg_conv_impl = ACG_IMPL_MFMA;
+int g_acg_precision = ACG_PREC_F32;
+extern "C" int acg_set_conv_precision(int prec)
+{
+    ACG_REQUIRE(prec == ACG_PREC_F32 || prec == ACG_PREC_BF16, "acg_set_conv_precision: unknown precision %d", prec);
+    g_acg_precision = prec;
+    return ACG_OK;
+}
+static bool use_bf16() { return g_acg_precision == ACG_PREC_BF16 && g_acg_conv_impl == ACG_IMPL_MFMA; }
 extern "C" int acg_set_conv_impl(int impl)
 {
     ACG_REQUIRE(impl == ACG_IMPL_MFMA || impl == ACG_IMPL_DIRECT, "acg_set_conv_impl: unknown impl %d", impl);
@@ -44,6 +52,37 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, int Or, int Ir, 
     }
 }
 
+// bf16 packing: wf16 [tap][Ci/16][CoP][16], wb16 [tap][Co/16][CiP][16] (same element counts, half the bytes)
+__global__ void pack_weight_bf16_kernel(const float *__restrict__ w, int Or, int Ir, int K, int Ci, int Co, int CoP,
+                                        int CiP, __bf16 *__restrict__ wf, __bf16 *__restrict__ wb)
+{
+    const int KK = K * K;
+    const long long nf = (long long)KK * (Ci / 16) * CoP * 16;
+    const long long nb = (long long)KK * (Co / 16) * CiP * 16;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nf + nb;
+         i += (long long)gridDim.x * blockDim.x) {
+        if (i < nf) {
+            if (wf == nullptr) continue;
+            long long r = i;
+            const int c16 = (int)(r % 16); r /= 16;
+            const int co = (int)(r % CoP); r /= CoP;
+            const int cb = (int)(r % (Ci / 16)); r /= (Ci / 16);
+            const int tap = (int)r;
+            const int ci = cb * 16 + c16;
+            wf[i] = (__bf16)((co < Or && ci < Ir) ? w[((long long)co * Ir + ci) * KK + tap] : 0.f);
+        } else {
+            if (wb == nullptr) continue;
+            long long r = i - nf;
+            const int c16 = (int)(r % 16); r /= 16;
+            const int ci = (int)(r % CiP); r /= CiP;
+            const int cb = (int)(r % (Co / 16)); r /= (Co / 16);
+            const int tap = (int)r;
+            const int co = cb * 16 + c16;
+            wb[i - nf] = (__bf16)((co < Or && ci < Ir) ? w[((long long)co * Ir + ci) * KK + tap] : 0.f);
+        }
+    }
+}
+
 extern "C" size_t acg_packed_wf_elems(int K, int Ci, int Co) { return (size_t)K * K * (Ci / 8) * acg_ncols_pad(Co) * 8; }
 extern "C" size_t acg_packed_wb_elems(int K, int Ci, int Co) { return (size_t)K * K * (Co / 8) * acg_ncols_pad(Ci) * 8; }
 
@@ -54,8 +93,12 @@ extern "C" int acg_pack_conv_weight(const float *w, int Or, int Ir, int K, int C
                 "acg_pack_conv_weight: bad dims Or=%d Ir=%d K=%d Ci=%d Co=%d", Or, Ir, K, Ci, Co);
     const long long n = (long long)acg_packed_wf_elems(K, Ci, Co) + (long long)acg_packed_wb_elems(K, Ci, Co);
     const int blocks = acg_cdiv(n, 256) > 2048 ? 2048 : acg_cdiv(n, 256);
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Or, Ir, K, Ci, Co,
-                       acg_ncols_pad(Co), acg_ncols_pad(Ci), wf, wb);
+    if (use_bf16())
+        hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Or, Ir, K, Ci, Co,
+                           acg_ncols_pad(Co), acg_ncols_pad(Ci), (__bf16 *)wf, (__bf16 *)wb);
+    else
+        hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Or, Ir, K, Ci, Co,
+                           acg_ncols_pad(Co), acg_ncols_pad(Ci), wf, wb);
     ACG_CHECK_LAUNCH("pack_weight_kernel");
     return ACG_OK;
 }
@@ -108,7 +151,7 @@ __global__ void reflect_fold_kernel(const float *__restrict__ dxp, float *__rest
 // ------------------------------------------------------------------------------------------
 // column sums (bias gradient): dy[M][C] -> db[c] (first Cr columns), two deterministic stages
 // ------------------------------------------------------------------------------------------
-#define COLSUM_ROWS 2048
+#define COLSUM_ROWS 4096
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ dy, long long M, int C,
                                                              float *__restrict__ part)
 {
@@ -131,13 +174,22 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__rest
         *(f32x4 *)(part + (long long)blockIdx.x * C + threadIdx.x * 4) = s;
     }
 }
-__global__ void colsum_final_kernel(const float *__restrict__ part, int nblk, int C, int Cr, float *__restrict__ db)
+// one block per 16 channels: 16 partial-block lanes per channel, fixed-order LDS tree (deterministic)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restrict__ part, int nblk, int C, int Cr,
+                                                           float *__restrict__ db)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Cr) return;
+    __shared__ float red[256];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), k = threadIdx.x >> 4;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(long long)b * C + c];
-    db[c] = s;
+    if (c < Cr)
+        for (int b = k; b < nblk; b += 16) s += part[(long long)b * C + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st >= 16; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x < 16 && c < Cr) db[c] = red[threadIdx.x];
 }
 static size_t colsum_ws_bytes(long long M, int C) { return (size_t)acg_cdiv(M, COLSUM_ROWS) * C * sizeof(float); }
 static int colsum_launch(const float *dy, long long M, int C, int Cr, float *db, float *ws, hipStream_t st)
@@ -145,7 +197,7 @@ static int colsum_launch(const float *dy, long long M, int C, int Cr, float *db,
     ACG_REQUIRE(C % 4 == 0 && C / 4 <= 256, "colsum: C=%d unsupported", C);
     const int nblk = acg_cdiv(M, COLSUM_ROWS);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, st, dy, M, C, ws);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(acg_cdiv(Cr, 64)), dim3(64), 0, st, ws, nblk, C, Cr, db);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(acg_cdiv(Cr, 16)), dim3(256), 0, st, ws, nblk, C, Cr, db);
     ACG_CHECK_LAUNCH("colsum");
     return ACG_OK;
 }
@@ -433,7 +485,7 @@ static void wgrad_plan(const acg_conv_desc *d, int Cx, int Cg, long long Mtot, i
     acg_wgrad_tiles(Cx, Cg, &bci, &bco);
     *CiP = (Cx + bci - 1) / bci * bci;
     *CoP = (Cg + bco - 1) / bco * bco;
-    const int KP = bci == 32 ? 128 : 32;
+    const int KP = 256; // multiple of every kernel variant's pixels-per-stage (fp32: 32/128, bf16: 64/256)
     const long long base = (long long)d->K * d->K * (*CiP / bci) * (*CoP / bco);
     long long ns = 1536 / base;
     const long long cap = Mtot / (KP * 4);

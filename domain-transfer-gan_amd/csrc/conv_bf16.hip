@@ -1,0 +1,386 @@
+// bf16-operand variants of the implicit-GEMM convolution and weight-gradient kernels
+// (v_mfma_f32_32x32x16_bf16: bf16 x bf16 products, fp32 accumulate — 16x the fp32 matrix rate).
+//
+// Tensors stay fp32 in HBM.  Activations are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) in registers
+// on their way into LDS; weights are pre-packed as bf16 once per optimiser step.  Same tap-list
+// formulation, tiling and C/D epilogue as the fp32 kernels (conv_igemm.hip / conv_wgrad.hip); the LDS
+// row slot is the same 32 bytes, now holding 16 k-values, so one ds_read_b128 is exactly one MFMA
+// operand (lane l: row l&31, k = 8*(l>>5) .. +7).
+//
+// This is the throughput mode (`acg_set_conv_precision(ACG_PREC_BF16)`); the fp32 kernels remain the
+// parity path (1e-3 bar).  Error model: each product carries two 2^-9 roundings, sums stay fp32.
+#include "conv_internal.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+template <int BM, int BN, int WM, int WN, int KC>
+__global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__ in, const __bf16 *__restrict__ wp,
+                                                       const float *__restrict__ bias, float *__restrict__ out,
+                                                       Geom g, Taps taps)
+{
+    constexpr int TM = BM / WM, TN = BN / WN, MB = TM / 32, NB = TN / 32;
+    constexpr int NKC = KC / 16;             // 16-wide k-chunks per stage
+    constexpr int UPR = KC / 8;              // 8-float units per gathered pixel row
+    constexpr int RPP = 256 / UPR;           // pixel rows per pass
+    constexpr int AL = BM / RPP;             // units per thread per stage
+    constexpr int BCH = NKC * BN * 2;        // 16-byte chunks in the B tile
+    constexpr int BL = (BCH + 255) / 256;
+    constexpr int AKS = BM * 16 + 16, BKS = BN * 16 + 16; // k-chunk strides (bf16 elements), +32 B pad
+    static_assert(WM * WN == 4 && AL >= 1 && MB >= 1 && NB >= 1, "tile config");
+
+    __shared__ __attribute__((aligned(16))) __bf16 As[NKC * AKS];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[NKC * BKS];
+    __shared__ long long out_off[BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int tiles_n = g.ncols_pad / BN;
+    const int tile_n = swz % tiles_n, tile_m = swz / tiles_n;
+    const int n0 = tile_n * BN;
+    const long long m0 = (long long)tile_m * BM;
+    const int GHW = g.GH * g.GW;
+
+    const int u = tid % UPR, rrow = tid / UPR;
+    int a_img[AL], a_by[AL], a_bx[AL];
+    bool a_ok[AL];
+#pragma unroll
+    for (int j = 0; j < AL; ++j) {
+        const long long m = m0 + rrow + RPP * j;
+        a_ok[j] = m < g.Mtot;
+        const long long mm = a_ok[j] ? m : 0;
+        const int n = (int)(mm / GHW);
+        const int r = (int)(mm - (long long)n * GHW);
+        const int gy = r / g.GW, gx = r - gy * g.GW;
+        a_img[j] = n;
+        a_by[j] = gy * g.is;
+        a_bx[j] = gx * g.is;
+    }
+    if (tid < BM) {
+        const long long m = m0 + tid;
+        long long off = -1;
+        if (m < g.Mtot) {
+            const int n = (int)(m / GHW);
+            const int r = (int)(m - (long long)n * GHW);
+            const int gy = r / g.GW, gx = r - gy * g.GW;
+            off = (((long long)n * g.Hout + (gy * g.os + g.oy0)) * g.Wout + (gx * g.os + g.ox0)) * g.Cout;
+        }
+        out_off[tid] = off;
+    }
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int S = taps.n * (g.Cin / KC);
+    f32x8 ra[AL];
+    f32x4 rb[BL]; // 8 bf16 each
+
+    auto load_stage = [&](int s) {
+        const int cc = s / taps.n;
+        const int t = s - cc * taps.n;
+        const int c0 = cc * KC;
+        const int ty = taps.dy[t], tx = taps.dx[t], tw = taps.w[t];
+#pragma unroll
+        for (int j = 0; j < AL; ++j) {
+            int iy = a_by[j] + ty, ix = a_bx[j] + tx;
+            bool ok = a_ok[j];
+            if (g.reflect) {
+                iy = iy < 0 ? -iy : iy;
+                iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
+                ix = ix < 0 ? -ix : ix;
+                ix = ix >= g.Win ? 2 * (g.Win - 1) - ix : ix;
+            } else {
+                ok = ok && iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win;
+            }
+            f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *(const f32x8 *)(in + (((long long)a_img[j] * g.Hin + iy) * g.Win + ix) * g.Cin + c0 + 8 * u);
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BL; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < BCH) {
+                const int kc = idx / (BN * 2);
+                const int rem = idx - kc * BN * 2;
+                rb[i] = *(const f32x4 *)(wp + (((long long)tw * (g.Cin >> 4) + (c0 >> 4) + kc) * g.ncols_pad + n0) * 16 +
+                                         rem * 8);
+            }
+        }
+    };
+
+    load_stage(0);
+    for (int s = 0; s < S; ++s) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < AL; ++j)
+            *(bf16x8 *)&As[(u >> 1) * AKS + (rrow + RPP * j) * 16 + (u & 1) * 8] = __builtin_convertvector(ra[j], bf16x8);
+#pragma unroll
+        for (int i = 0; i < BL; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < BCH) {
+                const int kc = idx / (BN * 2);
+                *(f32x4 *)&Bs[kc * BKS + (idx - kc * BN * 2) * 8] = rb[i];
+            }
+        }
+        __syncthreads();
+        if (s + 1 < S) load_stage(s + 1);
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            bf16x8 a[MB], b[NB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+                a[i] = *(const bf16x8 *)&As[kc * AKS + (wm * TM + i * 32 + (lane & 31)) * 16 + (lane >> 5) * 8];
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                b[j] = *(const bf16x8 *)&Bs[kc * BKS + (wn * TN + j * 32 + (lane & 31)) * 16 + (lane >> 5) * 8];
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int co = n0 + wn * TN + j * 32 + (lane & 31);
+        const bool cok = co < g.Cout;
+        const float bv = (bias != nullptr && cok) ? bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const long long off = out_off[row];
+                if (cok && off >= 0) out[off + co] = acg_apply_act(acc[i][j][r] + bv, g.act);
+            }
+        }
+    }
+}
+
+template <int KC>
+static void launch_bf16_kc(int bn, dim3 grid, hipStream_t st, const float *in, const __bf16 *wp, const float *bias,
+                           float *out, const Geom &g, const Taps &t)
+{
+    dim3 block(256);
+    if (bn == 128)
+        hipLaunchKernelGGL((igemm_conv_bf16<128, 128, 2, 2, KC>), grid, block, 0, st, in, wp, bias, out, g, t);
+    else if (bn == 64)
+        hipLaunchKernelGGL((igemm_conv_bf16<128, 64, 2, 2, KC>), grid, block, 0, st, in, wp, bias, out, g, t);
+    else
+        hipLaunchKernelGGL((igemm_conv_bf16<128, 32, 4, 1, KC>), grid, block, 0, st, in, wp, bias, out, g, t);
+}
+
+int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g0, const Taps &t,
+                          int bn, hipStream_t st)
+{
+    Geom g = g0;
+    g.tw = 0;
+    dim3 grid(acg_cdiv(g.Mtot, 128) * (g.ncols_pad / bn));
+    const __bf16 *w = (const __bf16 *)wp;
+    if (g.Cin % 64 == 0) launch_bf16_kc<64>(bn, grid, st, in, w, bias, out, g, t);
+    else if (g.Cin % 32 == 0) launch_bf16_kc<32>(bn, grid, st, in, w, bias, out, g, t);
+    else launch_bf16_kc<16>(bn, grid, st, in, w, bias, out, g, t);
+    ACG_CHECK_LAUNCH("igemm_conv_bf16");
+    return ACG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient, bf16 operands.  GEMM K = pixels: both operands need 8 consecutive PIXELS per lane for a
+// fixed channel, i.e. the transpose of the NHWC rows.  The transpose happens in registers on the way into
+// LDS: a thread loads the same channel quad of 8 consecutive pixels (8 x float4, each instruction covering
+// whole 512-B pixel rows across the wave) and writes four 16-byte [channel][8 pixels] fragments.
+// LDS images: Xs[ci][KP + 8], Ds[co][KP + 8] (bf16; +16 B row pad -> conflict-free ds_read_b128).
+// ------------------------------------------------------------------------------------------------
+template <int BCI, int BCO, int WI, int WJ, int WK, int KP>
+__global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, const float *__restrict__ dy,
+                                                  float *__restrict__ part, WGeom g, Taps taps)
+{
+    constexpr int TI = BCI / WI, TJ = BCO / WJ, MI = TI / 32, MJ = TJ / 32;
+    constexpr int RS = KP + 8;                          // LDS row stride (elements)
+    constexpr int XU = (KP / 8) * (BCI / 4), DU = (KP / 8) * (BCO / 4); // 8-pixel x 4-channel units
+    constexpr int XL = (XU + 255) / 256, DL = (DU + 255) / 256;
+    constexpr int KW = KP / WK;                         // pixels of a stage per wave
+    constexpr int DOFF = (XU + DU <= 256) ? XU : 0;     // threads [XU, XU+DU) load the dy units when both fit
+    static_assert(WI * WJ * WK == 4 && MI >= 1 && MJ >= 1 && KW % 16 == 0, "tile config");
+
+    __shared__ __attribute__((aligned(16))) __bf16 Xs[BCI * RS];
+    __shared__ __attribute__((aligned(16))) __bf16 Ds[BCO * RS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave % WK, wj = (wave / WK) % WJ, wi = wave / (WK * WJ);
+    const int tiles_ci = g.CiP / BCI, tiles_co = g.CoP / BCO;
+    int b = blockIdx.x;
+    const int tco = b % tiles_co; b /= tiles_co;
+    const int tci = b % tiles_ci; b /= tiles_ci;
+    const int tap = b % taps.n;
+    const int split = b / taps.n;
+    const int ci0 = tci * BCI, co0 = tco * BCO;
+    const int ty = taps.dy[tap], tx = taps.dx[tap];
+    const long long mbeg = (long long)split * g.m_per_split;
+    long long mend = mbeg + g.m_per_split;
+    if (mend > g.Mtot) mend = g.Mtot;
+    const int GHW = g.Hg * g.Wg;
+
+    f32x16 acc[MI][MJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 rx[XL][8], rd[DL][8];
+
+    auto load_stage = [&](long long k0) {
+#pragma unroll
+        for (int l = 0; l < XL; ++l) {
+            const int unit = tid + 256 * l;
+            const int c4 = unit % (BCI / 4), pg = unit / (BCI / 4);
+            const int ci = ci0 + c4 * 4;
+            long long m = k0 + pg * 8;
+            // decode the first pixel, then walk (gx, gy, n) incrementally
+            const long long mm = m < g.Mtot ? m : 0;
+            int n = (int)(mm / GHW);
+            int rr = (int)(mm - (long long)n * GHW);
+            int gy = rr / g.Wg, gx = rr - gy * g.Wg;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (unit < XU && m + p < mend && ci < g.Cin) {
+                    int iy = gy * g.is + ty, ix = gx * g.is + tx;
+                    bool ok = true;
+                    if (g.reflect) {
+                        iy = iy < 0 ? -iy : iy;
+                        iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
+                        ix = ix < 0 ? -ix : ix;
+                        ix = ix >= g.Win ? 2 * (g.Win - 1) - ix : ix;
+                    } else {
+                        ok = iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win;
+                    }
+                    if (ok) v = *(const f32x4 *)(x + (((long long)n * g.Hin + iy) * g.Win + ix) * g.Cin + ci);
+                }
+                rx[l][p] = v;
+                if (++gx == g.Wg) { gx = 0; if (++gy == g.Hg) { gy = 0; ++n; } }
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < DL; ++l) {
+            const int unit = DOFF ? (tid >= DOFF ? tid - DOFF : DU) : tid + 256 * l;
+            const int c4 = unit % (BCO / 4), pg = unit / (BCO / 4);
+            const int co = co0 + c4 * 4;
+            const long long m = k0 + pg * 8;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (unit < DU && m + p < mend && co < g.Cg) v = *(const f32x4 *)(dy + (m + p) * g.Cg + co);
+                rd[l][p] = v;
+            }
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int l = 0; l < XL; ++l) {
+            const int unit = tid + 256 * l;
+            if (unit < XU) {
+                const int c4 = unit % (BCI / 4), pg = unit / (BCI / 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    f32x8 v;
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) v[p] = rx[l][p][c];
+                    *(bf16x8 *)&Xs[(c4 * 4 + c) * RS + pg * 8] = __builtin_convertvector(v, bf16x8);
+                }
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < DL; ++l) {
+            const int unit = DOFF ? (tid >= DOFF ? tid - DOFF : DU) : tid + 256 * l;
+            if (unit < DU) {
+                const int c4 = unit % (BCO / 4), pg = unit / (BCO / 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    f32x8 v;
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) v[p] = rd[l][p][c];
+                    *(bf16x8 *)&Ds[(c4 * 4 + c) * RS + pg * 8] = __builtin_convertvector(v, bf16x8);
+                }
+            }
+        }
+    };
+
+    if (mbeg < mend) load_stage(mbeg);
+    for (long long k0 = mbeg; k0 < mend; k0 += KP) {
+        __syncthreads();
+        store_stage();
+        __syncthreads();
+        if (k0 + KP < mend) load_stage(k0 + KP);
+#pragma unroll
+        for (int kk = wk * KW; kk < (wk + 1) * KW; kk += 16) {
+            bf16x8 a[MI], bb[MJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = *(const bf16x8 *)&Xs[(wi * TI + i * 32 + (lane & 31)) * RS + kk + (lane >> 5) * 8];
+#pragma unroll
+            for (int j = 0; j < MJ; ++j) bb[j] = *(const bf16x8 *)&Ds[(wj * TJ + j * 32 + (lane & 31)) * RS + kk + (lane >> 5) * 8];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < MJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    if (WK > 1) {
+        static_assert(WK == 1 || (MI == 1 && MJ == 1), "split-K-in-block only for 32x32 tiles");
+        __syncthreads();
+        float *red = (float *)Xs; // needs 3 * 1024 floats = 12 KB
+        static_assert(WK == 1 || sizeof(__bf16) * BCI * RS >= 3 * 1024 * sizeof(float), "LDS reduce space");
+        if (wk > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wk - 1) * 16 + r) * 64 + lane] = acc[0][0][r];
+        }
+        __syncthreads();
+        if (wk == 0) {
+#pragma unroll
+            for (int w = 0; w < WK - 1; ++w)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][0][r] += red[(w * 16 + r) * 64 + lane];
+        }
+        if (wk != 0) return;
+    }
+
+    float *o = part + ((long long)split * taps.n + tap) * g.CiP * g.CoP;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + wi * TI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int co = co0 + wj * TJ + j * 32 + (lane & 31);
+                o[(long long)ci * g.CoP + co] = acc[i][j][r];
+            }
+}
+
+int acg_wgrad_bf16_launch(const float *x, const float *dy, float *part, const WGeom &g, const Taps &t, int bci,
+                          hipStream_t st)
+{
+    const int blocks = g.nsplit * t.n * (g.CiP / bci) * (g.CoP / bci);
+    dim3 grid(blocks), block(256);
+    if (bci == 128)
+        hipLaunchKernelGGL((wgrad_bf16<128, 128, 2, 2, 1, 64>), grid, block, 0, st, x, dy, part, g, t);
+    else if (bci == 64)
+        hipLaunchKernelGGL((wgrad_bf16<64, 64, 2, 2, 1, 64>), grid, block, 0, st, x, dy, part, g, t);
+    else
+        hipLaunchKernelGGL((wgrad_bf16<32, 32, 1, 1, 4, 256>), grid, block, 0, st, x, dy, part, g, t);
+    ACG_CHECK_LAUNCH("wgrad_bf16");
+    return ACG_OK;
+}

@@ -20,6 +20,7 @@ struct Geom {
     int reflect;          // 1: mirror out-of-range coordinates (ReflectionPad2d), 0: zeros
     int act;
     int ncols_pad;        // packed-weight column count (multiple of the N tile)
+    int tw;               // M-tile width for 2-D spatial tiles (0 = flattened pixels); set by the launcher
     long long Mtot;       // N*GH*GW
 };
 
@@ -39,3 +40,9 @@ struct WGeom {
 };
 int acg_wgrad_launch(const float *x, const float *dy, float *part, const WGeom &g, const Taps &t, hipStream_t st);
 void acg_wgrad_tiles(int Ci, int Co, int *bci, int *bco);
+
+extern int g_acg_precision;
+int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g, const Taps &t,
+                          int bn, hipStream_t st);
+int acg_wgrad_bf16_launch(const float *x, const float *dy, float *part, const WGeom &g, const Taps &t, int bci,
+                          hipStream_t st);

@@ -156,6 +156,7 @@ int acg_wgrad_launch(const float *x, const float *dy, float *part, const WGeom &
 {
     int bci, bco;
     acg_wgrad_tiles(g.Cin, g.Cg, &bci, &bco);
+    if (g_acg_precision == ACG_PREC_BF16) return acg_wgrad_bf16_launch(x, dy, part, g, t, bci, st);
     const int blocks = g.nsplit * t.n * (g.CiP / bci) * (g.CoP / bco);
     dim3 grid(blocks), block(256);
     if (bci == 128)

@@ -31,7 +31,7 @@ class _Cached(object):
     _acg_cache = None
 
     def _cache_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters(recurse=False))
+        return (ops.CONFIG_EPOCH,) + tuple((p.data_ptr(), p._version) for p in self.parameters(recurse=False))
 
     def _cached(self, build):
         key = self._cache_key()

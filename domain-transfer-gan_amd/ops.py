@@ -55,9 +55,28 @@ def workspace(nbytes, slot=0):
     return buf
 
 
+CONFIG_EPOCH = 0  # bumped whenever the packed-weight format changes (impl / precision switch)
+_PRECISION = "f32"
+
+
 def set_conv_impl(name):
     """'mfma' (product path) or 'direct' (naive HIP kernels, cross-check only)."""
+    global CONFIG_EPOCH
     _lib.call("acg_set_conv_impl", {"mfma": _lib.IMPL_MFMA, "direct": _lib.IMPL_DIRECT}[name])
+    CONFIG_EPOCH += 1
+
+
+def set_precision(name):
+    """Arithmetic of the MFMA convolution kernels: 'f32' (default, exact-fp32 matrix pipe, the parity path) or
+    'bf16' (operands rounded to bf16 in LDS, fp32 accumulate — throughput mode).  HBM tensors stay fp32."""
+    global CONFIG_EPOCH, _PRECISION
+    _lib.call("acg_set_conv_precision", {"f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16}[name])
+    _PRECISION = name
+    CONFIG_EPOCH += 1
+
+
+def get_precision():
+    return _PRECISION
 
 
 # ----------------------------------------------------------------------------------------------
