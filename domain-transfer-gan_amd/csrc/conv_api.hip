@@ -151,7 +151,7 @@ __global__ void reflect_fold_kernel(const float *__restrict__ dxp, float *__rest
 // ------------------------------------------------------------------------------------------
 // column sums (bias gradient): dy[M][C] -> db[c] (first Cr columns), two deterministic stages
 // ------------------------------------------------------------------------------------------
-#define COLSUM_ROWS 4096
+#define COLSUM_ROWS 2048
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ dy, long long M, int C,
                                                              float *__restrict__ part)
 {
@@ -221,6 +221,16 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ part, int nsplit, 
     const float *p = part + ((long long)tap * CiP + ci) * CoP + o;
     for (int k = 0; k < nsplit; ++k) s += p[k * stride];
     dw[((long long)o * Ir + ci) * KK + tap] = s;
+}
+
+// bias_part[nsplit][Cp] -> db[c] (first Cr channels), fixed order
+__global__ void bias_reduce_kernel(const float *__restrict__ part, int nsplit, int Cp, int Cr, float *__restrict__ db)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cr) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += part[(long long)k * Cp + c];
+    db[c] = s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -506,7 +516,8 @@ static size_t wgrad_ws_bytes(const acg_conv_desc *d, int Cx, int Cg, long long M
     const size_t part = (size_t)ns * d->K * d->K * CiP * CoP * sizeof(float);
     const int Cmax = d->Ci > d->Co ? d->Ci : d->Co;
     const long long Mbig = (long long)d->N * (d->Hi > d->Ho ? d->Hi : d->Ho) * (d->Wi > d->Wo ? d->Wi : d->Wo);
-    return acg_round_up(part, 256) + acg_round_up(colsum_ws_bytes(Mbig, Cmax), 256);
+    const size_t bias_part = (size_t)ns * (CiP > CoP ? CiP : CoP) * sizeof(float);
+    return acg_round_up(part, 256) + acg_round_up(colsum_ws_bytes(Mbig, Cmax) + bias_part, 256);
 }
 
 extern "C" size_t acg_conv2d_bwd_weight_workspace_bytes(const acg_conv_desc *d)
@@ -518,8 +529,9 @@ extern "C" size_t acg_conv2d_bwd_weight_workspace_bytes(const acg_conv_desc *d)
 }
 
 // x_side: conv-input-side tensor (N,Hi,Wi,Ci); g_side: conv-output-side tensor (N,Ho,Wo,Co)
+// bias_from: 0 none; 1 db[c] = column sums of g_side (Conv2d bias, Or entries); 2 of x_side (ConvTranspose bias, Ir entries)
 static int wgrad_common(const acg_conv_desc *d, const float *x_side, const float *g_side, float *dw, int Or, int Ir,
-                        void *ws, size_t ws_bytes, hipStream_t st)
+                        void *ws, size_t ws_bytes, hipStream_t st, int bias_from = 0, float *db = nullptr)
 {
     ACG_REQUIRE(Or <= d->Co && Ir <= d->Ci, "wgrad: Or=%d Ir=%d exceed padded dims", Or, Ir);
     if (g_acg_conv_impl == ACG_IMPL_DIRECT) {
@@ -539,8 +551,15 @@ static int wgrad_common(const acg_conv_desc *d, const float *x_side, const float
         acg_set_error("acg_conv2d_bwd_weight: workspace %zu < %zu", ws_bytes, need);
         return ACG_ERR_WORKSPACE;
     }
+    g.bias_from = db != nullptr ? bias_from : 0;
+    g.bias_part = (float *)((char *)ws + acg_round_up(need, 256));
     int rc = acg_wgrad_launch(x_side, g_side, (float *)ws, g, t, st);
     if (rc) return rc;
+    if (g.bias_from) {
+        const int Cp = bias_from == 1 ? g.CoP : g.CiP, Cr = bias_from == 1 ? Or : Ir;
+        hipLaunchKernelGGL(bias_reduce_kernel, dim3(acg_cdiv(Cr, 64)), dim3(64), 0, st, (const float *)g.bias_part, g.nsplit, Cp,
+                           Cr, db);
+    }
     const long long total = (long long)t.n * Ir * Or;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(acg_cdiv(total, 256)), dim3(256), 0, st, (const float *)ws, g.nsplit,
                        t.n, g.CiP, g.CoP, Or, Ir, dw);
@@ -564,11 +583,12 @@ extern "C" int acg_conv2d_bwd_weight(const acg_conv_desc *d, const float *x, con
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     ACG_REQUIRE(ws != nullptr && ws_bytes >= acg_conv2d_bwd_weight_workspace_bytes(d), "acg_conv2d_bwd_weight: workspace too small");
+    const bool fused = dw != nullptr && db != nullptr && g_acg_conv_impl == ACG_IMPL_MFMA;
     if (dw != nullptr) {
-        rc = wgrad_common(d, x, dy, dw, Or, Ir, ws, ws_bytes, st);
+        rc = wgrad_common(d, x, dy, dw, Or, Ir, ws, ws_bytes, st, 1, fused ? db : nullptr);
         if (rc) return rc;
     }
-    if (db != nullptr) {
+    if (db != nullptr && !fused) {
         size_t avail; float *cw = colsum_area(d, ws, ws_bytes, &avail);
         const long long M = (long long)d->N * d->Ho * d->Wo;
         ACG_REQUIRE(avail >= colsum_ws_bytes(M, d->Co), "acg_conv2d_bwd_weight: colsum workspace");
@@ -609,11 +629,14 @@ extern "C" int acg_conv_transpose2d_bwd_weight(const acg_conv_desc *d, const flo
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     ACG_REQUIRE(ws != nullptr && ws_bytes >= acg_conv2d_bwd_weight_workspace_bytes(d), "acg_conv_transpose2d_bwd_weight: workspace too small");
+    // no bias fusion here: the bias sums the GATHERED-side operand (dy of the ConvTranspose), whose tap-0 gather
+    // visits only a strided subset of its pixels; one separate column-sum pass per generator is cheap.
+    const bool fused = false;
     if (dw != nullptr) {
-        rc = wgrad_common(d, dy, x, dw, Or, Ir, ws, ws_bytes, st);
+        rc = wgrad_common(d, dy, x, dw, Or, Ir, ws, ws_bytes, st, 0, nullptr);
         if (rc) return rc;
     }
-    if (db != nullptr) {
+    if (db != nullptr && !fused) {
         size_t avail; float *cw = colsum_area(d, ws, ws_bytes, &avail);
         const long long M = (long long)d->N * d->Hi * d->Wi;
         ACG_REQUIRE(avail >= colsum_ws_bytes(M, d->Ci), "acg_conv_transpose2d_bwd_weight: colsum workspace");

@@ -218,7 +218,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave % WK, wj = (wave / WK) % WJ, wi = wave / (WK * WJ);
     const int tiles_ci = g.CiP / BCI, tiles_co = g.CoP / BCO;
-    int b = blockIdx.x;
+    // XCD-aware order: the blocks of one pixel range (all taps / tiles of a split) share an XCD and stream the
+    // same x / dy rows through one L2 instead of eight (bijective remap, any grid size)
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+    int b = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const int tco = b % tiles_co; b /= tiles_co;
     const int tci = b % tiles_ci; b /= tiles_ci;
     const int tap = b % taps.n;
@@ -239,6 +243,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 rx[XL][8], rd[DL][8];
+    const bool do_bias = g.bias_from != 0 && tap == 0 && (g.bias_from == 1 ? tci == 0 : tco == 0);
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
 
     auto load_stage = [&](long long k0) {
 #pragma unroll
@@ -321,6 +327,19 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
     for (long long k0 = mbeg; k0 < mend; k0 += KP) {
         __syncthreads();
         store_stage();
+        if (do_bias) { // fp32 column sums of the operand rows as they stream through registers (exact, not bf16)
+            if (g.bias_from == 1) {
+#pragma unroll
+                for (int l = 0; l < DL; ++l)
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) bsum += rd[l][p];
+            } else {
+#pragma unroll
+                for (int l = 0; l < XL; ++l)
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) bsum += rx[l][p];
+            }
+        }
         __syncthreads();
         if (k0 + KP < mend) load_stage(k0 + KP);
 #pragma unroll
@@ -336,6 +355,27 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
                 for (int j = 0; j < MJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bb[j], acc[i][j], 0, 0, 0);
         }
+    }
+
+    if (do_bias) { // threads of one unit column share a channel quad: fold them in fixed order through LDS
+        __syncthreads();
+        float *red = (float *)Xs;
+        const bool fromD = g.bias_from == 1;
+        const int q4 = (fromD ? BCO : BCI) / 4, nun = fromD ? DU : XU, off = fromD ? DOFF : 0;
+        // unit index of this thread for the chosen operand (first pass only: XL == DL == 1 whenever units <= 256)
+        const int unit = fromD ? (DOFF ? (tid >= DOFF ? tid - DOFF : nun) : tid) : tid;
+        static_assert(XL == 1 && DL == 1, "bias fusion assumes one unit per thread per operand");
+        (void)off;
+        if (unit < nun) *(f32x4 *)&red[unit * 4] = bsum;
+        __syncthreads();
+        if (tid < q4) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < nun / q4; ++r) s += *(const f32x4 *)&red[(r * q4 + tid) * 4];
+            const int cpad = fromD ? g.CoP : g.CiP;
+            const int c0 = fromD ? co0 : ci0;
+            *(f32x4 *)&g.bias_part[(long long)split * cpad + c0 + tid * 4] = s;
+        }
+        __syncthreads();
     }
 
     if (WK > 1) {

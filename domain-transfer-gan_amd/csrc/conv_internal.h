@@ -37,6 +37,8 @@ struct WGeom {
     int nsplit;
     long long Mtot;       // N*Hg*Wg
     long long m_per_split;
+    int bias_from;        // 0: none, 1: column sums of the gradient-side operand, 2: of the gathered-side operand
+    float *bias_part;     // [nsplit][CoP or CiP] partial column sums (written by the tap-0 / tile-0 blocks)
 };
 int acg_wgrad_launch(const float *x, const float *dy, float *part, const WGeom &g, const Taps &t, hipStream_t st);
 void acg_wgrad_tiles(int Ci, int Co, int *bci, int *bco);

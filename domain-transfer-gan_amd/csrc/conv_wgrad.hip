@@ -27,7 +27,11 @@ __global__ __launch_bounds__(256) void wgrad_f32(const float *__restrict__ x, co
     const int wk = wave % WK, wj = (wave / WK) % WJ, wi = wave / (WK * WJ);
 
     const int tiles_ci = g.CiP / BCI, tiles_co = g.CoP / BCO;
-    int b = blockIdx.x;
+    // XCD-aware order: the blocks of one pixel range (all taps / tiles of a split) share an XCD and stream the
+    // same x / dy rows through one L2 instead of eight (bijective remap, any grid size)
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+    int b = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const int tco = b % tiles_co; b /= tiles_co;
     const int tci = b % tiles_ci; b /= tiles_ci;
     const int tap = b % taps.n;
@@ -48,6 +52,8 @@ __global__ __launch_bounds__(256) void wgrad_f32(const float *__restrict__ x, co
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 rx[XL], rd[DL];
+    const bool do_bias = g.bias_from != 0 && tap == 0 && (g.bias_from == 1 ? tci == 0 : tco == 0);
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     auto load_stage = [&](long long k0) {
 #pragma unroll
         for (int j = 0; j < XL; ++j) {
@@ -93,6 +99,15 @@ __global__ __launch_bounds__(256) void wgrad_f32(const float *__restrict__ x, co
         for (int j = 0; j < XL; ++j) *(f32x4 *)&Xs[(tid + 256 * j) * 4] = rx[j];
 #pragma unroll
         for (int j = 0; j < DL; ++j) *(f32x4 *)&Ds[(tid + 256 * j) * 4] = rd[j];
+        if (do_bias) { // every j of a thread holds the same channel quad (256 % (BC/4) == 0)
+            if (g.bias_from == 1) {
+#pragma unroll
+                for (int j = 0; j < DL; ++j) bsum += rd[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < XL; ++j) bsum += rx[j];
+            }
+        }
         __syncthreads();
         if (k0 + KP < mend) load_stage(k0 + KP);
 #pragma unroll 4
@@ -109,6 +124,22 @@ __global__ __launch_bounds__(256) void wgrad_f32(const float *__restrict__ x, co
                 for (int j = 0; j < MJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
         }
+    }
+
+    if (do_bias) { // fixed-order fold of the per-thread column sums through LDS -> bias_part[split][channel]
+        __syncthreads();
+        const int BC = g.bias_from == 1 ? BCO : BCI;
+        const int q4 = BC / 4, rows = 256 / q4;
+        *(f32x4 *)&Xs[tid * 4] = bsum;
+        __syncthreads();
+        if (tid < q4) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < rows; ++r) s += *(const f32x4 *)&Xs[(r * q4 + tid) * 4];
+            const int cpad = g.bias_from == 1 ? g.CoP : g.CiP;
+            const int c0 = g.bias_from == 1 ? co0 : ci0;
+            *(f32x4 *)&g.bias_part[(long long)split * cpad + c0 + tid * 4] = s;
+        }
+        __syncthreads();
     }
 
     if (WK > 1) {
