@@ -20,7 +20,7 @@ c_int, c_float, c_size_t, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_size
 
 class ConvDesc(ctypes.Structure):
     """acg_conv_desc (include/acgan_hip.h)."""
-    _fields_ = [(k, c_int) for k in ("N", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "K", "stride", "pad", "pad_mode")]
+    _fields_ = [(k, c_int) for k in ("N", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "K", "stride", "pad", "pad_mode", "Cir", "Cor")]
 
 
 _P = c_void_p

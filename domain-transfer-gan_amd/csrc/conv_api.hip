@@ -12,6 +12,8 @@ extern "C" int acg_set_conv_precision(int prec)
     return ACG_OK;
 }
 static bool use_bf16() { return g_acg_precision == ACG_PREC_BF16 && g_acg_conv_impl == ACG_IMPL_MFMA; }
+// thin-channel K-flattening (fp32 MFMA kernels only): the gathered tensor has <= 4 real channels and K > 1
+static bool thin_ok(int creal, int K) { return creal >= 1 && creal <= 4 && K > 1 && g_acg_conv_impl == ACG_IMPL_MFMA && !use_bf16(); }
 extern "C" int acg_set_conv_impl(int impl)
 {
     ACG_REQUIRE(impl == ACG_IMPL_MFMA || impl == ACG_IMPL_DIRECT, "acg_set_conv_impl: unknown impl %d", impl);
@@ -83,6 +85,30 @@ __global__ void pack_weight_bf16_kernel(const float *__restrict__ w, int Or, int
     }
 }
 
+// thin packing: rows are k = tap*4 + c (c < 4), grouped in 8-chunks: out[kc][col][8].
+// mode 0 (forward operand):  c = input channel,  col = output channel -> w[col][c][tap]
+// mode 1 (data-gradient):    c = output channel, col = input channel  -> w[c][col][tap]
+__global__ void pack_weight_thin_kernel(const float *__restrict__ w, int Or, int Ir, int KK, int ColP, int mode,
+                                        float *__restrict__ out)
+{
+    const int nkc = 4 * ((KK + 7) / 8);
+    const long long total = (long long)nkc * ColP * 8;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long r = i;
+        const int c8 = (int)(r % 8); r /= 8;
+        const int col = (int)(r % ColP); r /= ColP;
+        const int kflat = (int)r * 8 + c8;
+        const int tap = kflat >> 2, c = kflat & 3;
+        float v = 0.f;
+        if (tap < KK) {
+            if (mode == 0) { if (col < Or && c < Ir) v = w[((long long)col * Ir + c) * KK + tap]; }
+            else           { if (c < Or && col < Ir) v = w[((long long)c * Ir + col) * KK + tap]; }
+        }
+        out[i] = v;
+    }
+}
+
 extern "C" size_t acg_packed_wf_elems(int K, int Ci, int Co) { return (size_t)K * K * (Ci / 8) * acg_ncols_pad(Co) * 8; }
 extern "C" size_t acg_packed_wb_elems(int K, int Ci, int Co) { return (size_t)K * K * (Co / 8) * acg_ncols_pad(Ci) * 8; }
 
@@ -93,6 +119,20 @@ extern "C" int acg_pack_conv_weight(const float *w, int Or, int Ir, int K, int C
                 "acg_pack_conv_weight: bad dims Or=%d Ir=%d K=%d Ci=%d Co=%d", Or, Ir, K, Ci, Co);
     const long long n = (long long)acg_packed_wf_elems(K, Ci, Co) + (long long)acg_packed_wb_elems(K, Ci, Co);
     const int blocks = acg_cdiv(n, 256) > 2048 ? 2048 : acg_cdiv(n, 256);
+    const bool thin_f = thin_ok(Ir, K), thin_b = thin_ok(Or, K);
+    if (thin_f || thin_b) {
+        // thin operands get their own (smaller) layout in the same buffers; the other operand is packed normally
+        if (thin_f && wf)
+            hipLaunchKernelGGL(pack_weight_thin_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, Or, Ir, K * K,
+                               acg_ncols_pad(Co), 0, wf);
+        if (thin_b && wb)
+            hipLaunchKernelGGL(pack_weight_thin_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, Or, Ir, K * K,
+                               acg_ncols_pad(Ci), 1, wb);
+        hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Or, Ir, K, Ci, Co,
+                           acg_ncols_pad(Co), acg_ncols_pad(Ci), thin_f ? (float *)nullptr : wf, thin_b ? (float *)nullptr : wb);
+        ACG_CHECK_LAUNCH("pack_weight_thin_kernel");
+        return ACG_OK;
+    }
     if (use_bf16())
         hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Or, Ir, K, Ci, Co,
                            acg_ncols_pad(Co), acg_ncols_pad(Ci), (__bf16 *)wf, (__bf16 *)wb);
@@ -206,8 +246,9 @@ static int colsum_launch(const float *dy, long long M, int C, int Cr, float *db,
 // split-K reduction of weight-gradient partials -> torch OIHW (real Or x Ir)
 // part[nsplit][KK][CiP][CoP]
 // ------------------------------------------------------------------------------------------
+// thin: part[nsplit][1][CiP][CoP] with row = tap*4 + ci
 __global__ void wgrad_reduce_kernel(const float *__restrict__ part, int nsplit, int KK, int CiP, int CoP, int Or,
-                                    int Ir, float *__restrict__ dw)
+                                    int Ir, float *__restrict__ dw, int thin)
 {
     const long long total = (long long)KK * Ir * Or;
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -217,8 +258,8 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ part, int nsplit, 
     const int ci = (int)(r % Ir); r /= Ir;
     const int tap = (int)r;
     float s = 0.f;
-    const long long stride = (long long)KK * CiP * CoP;
-    const float *p = part + ((long long)tap * CiP + ci) * CoP + o;
+    const long long stride = thin ? (long long)CiP * CoP : (long long)KK * CiP * CoP;
+    const float *p = thin ? part + ((long long)(tap * 4 + ci)) * CoP + o : part + ((long long)tap * CiP + ci) * CoP + o;
     for (int k = 0; k < nsplit; ++k) s += p[k * stride];
     dw[((long long)o * Ir + ci) * KK + tap] = s;
 }
@@ -367,6 +408,7 @@ static void fwd_geom(const acg_conv_desc *d, Geom *g, Taps *t, int act)
     g->GH = d->Ho; g->GW = d->Wo; g->os = 1; g->oy0 = 0; g->ox0 = 0; g->is = d->stride;
     g->reflect = d->pad_mode == ACG_PAD_REFLECT; g->act = act; g->ncols_pad = acg_ncols_pad(d->Co);
     g->Mtot = (long long)d->N * d->Ho * d->Wo;
+    g->thin = thin_ok(d->Cir, d->K) ? 1 : 0;
     t->n = 0;
     for (int kh = 0; kh < d->K; ++kh)
         for (int kw = 0; kw < d->K; ++kw) {
@@ -383,6 +425,7 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
     Geom g; Taps t;
     g.Hin = d->Ho; g.Win = d->Wo; g.Cin = d->Co;
     g.Cout = d->Ci; g.reflect = 0; g.act = act; g.ncols_pad = acg_ncols_pad(d->Ci); g.is = 1;
+    g.thin = (d->stride == 1 && thin_ok(d->Cor, d->K)) ? 1 : 0;
     const int p = d->pad, K = d->K;
     if (d->stride == 1) {
         const bool refl = d->pad_mode == ACG_PAD_REFLECT && p > 0;
@@ -419,6 +462,7 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
         }
         return ACG_OK;
     }
+    ACG_REQUIRE(!thin_ok(d->Cor, d->K), "dgrad: stride 2 with <= 4 output channels is not supported by the thin packing");
     // stride 2: four sub-pixel phases, each a dense small-tap convolution (no zero insertion)
     ACG_REQUIRE(d->pad_mode == ACG_PAD_ZERO, "dgrad: stride 2 needs zero padding");
     g.Hout = d->Hi; g.Wout = d->Wi; g.os = 2;
@@ -488,6 +532,8 @@ extern "C" int acg_conv2d_bwd_data(const acg_conv_desc *d, const float *dy, cons
 }
 
 // split-K plan shared by the workspace query and the launch
+static bool wgrad_thin(const acg_conv_desc *d) { return thin_ok(d->Cir, d->K); }
+
 static void wgrad_plan(const acg_conv_desc *d, int Cx, int Cg, long long Mtot, int *CiP, int *CoP, int *nsplit,
                        long long *mps)
 {
@@ -495,8 +541,13 @@ static void wgrad_plan(const acg_conv_desc *d, int Cx, int Cg, long long Mtot, i
     acg_wgrad_tiles(Cx, Cg, &bci, &bco);
     *CiP = (Cx + bci - 1) / bci * bci;
     *CoP = (Cg + bco - 1) / bco * bco;
+    if (wgrad_thin(d)) { // gathered columns = (tap, 4 channels): 32 per 8 taps, ONE tap-block
+        bci = bco = 32;
+        *CiP = 32 * ((d->K * d->K + 7) / 8);
+        *CoP = (Cg + 31) / 32 * 32;
+    }
     const int KP = 256; // multiple of every kernel variant's pixels-per-stage (fp32: 32/128, bf16: 64/256)
-    const long long base = (long long)d->K * d->K * (*CiP / bci) * (*CoP / bco);
+    const long long base = (wgrad_thin(d) ? 1LL : (long long)d->K * d->K) * (*CiP / bci) * (*CoP / bco);
     long long ns = 1536 / base;
     const long long cap = Mtot / (KP * 4);
     if (ns > cap) ns = cap;
@@ -531,7 +582,8 @@ extern "C" size_t acg_conv2d_bwd_weight_workspace_bytes(const acg_conv_desc *d)
 // x_side: conv-input-side tensor (N,Hi,Wi,Ci); g_side: conv-output-side tensor (N,Ho,Wo,Co)
 // bias_from: 0 none; 1 db[c] = column sums of g_side (Conv2d bias, Or entries); 2 of x_side (ConvTranspose bias, Ir entries)
 static int wgrad_common(const acg_conv_desc *d, const float *x_side, const float *g_side, float *dw, int Or, int Ir,
-                        void *ws, size_t ws_bytes, hipStream_t st, int bias_from = 0, float *db = nullptr)
+                        void *ws, size_t ws_bytes, hipStream_t st, int bias_from = 0, float *db = nullptr,
+                        bool thin_conv = false)
 {
     ACG_REQUIRE(Or <= d->Co && Ir <= d->Ci, "wgrad: Or=%d Ir=%d exceed padded dims", Or, Ir);
     if (g_acg_conv_impl == ACG_IMPL_DIRECT) {
@@ -544,9 +596,11 @@ static int wgrad_common(const acg_conv_desc *d, const float *x_side, const float
     fwd_geom(d, &gf, &t, 0);
     g.Hin = d->Hi; g.Win = d->Wi; g.Cin = d->Ci; g.Hg = d->Ho; g.Wg = d->Wo; g.Cg = d->Co;
     g.is = d->stride; g.reflect = d->pad_mode == ACG_PAD_REFLECT;
+    g.thin = (thin_conv && wgrad_thin(d)) ? 1 : 0;
     g.Mtot = (long long)d->N * d->Ho * d->Wo;
     wgrad_plan(d, d->Ci, d->Co, g.Mtot, &g.CiP, &g.CoP, &g.nsplit, &g.m_per_split);
-    const size_t need = (size_t)g.nsplit * t.n * g.CiP * g.CoP * sizeof(float);
+    const int ntb = g.thin ? 1 : t.n;
+    const size_t need = (size_t)g.nsplit * ntb * g.CiP * g.CoP * sizeof(float);
     if (ws == nullptr || ws_bytes < need) {
         acg_set_error("acg_conv2d_bwd_weight: workspace %zu < %zu", ws_bytes, need);
         return ACG_ERR_WORKSPACE;
@@ -562,7 +616,7 @@ static int wgrad_common(const acg_conv_desc *d, const float *x_side, const float
     }
     const long long total = (long long)t.n * Ir * Or;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(acg_cdiv(total, 256)), dim3(256), 0, st, (const float *)ws, g.nsplit,
-                       t.n, g.CiP, g.CoP, Or, Ir, dw);
+                       t.n, g.CiP, g.CoP, Or, Ir, dw, g.thin);
     ACG_CHECK_LAUNCH("wgrad_reduce_kernel");
     return ACG_OK;
 }
@@ -585,7 +639,7 @@ extern "C" int acg_conv2d_bwd_weight(const acg_conv_desc *d, const float *x, con
     ACG_REQUIRE(ws != nullptr && ws_bytes >= acg_conv2d_bwd_weight_workspace_bytes(d), "acg_conv2d_bwd_weight: workspace too small");
     const bool fused = dw != nullptr && db != nullptr && g_acg_conv_impl == ACG_IMPL_MFMA;
     if (dw != nullptr) {
-        rc = wgrad_common(d, x, dy, dw, Or, Ir, ws, ws_bytes, st, 1, fused ? db : nullptr);
+        rc = wgrad_common(d, x, dy, dw, Or, Ir, ws, ws_bytes, st, 1, fused ? db : nullptr, true);
         if (rc) return rc;
     }
     if (db != nullptr && !fused) {

@@ -184,6 +184,7 @@ int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, fl
 {
     Geom g = g0;
     g.tw = 0;
+    g.thin = 0;
     dim3 grid(acg_cdiv(g.Mtot, 128) * (g.ncols_pad / bn));
     const __bf16 *w = (const __bf16 *)wp;
     if (g.Cin % 64 == 0) launch_bf16_kc<64>(bn, grid, st, in, w, bias, out, g, t);

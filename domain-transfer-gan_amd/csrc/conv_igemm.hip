@@ -102,18 +102,30 @@ __global__ __launch_bounds__(256) void igemm_conv_f32(const float *__restrict__ 
 
     // K order: channel chunk OUTER, taps INNER — the 128-B (KC=32) segment of every halo pixel is re-read by
     // all taps back to back while it is hot in L1/L2, so the per-XCD working set stays ~halo x 128 B per block.
-    const int S = taps.n * (g.Cin / KC);
+    const int S = g.thin ? (taps.n + 7) / 8 : taps.n * (g.Cin / KC);
     f32x4 ra[AL], rb[BL];
 
     auto load_stage = [&](int s) {
-        const int cc = s / taps.n;
-        const int t = s - cc * taps.n;
-        const int c0 = cc * KC;
-        const int ty = taps.dy[t], tx = taps.dx[t], tw = taps.w[t];
+        int cc = s / taps.n;
+        int t = s - cc * taps.n;
+        int c0 = cc * KC, tw, ty, tx, coff = 4 * q;
+        bool tok = true;
+        if (KC == 32 && g.thin) { // this thread's 16-byte chunk q is tap 8s+q, channels 0..3
+            t = s * 8 + q;
+            tok = t < taps.n;
+            t = tok ? t : 0;
+            c0 = s * KC;
+            coff = -c0; // gather channel offset 0 (c0 + coff == 0); c0 still addresses the flattened weight rows
+            tw = 0;
+        } else {
+            tw = taps.w[t];
+        }
+        ty = taps.dy[t];
+        tx = taps.dx[t];
 #pragma unroll
         for (int j = 0; j < AL; ++j) {
             int iy = a_by[j] + ty, ix = a_bx[j] + tx;
-            bool ok = a_ok[j];
+            bool ok = a_ok[j] && tok;
             if (g.reflect) {
                 iy = iy < 0 ? -iy : iy;
                 iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
@@ -123,7 +135,7 @@ __global__ __launch_bounds__(256) void igemm_conv_f32(const float *__restrict__ 
                 ok = ok && iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win;
             }
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *(const f32x4 *)(in + (((long long)a_img[j] * g.Hin + iy) * g.Win + ix) * g.Cin + c0 + 4 * q);
+            if (ok) v = *(const f32x4 *)(in + (((long long)a_img[j] * g.Hin + iy) * g.Win + ix) * g.Cin + c0 + coff);
             ra[j] = v;
         }
 #pragma unroll
@@ -132,7 +144,7 @@ __global__ __launch_bounds__(256) void igemm_conv_f32(const float *__restrict__ 
             if (idx < BCH) {
                 const int kc = idx / (BN * 2);
                 const int rem = idx - kc * BN * 2;
-                rb[i] = *(const f32x4 *)(wp + (((long long)tw * (g.Cin >> 3) + (c0 >> 3) + kc) * g.ncols_pad + n0) * 8 +
+                rb[i] = *(const f32x4 *)(wp + (((long long)tw * g.bk8 + (c0 >> 3) + kc) * g.ncols_pad + n0) * 8 +
                                          rem * 4);
             }
         }
@@ -258,7 +270,8 @@ int acg_igemm_launch(const float *in, const float *wp, const float *bias, float 
     }
     const int tiles_n = g.ncols_pad / bn;
     dim3 grid(tiles_m * tiles_n);
-    const bool kc32 = (g.Cin % 32 == 0) && kKC == 32;
+    if (g.thin) g.bk8 = 4 * ((t.n + 7) / 8); else g.bk8 = g.Cin / 8;
+    const bool kc32 = ((g.Cin % 32 == 0) && kKC == 32) || g.thin;
     if (kc32 && kDB) launch_kc<32, 1>(bn, grid, st, in, wp, bias, out, g, t);
     else if (kc32) launch_kc<32, 0>(bn, grid, st, in, wp, bias, out, g, t);
     else if (kDB) launch_kc<16, 1>(bn, grid, st, in, wp, bias, out, g, t);

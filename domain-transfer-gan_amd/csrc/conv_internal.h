@@ -20,6 +20,8 @@ struct Geom {
     int reflect;          // 1: mirror out-of-range coordinates (ReflectionPad2d), 0: zeros
     int act;
     int ncols_pad;        // packed-weight column count (multiple of the N tile)
+    int thin;             // 1: K flattened over (tap, 4 channels): stage s = taps 8s..8s+7, channels 0..3 of each
+    int bk8;              // 8-float k-chunks per packed weight slab (Cin/8; thin: 4*ceil(ntaps/8), single slab)
     int tw;               // M-tile width for 2-D spatial tiles (0 = flattened pixels); set by the launcher
     long long Mtot;       // N*GH*GW
 };
@@ -37,6 +39,7 @@ struct WGeom {
     int nsplit;
     long long Mtot;       // N*Hg*Wg
     long long m_per_split;
+    int thin;             // 1: gathered operand columns = (tap, 4 channels) flattened, 8 taps per 32-column tile
     int bias_from;        // 0: none, 1: column sums of the gradient-side operand, 2: of the gathered-side operand
     float *bias_part;     // [nsplit][CoP or CiP] partial column sums (written by the tap-0 / tile-0 blocks)
 };

@@ -34,10 +34,11 @@ __global__ __launch_bounds__(256) void wgrad_f32(const float *__restrict__ x, co
     int b = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const int tco = b % tiles_co; b /= tiles_co;
     const int tci = b % tiles_ci; b /= tiles_ci;
-    const int tap = b % taps.n;
-    const int split = b / taps.n;
+    const int ntap_blocks = g.thin ? 1 : taps.n;
+    const int tap = b % ntap_blocks;
+    const int split = b / ntap_blocks;
     const int ci0 = tci * BCI, co0 = tco * BCO;
-    const int ty = taps.dy[tap], tx = taps.dx[tap];
+    int ty = taps.dy[tap], tx = taps.dx[tap];
     const long long mbeg = (long long)split * g.m_per_split;
     long long mend = mbeg + g.m_per_split;
     if (mend > g.Mtot) mend = g.Mtot;
@@ -61,8 +62,16 @@ __global__ __launch_bounds__(256) void wgrad_f32(const float *__restrict__ x, co
             const int r = idx / (BCI / 4), c4 = idx - r * (BCI / 4);
             const long long m = k0 + r;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            const int ci = ci0 + c4 * 4;
-            if (m < mend && ci < g.Cin) {
+            int ci = ci0 + c4 * 4;
+            bool cok = ci < g.Cin;
+            if (BCI == 32 && g.thin) { // column quad c4 of tile tci = tap 8*tci + c4, channels 0..3
+                const int t = tci * 8 + c4;
+                cok = t < taps.n;
+                ty = taps.dy[cok ? t : 0];
+                tx = taps.dx[cok ? t : 0];
+                ci = 0;
+            }
+            if (m < mend && cok) {
                 const int n = (int)(m / GHW);
                 const int rr = (int)(m - (long long)n * GHW);
                 const int gy = rr / g.Wg, gx = rr - gy * g.Wg;
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(256) void wgrad_f32(const float *__restrict__ x, co
         if (wk != 0) return;
     }
 
-    float *o = part + ((long long)split * taps.n + tap) * g.CiP * g.CoP;
+    float *o = part + ((long long)split * ntap_blocks + tap) * g.CiP * g.CoP;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -188,7 +197,7 @@ int acg_wgrad_launch(const float *x, const float *dy, float *part, const WGeom &
     int bci, bco;
     acg_wgrad_tiles(g.Cin, g.Cg, &bci, &bco);
     if (g_acg_precision == ACG_PREC_BF16) return acg_wgrad_bf16_launch(x, dy, part, g, t, bci, st);
-    const int blocks = g.nsplit * t.n * (g.CiP / bci) * (g.CoP / bco);
+    const int blocks = g.nsplit * (g.thin ? 1 : t.n) * (g.CiP / bci) * (g.CoP / bco);
     dim3 grid(blocks), block(256);
     if (bci == 128)
         hipLaunchKernelGGL((wgrad_f32<128, 128, 2, 2, 1, 32>), grid, block, 0, st, x, dy, part, g, t);

@@ -195,10 +195,11 @@ class ConvTimer(object):
 CONV_TIMER = None
 
 
-def conv_desc(N, Hi, Wi, Ci, Co, K, stride, pad, pad_mode):
+def conv_desc(N, Hi, Wi, Ci, Co, K, stride, pad, pad_mode, Cir=0, Cor=0):
+    """Cir / Cor: real (unpadded) channel counts — let the library pick the thin-channel kernels (0 = unknown)."""
     Ho = (Hi + 2 * pad - K) // stride + 1
     Wo = (Wi + 2 * pad - K) // stride + 1
-    return ConvDesc(N, Hi, Wi, Ci, Ho, Wo, Co, K, stride, pad, pad_mode)
+    return ConvDesc(N, Hi, Wi, Ci, Ho, Wo, Co, K, stride, pad, pad_mode, Cir, Cor)
 
 
 class Conv2dFn(torch.autograd.Function):
@@ -211,7 +212,7 @@ class Conv2dFn(torch.autograd.Function):
         N, Hi, Wi, Ci = x.shape
         if Ci != packed.Ci:
             raise _lib.AcgError("conv: input has %d stored channels, weight packed for %d" % (Ci, packed.Ci))
-        d = conv_desc(N, Hi, Wi, Ci, packed.Co, packed.K, stride, pad, pad_mode)
+        d = conv_desc(N, Hi, Wi, Ci, packed.Co, packed.K, stride, pad, pad_mode, packed.Ir, packed.Or)
         if d.Ho <= 0 or d.Wo <= 0:
             raise _lib.AcgError("conv: input %dx%d too small for kernel %d" % (Hi, Wi, packed.K))
         y = torch.empty((N, d.Ho, d.Wo, packed.Co), device=x.device, dtype=torch.float32)

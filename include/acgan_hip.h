@@ -47,6 +47,8 @@ typedef struct {
     int N, Hi, Wi, Ci;
     int Ho, Wo, Co;
     int K, stride, pad, pad_mode;
+    int Cir, Cor; /* REAL (unpadded) channel counts, 0 = unknown.  Cir <= 4 / Cor <= 4 select the thin-channel
+                   * K-flattening (8 taps x 4 channels per 32-deep stage) in the fp32 kernels. */
 } acg_conv_desc;
 
 int acg_version(void);
