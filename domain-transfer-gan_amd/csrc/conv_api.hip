@@ -14,6 +14,12 @@ extern "C" int acg_set_conv_precision(int prec)
 static bool use_bf16() { return g_acg_precision == ACG_PREC_BF16 && g_acg_conv_impl == ACG_IMPL_MFMA; }
 // thin-channel K-flattening (fp32 MFMA kernels only): the gathered tensor has <= 4 real channels and K > 1
 static bool thin_ok(int creal, int K) { return creal >= 1 && creal <= 4 && K > 1 && g_acg_conv_impl == ACG_IMPL_MFMA && !use_bf16(); }
+// a layer is treated as thin on exactly one side (3->3 convolutions do not occur on this path and stay regular)
+static bool thin_in(const acg_conv_desc *d) { return thin_ok(d->Cir, d->K) && !thin_ok(d->Cor, d->K); }
+static bool thin_out(const acg_conv_desc *d) { return thin_ok(d->Cor, d->K) && !thin_ok(d->Cir, d->K); }
+// the VALU thin-output kernel pays off up to 64 gathered channels (>= 4 pixels per wave); wider layers use the MFMA kernel
+static bool thin_out_valu_fwd(const acg_conv_desc *d) { return thin_out(d) && d->Ci <= 64; }
+static bool thin_in_valu_dgrad(const acg_conv_desc *d) { return thin_in(d) && d->Co <= 64; }
 extern "C" int acg_set_conv_impl(int impl)
 {
     ACG_REQUIRE(impl == ACG_IMPL_MFMA || impl == ACG_IMPL_DIRECT, "acg_set_conv_impl: unknown impl %d", impl);
@@ -109,6 +115,127 @@ __global__ void pack_weight_thin_kernel(const float *__restrict__ w, int Or, int
     }
 }
 
+// thin-OUTPUT packing: out[(tap*Kc + k)*4 + n], n < 4 output columns, k over the Kc gathered channels.
+// mode 0 (forward, Cout <= 4): k = input channel, n = output channel -> w[n][k][tap]
+// mode 1 (data-gradient, Cin <= 4): k = output channel, n = input channel -> w[k][n][tap]
+__global__ void pack_weight_thinN_kernel(const float *__restrict__ w, int Or, int Ir, int KK, int Kc, int mode,
+                                         float *__restrict__ out)
+{
+    const long long total = (long long)KK * Kc * 4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i & 3);
+        const int k = (int)((i >> 2) % Kc);
+        const int tap = (int)((i >> 2) / Kc);
+        float v = 0.f;
+        if (mode == 0) { if (n < Or && k < Ir) v = w[((long long)n * Ir + k) * KK + tap]; }
+        else           { if (k < Or && n < Ir) v = w[((long long)k * Ir + n) * KK + tap]; }
+        out[i] = v;
+    }
+}
+
+// Convolutions whose OUTPUT has <= 4 real channels (7x7 32->3 head + tanh, PatchGAN heads, data gradients into
+// image tensors).  N = 4 cannot feed a 32-wide MFMA tile, so this is a VALU kernel (HBM/L1-friendly form):
+// LPP = Cin/4 lanes cooperate on one output pixel — lane j owns channels 4j..4j+3, so a wave reads whole
+// contiguous pixel rows (coalesced) — each lane keeps 4 partial sums, the weights [tap][ci][4] are staged once
+// per block in LDS, and the LPP partials are folded with wave shuffles.  Same Geom/Taps formulation as the MFMA
+// kernel; lane 0 of each pixel writes the full C16 row (pad channels = 0).
+#define THIN_PIX_ITERS 32
+template <int LPP>
+__global__ __launch_bounds__(256) void thin_out_conv_kernel(const float *__restrict__ in, const float *__restrict__ wn,
+                                                            const float *__restrict__ bias, float *__restrict__ out,
+                                                            Geom g, Taps taps)
+{
+    extern __shared__ __attribute__((aligned(16))) float wsm[]; // [taps.n][Cin][4]
+    constexpr int PPB = 256 / LPP; // pixels per block pass
+    const int tid = threadIdx.x, j = tid % LPP, pl = tid / LPP;
+    const int wtot = taps.n * g.Cin; // float4 entries; slab order follows the tap LIST (taps.w indexes global slabs)
+    for (int i = tid; i < wtot; i += 256) {
+        const int t = i / g.Cin, k = i - t * g.Cin;
+        *(f32x4 *)&wsm[i * 4] = *(const f32x4 *)(wn + ((long long)taps.w[t] * g.Cin + k) * 4);
+    }
+    __shared__ int tdy[64], tdx[64];
+    if (tid < 64) { tdy[tid] = tid < taps.n ? taps.dy[tid] : 0; tdx[tid] = tid < taps.n ? taps.dx[tid] : 0; }
+    __syncthreads();
+    const int GHW = g.GH * g.GW;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bv = z;
+    if (bias != nullptr) bv = *(const f32x4 *)bias;
+    for (int it = 0; it < THIN_PIX_ITERS; ++it) {
+        const long long m = ((long long)blockIdx.x * THIN_PIX_ITERS + it) * PPB + pl;
+        const bool mok = m < g.Mtot; // uniform across the LPP lanes of a pixel
+        const long long mm = mok ? m : 0;
+        const int n = (int)(mm / GHW);
+        const int r = (int)(mm - (long long)n * GHW);
+        const int gy = r / g.GW, gx = r - gy * g.GW;
+        f32x4 acc = z;
+        const float *img = in + (long long)n * g.Hin * g.Win * g.Cin + 4 * j;
+        for (int t0 = 0; t0 < taps.n; t0 += 4) { // 4 taps per trip: their gathers are issued together
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + u;
+                const int tt = t < taps.n ? t : 0;
+                int iy = gy * g.is + tdy[tt], ix = gx * g.is + tdx[tt];
+                bool ok = mok && t < taps.n;
+                if (g.reflect) {
+                    iy = iy < 0 ? -iy : iy;
+                    iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
+                    ix = ix < 0 ? -ix : ix;
+                    ix = ix >= g.Win ? 2 * (g.Win - 1) - ix : ix;
+                } else {
+                    ok = ok && iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win;
+                }
+                v[u] = z;
+                if (ok) v[u] = *(const f32x4 *)(img + ((long long)iy * g.Win + ix) * g.Cin);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + u < taps.n ? t0 + u : 0; // v[u] is zero for the tail taps
+                const float *wt = &wsm[((long long)t * g.Cin + 4 * j) * 4];
+                acc += v[u][0] * *(const f32x4 *)(wt) + v[u][1] * *(const f32x4 *)(wt + 4) +
+                       v[u][2] * *(const f32x4 *)(wt + 8) + v[u][3] * *(const f32x4 *)(wt + 12);
+            }
+        }
+#pragma unroll
+        for (int sft = LPP / 2; sft >= 1; sft >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += __shfl_xor(acc[k], sft, 64);
+        }
+        if (j == 0 && mok) {
+            acc += bv;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = acg_apply_act(acc[k], g.act);
+            float *o = out + (((long long)n * g.Hout + (gy * g.os + g.oy0)) * g.Wout + (gx * g.os + g.ox0)) * g.Cout;
+            *(f32x4 *)o = acc;
+            for (int c = 4; c < g.Cout; c += 4) *(f32x4 *)(o + c) = z;
+        }
+    }
+}
+
+static int thin_out_launch(const float *in, const float *wn, const float *bias, float *out, const Geom &g, const Taps &t,
+                           hipStream_t st)
+{
+    if (g.Mtot <= 0 || t.n <= 0) return ACG_OK;
+    const int lpp = g.Cin / 4;
+    ACG_REQUIRE(lpp == 4 || lpp == 8 || lpp == 16 || lpp == 32 || lpp == 64, "thin_out_conv: Cin=%d unsupported", g.Cin);
+    const size_t lds = (size_t)t.n * g.Cin * 4 * sizeof(float);
+    ACG_REQUIRE(lds <= 160 * 1024, "thin_out_conv: weights (%zu B) exceed LDS", lds);
+    const int ppb = (256 / lpp) * THIN_PIX_ITERS;
+    dim3 grid(acg_cdiv(g.Mtot, ppb)), block(256);
+#define THIN_LAUNCH(L) hipLaunchKernelGGL((thin_out_conv_kernel<L>), grid, block, lds, st, in, wn, bias, out, g, t)
+    switch (lpp) {
+    case 4: THIN_LAUNCH(4); break;
+    case 8: THIN_LAUNCH(8); break;
+    case 16: THIN_LAUNCH(16); break;
+    case 32: THIN_LAUNCH(32); break;
+    default: THIN_LAUNCH(64); break;
+    }
+#undef THIN_LAUNCH
+    ACG_CHECK_LAUNCH("thin_out_conv_kernel");
+    return ACG_OK;
+}
+
 extern "C" size_t acg_packed_wf_elems(int K, int Ci, int Co) { return (size_t)K * K * (Ci / 8) * acg_ncols_pad(Co) * 8; }
 extern "C" size_t acg_packed_wb_elems(int K, int Ci, int Co) { return (size_t)K * K * (Co / 8) * acg_ncols_pad(Ci) * 8; }
 
@@ -119,17 +246,21 @@ extern "C" int acg_pack_conv_weight(const float *w, int Or, int Ir, int K, int C
                 "acg_pack_conv_weight: bad dims Or=%d Ir=%d K=%d Ci=%d Co=%d", Or, Ir, K, Ci, Co);
     const long long n = (long long)acg_packed_wf_elems(K, Ci, Co) + (long long)acg_packed_wb_elems(K, Ci, Co);
     const int blocks = acg_cdiv(n, 256) > 2048 ? 2048 : acg_cdiv(n, 256);
-    const bool thin_f = thin_ok(Ir, K), thin_b = thin_ok(Or, K);
-    if (thin_f || thin_b) {
-        // thin operands get their own (smaller) layout in the same buffers; the other operand is packed normally
-        if (thin_f && wf)
-            hipLaunchKernelGGL(pack_weight_thin_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, Or, Ir, K * K,
-                               acg_ncols_pad(Co), 0, wf);
-        if (thin_b && wb)
-            hipLaunchKernelGGL(pack_weight_thin_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, Or, Ir, K * K,
-                               acg_ncols_pad(Ci), 1, wb);
-        hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Or, Ir, K, Ci, Co,
-                           acg_ncols_pad(Co), acg_ncols_pad(Ci), thin_f ? (float *)nullptr : wf, thin_b ? (float *)nullptr : wb);
+    const bool thin_i = thin_ok(Ir, K), thin_o = thin_ok(Or, K);
+    if ((thin_i || thin_o) && !(thin_i && thin_o)) {
+        // thin layers: each operand in the layout its kernel wants (all fit in the regular-size buffers)
+        //   Cin <= 4 : wf = thin-K (flattened taps, MFMA fwd)   wb = thin-N (VALU data gradient into the image)
+        //   Cout <= 4: wf = thin-N (VALU forward)               wb = thin-K (MFMA data gradient gathers thin dy)
+        hipStream_t st = (hipStream_t)stream;
+        if (thin_i) {
+            if (wf) hipLaunchKernelGGL(pack_weight_thin_kernel, dim3(64), dim3(256), 0, st, w, Or, Ir, K * K, acg_ncols_pad(Co), 0, wf);
+            if (wb && Co <= 64) hipLaunchKernelGGL(pack_weight_thinN_kernel, dim3(64), dim3(256), 0, st, w, Or, Ir, K * K, Co, 1, wb);
+            else if (wb) hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, st, w, Or, Ir, K, Ci, Co, acg_ncols_pad(Co), acg_ncols_pad(Ci), (float *)nullptr, wb);
+        } else {
+            if (wf && Ci <= 64) hipLaunchKernelGGL(pack_weight_thinN_kernel, dim3(64), dim3(256), 0, st, w, Or, Ir, K * K, Ci, 0, wf);
+            else if (wf) hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, st, w, Or, Ir, K, Ci, Co, acg_ncols_pad(Co), acg_ncols_pad(Ci), wf, (float *)nullptr);
+            if (wb) hipLaunchKernelGGL(pack_weight_thin_kernel, dim3(64), dim3(256), 0, st, w, Or, Ir, K * K, acg_ncols_pad(Ci), 1, wb);
+        }
         ACG_CHECK_LAUNCH("pack_weight_thin_kernel");
         return ACG_OK;
     }
@@ -259,19 +390,29 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ part, int nsplit, 
     const int tap = (int)r;
     float s = 0.f;
     const long long stride = thin ? (long long)CiP * CoP : (long long)KK * CiP * CoP;
-    const float *p = thin ? part + ((long long)(tap * 4 + ci)) * CoP + o : part + ((long long)tap * CiP + ci) * CoP + o;
+    const float *p = thin == 2 ? part + ((long long)(tap * 4 + o)) * CoP + ci   // rows (tap, co), columns ci
+                   : thin == 1 ? part + ((long long)(tap * 4 + ci)) * CoP + o  // rows (tap, ci), columns co
+                               : part + ((long long)tap * CiP + ci) * CoP + o;
     for (int k = 0; k < nsplit; ++k) s += p[k * stride];
     dw[((long long)o * Ir + ci) * KK + tap] = s;
 }
 
-// bias_part[nsplit][Cp] -> db[c] (first Cr channels), fixed order
-__global__ void bias_reduce_kernel(const float *__restrict__ part, int nsplit, int Cp, int Cr, float *__restrict__ db)
+// bias_part[nsplit][Cp] -> db[c] (first Cr channels): 16 channels per block, 16 split-lanes each, fixed-order tree
+__global__ __launch_bounds__(256) void bias_reduce_kernel(const float *__restrict__ part, int nsplit, int Cp, int Cr,
+                                                          float *__restrict__ db)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Cr) return;
+    __shared__ float red[256];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), k0 = threadIdx.x >> 4;
     float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += part[(long long)k * Cp + c];
-    db[c] = s;
+    if (c < Cr)
+        for (int k = k0; k < nsplit; k += 16) s += part[(long long)k * Cp + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st >= 16; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x < 16 && c < Cr) db[c] = red[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -408,7 +549,7 @@ static void fwd_geom(const acg_conv_desc *d, Geom *g, Taps *t, int act)
     g->GH = d->Ho; g->GW = d->Wo; g->os = 1; g->oy0 = 0; g->ox0 = 0; g->is = d->stride;
     g->reflect = d->pad_mode == ACG_PAD_REFLECT; g->act = act; g->ncols_pad = acg_ncols_pad(d->Co);
     g->Mtot = (long long)d->N * d->Ho * d->Wo;
-    g->thin = thin_ok(d->Cir, d->K) ? 1 : 0;
+    g->thin = thin_in(d) ? 1 : 0;
     t->n = 0;
     for (int kh = 0; kh < d->K; ++kh)
         for (int kw = 0; kw < d->K; ++kw) {
@@ -425,7 +566,7 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
     Geom g; Taps t;
     g.Hin = d->Ho; g.Win = d->Wo; g.Cin = d->Co;
     g.Cout = d->Ci; g.reflect = 0; g.act = act; g.ncols_pad = acg_ncols_pad(d->Ci); g.is = 1;
-    g.thin = (d->stride == 1 && thin_ok(d->Cor, d->K)) ? 1 : 0;
+    g.thin = (d->stride == 1 && thin_out(d)) ? 1 : 0;
     const int p = d->pad, K = d->K;
     if (d->stride == 1) {
         const bool refl = d->pad_mode == ACG_PAD_REFLECT && p > 0;
@@ -451,7 +592,7 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
                 t.dy[t.n] = (short)(base - kh); t.dx[t.n] = (short)(base - kw); t.w[t.n] = (short)(kh * K + kw);
                 t.n++;
             }
-        int rc = acg_igemm_launch(src, wb, bias, out, g, t, st);
+        int rc = thin_in_valu_dgrad(d) ? thin_out_launch(src, wb, bias, out, g, t, st) : acg_igemm_launch(src, wb, bias, out, g, t, st);
         if (rc != ACG_OK) return rc;
         if (refl) {
             const long long total = (long long)d->N * d->Hi * d->Wi * (d->Ci / 4);
@@ -462,7 +603,7 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
         }
         return ACG_OK;
     }
-    ACG_REQUIRE(!thin_ok(d->Cor, d->K), "dgrad: stride 2 with <= 4 output channels is not supported by the thin packing");
+    ACG_REQUIRE(!thin_out(d), "dgrad: stride 2 with <= 4 output channels is not supported by the thin packing");
     // stride 2: four sub-pixel phases, each a dense small-tap convolution (no zero insertion)
     ACG_REQUIRE(d->pad_mode == ACG_PAD_ZERO, "dgrad: stride 2 needs zero padding");
     g.Hout = d->Hi; g.Wout = d->Wi; g.os = 2;
@@ -482,7 +623,7 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
                 }
             }
             ACG_REQUIRE(t.n > 0, "dgrad: empty phase (K=%d p=%d)", K, p);
-            int rc = acg_igemm_launch(src, wb, bias, dst, g, t, st);
+            int rc = thin_in_valu_dgrad(d) ? thin_out_launch(src, wb, bias, dst, g, t, st) : acg_igemm_launch(src, wb, bias, dst, g, t, st);
             if (rc != ACG_OK) return rc;
         }
     return ACG_OK;
@@ -506,6 +647,7 @@ extern "C" int acg_conv2d_fwd(const acg_conv_desc *d, const float *x, const floa
     }
     Geom g; Taps t;
     fwd_geom(d, &g, &t, act);
+    if (thin_out_valu_fwd(d)) return thin_out_launch(x, wf, bias, y, g, t, st);
     return acg_igemm_launch(x, wf, bias, y, g, t, st);
 }
 
@@ -532,7 +674,7 @@ extern "C" int acg_conv2d_bwd_data(const acg_conv_desc *d, const float *dy, cons
 }
 
 // split-K plan shared by the workspace query and the launch
-static bool wgrad_thin(const acg_conv_desc *d) { return thin_ok(d->Cir, d->K); }
+static bool wgrad_thin(const acg_conv_desc *d) { return thin_in(d); }
 
 static void wgrad_plan(const acg_conv_desc *d, int Cx, int Cg, long long Mtot, int *CiP, int *CoP, int *nsplit,
                        long long *mps)
@@ -568,7 +710,19 @@ static size_t wgrad_ws_bytes(const acg_conv_desc *d, int Cx, int Cg, long long M
     const int Cmax = d->Ci > d->Co ? d->Ci : d->Co;
     const long long Mbig = (long long)d->N * (d->Hi > d->Ho ? d->Hi : d->Ho) * (d->Wi > d->Wo ? d->Wi : d->Wo);
     const size_t bias_part = (size_t)ns * (CiP > CoP ? CiP : CoP) * sizeof(float);
-    return acg_round_up(part, 256) + acg_round_up(colsum_ws_bytes(Mbig, Cmax) + bias_part, 256);
+    size_t total = acg_round_up(part, 256) + acg_round_up(colsum_ws_bytes(Mbig, Cmax) + bias_part, 256);
+    if (thin_out(d) && d->stride == 1) { // wgrad_thin_out's partial buffer (its own split plan, <= 512 splits)
+        const size_t tneed = (size_t)512 * 32 * ((d->K * d->K + 7) / 8) * ((d->Ci + 31) / 32 * 32) * sizeof(float);
+        const long long Mx = (long long)d->N * d->Hi * d->Wi;
+        long long ns2 = 1536 / ((long long)((d->K * d->K + 7) / 8) * ((d->Ci + 31) / 32)), cap = Mx / 1024;
+        if (ns2 > cap) ns2 = cap;
+        if (ns2 > 512) ns2 = 512;
+        if (ns2 < 1) ns2 = 1;
+        const size_t t2 = (size_t)(ns2 + 1) * 32 * ((d->K * d->K + 7) / 8) * ((d->Ci + 31) / 32 * 32) * sizeof(float);
+        (void)tneed;
+        if (t2 > total) total = t2;
+    }
+    return total;
 }
 
 extern "C" size_t acg_conv2d_bwd_weight_workspace_bytes(const acg_conv_desc *d)
@@ -611,12 +765,52 @@ static int wgrad_common(const acg_conv_desc *d, const float *x_side, const float
     if (rc) return rc;
     if (g.bias_from) {
         const int Cp = bias_from == 1 ? g.CoP : g.CiP, Cr = bias_from == 1 ? Or : Ir;
-        hipLaunchKernelGGL(bias_reduce_kernel, dim3(acg_cdiv(Cr, 64)), dim3(64), 0, st, (const float *)g.bias_part, g.nsplit, Cp,
+        hipLaunchKernelGGL(bias_reduce_kernel, dim3(acg_cdiv(Cr, 16)), dim3(256), 0, st, (const float *)g.bias_part, g.nsplit, Cp,
                            Cr, db);
     }
     const long long total = (long long)t.n * Ir * Or;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(acg_cdiv(total, 256)), dim3(256), 0, st, (const float *)ws, g.nsplit,
                        t.n, g.CiP, g.CoP, Or, Ir, dw, g.thin);
+    ACG_CHECK_LAUNCH("wgrad_reduce_kernel");
+    return ACG_OK;
+}
+
+// Weight gradient of a convolution with <= 4 OUTPUT channels (stride 1): mirror image of the thin-Cin case.
+//   dW[co][ci][kh,kw] = sum_{iy,ix} x[iy,ix][ci] * dy[iy-kh+p, ix-kw+p][co]
+// GEMM rows (gathered, thin) = (tap, co<4) from dy, columns = ci from the plain x rows, K = input pixels.
+static int wgrad_thin_out(const acg_conv_desc *d, const float *x, const float *dy, float *dw, int Or, int Ir, void *ws,
+                          size_t ws_bytes, hipStream_t st)
+{
+    WGeom g; Taps t;
+    const int K = d->K, p = d->pad;
+    t.n = 0;
+    for (int kh = 0; kh < K; ++kh)
+        for (int kw = 0; kw < K; ++kw) { t.dy[t.n] = (short)(p - kh); t.dx[t.n] = (short)(p - kw); t.w[t.n] = (short)(kh * K + kw); t.n++; }
+    g.Hin = d->Ho; g.Win = d->Wo; g.Cin = d->Co;      // gathered side: dy
+    g.Hg = d->Hi; g.Wg = d->Wi; g.Cg = d->Ci;         // plain rows: x
+    g.is = 1; g.reflect = 0; g.thin = 1; g.bias_from = 0; g.bias_part = nullptr;
+    g.Mtot = (long long)d->N * d->Hi * d->Wi;
+    g.CiP = 32 * ((K * K + 7) / 8);
+    g.CoP = (d->Ci + 31) / 32 * 32;
+    const long long base = (long long)(g.CiP / 32) * (g.CoP / 32);
+    long long ns = 1536 / base, cap = g.Mtot / 1024;
+    if (ns > cap) ns = cap;
+    if (ns > 512) ns = 512;
+    if (ns < 1) ns = 1;
+    long long per = (g.Mtot + ns - 1) / ns;
+    per = (per + 255) / 256 * 256;
+    g.nsplit = (int)((g.Mtot + per - 1) / per);
+    g.m_per_split = per;
+    const size_t need = (size_t)g.nsplit * g.CiP * g.CoP * sizeof(float);
+    if (ws == nullptr || ws_bytes < need) {
+        acg_set_error("acg_conv2d_bwd_weight(thin out): workspace %zu < %zu", ws_bytes, need);
+        return ACG_ERR_WORKSPACE;
+    }
+    int rc = acg_wgrad_launch(dy, x, (float *)ws, g, t, st);
+    if (rc) return rc;
+    const long long total = (long long)t.n * Ir * Or;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(acg_cdiv(total, 256)), dim3(256), 0, st, (const float *)ws, g.nsplit, t.n,
+                       g.CiP, g.CoP, Or, Ir, dw, 2);
     ACG_CHECK_LAUNCH("wgrad_reduce_kernel");
     return ACG_OK;
 }
@@ -637,9 +831,11 @@ extern "C" int acg_conv2d_bwd_weight(const acg_conv_desc *d, const float *x, con
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     ACG_REQUIRE(ws != nullptr && ws_bytes >= acg_conv2d_bwd_weight_workspace_bytes(d), "acg_conv2d_bwd_weight: workspace too small");
-    const bool fused = dw != nullptr && db != nullptr && g_acg_conv_impl == ACG_IMPL_MFMA;
+    const bool tout = thin_out(d) && d->stride == 1;
+    const bool fused = dw != nullptr && db != nullptr && g_acg_conv_impl == ACG_IMPL_MFMA && !tout;
     if (dw != nullptr) {
-        rc = wgrad_common(d, x, dy, dw, Or, Ir, ws, ws_bytes, st, 1, fused ? db : nullptr, true);
+        rc = tout ? wgrad_thin_out(d, x, dy, dw, Or, Ir, ws, ws_bytes, st)
+                  : wgrad_common(d, x, dy, dw, Or, Ir, ws, ws_bytes, st, 1, fused ? db : nullptr, true);
         if (rc) return rc;
     }
     if (db != nullptr && !fused) {
