@@ -235,6 +235,25 @@ __global__ __launch_bounds__(256) void norm_bwd_apply(const float *__restrict__ 
     }
 }
 
+// BatchNorm eval mode: statistics come from the running buffers
+__global__ void bn_eval_stats_kernel(const float *__restrict__ rm, const float *__restrict__ rv, int C, int Cp, float eps,
+                                     float *__restrict__ mean, float *__restrict__ rstd)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cp) return;
+    mean[c] = c < C ? rm[c] : 0.f;
+    rstd[c] = rsqrtf((c < C ? rv[c] : 0.f) + eps);
+}
+extern "C" int acg_bn_eval_stats(const float *run_mean, const float *run_var, int C, int Cp, float eps, float *mean,
+                                 float *rstd, void *stream)
+{
+    ACG_REQUIRE(C > 0 && Cp >= C, "acg_bn_eval_stats: bad dims");
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(acg_cdiv(Cp, 256)), dim3(256), 0, (hipStream_t)stream, run_mean, run_var, C,
+                       Cp, eps, mean, rstd);
+    ACG_CHECK_LAUNCH("bn_eval_stats_kernel");
+    return ACG_OK;
+}
+
 static int nchunks_of(size_t P) { return (int)((P + NORM_ROWS - 1) / NORM_ROWS); }
 
 extern "C" size_t acg_norm_workspace_bytes(int G, size_t P, int C)
@@ -312,8 +331,9 @@ extern "C" int acg_norm_bwd(const float *dy, const float *y, const float *x, con
     if (dgamma != nullptr || dbeta != nullptr)
         hipLaunchKernelGGL(norm_bwd_params, dim3(acg_cdiv((long)G * C, 256)), dim3(256), 0, st, (const float *)sums, G, C,
                            gstride, dgamma, dbeta);
-    const float invP = 1.f / (float)P;
-    const float invD = unbiased ? 1.f / (float)(P - 1) : invP;
+    // unbiased == 2: statistics are constants (BatchNorm eval mode) -> dx = gamma * rstd * gy
+    const float invP = unbiased == 2 ? 0.f : 1.f / (float)P;
+    const float invD = unbiased == 2 ? 0.f : (unbiased ? 1.f / (float)(P - 1) : invP);
     hipLaunchKernelGGL(norm_bwd_apply, dim3(ew_blocks((long long)P * (C / 4)), G), dim3(256), 0, st, dy, y, x, mean, rstd,
                        gamma, gstride, (const float *)sums, dx, dres, (long long)P, C, act, invP, invD);
     ACG_CHECK_LAUNCH("norm_bwd");

@@ -88,16 +88,12 @@ class _BatchNormMixin(_Cached):
         C = cpad(self.num_features) if self._pad16 else self.num_features
         return self._cached(lambda: (_padded_vec(self.weight, C), _padded_vec(self.bias, C)))
 
-    def _run_buffers(self, C):
-        # running stats live in the (real-length) torch buffers; the kernel updates padded scratch copies
-        # that are written back, keeping state_dict identical to torch's BatchNorm.
-        return None
-
     def forward_act(self, x, act=ACT_NONE):
-        if not self.training:
-            raise NotImplementedError("BatchNorm eval mode (running statistics) is not on the training hot path")
         C = x.shape[-1]
         g, b = self._gb()
+        if not self.training:  # eval mode: normalise with the running buffers (model.eval(), train.py:258)
+            return ops.NormAct.apply(x, self.weight, self.bias, None, "bn_eval", act, self.eps, g, b,
+                                     self.running_mean.contiguous(), self.running_var.contiguous(), 0.0)
         rm = torch.zeros(C, device=x.device, dtype=torch.float32)
         rv = torch.ones(C, device=x.device, dtype=torch.float32)
         rm[:self.num_features].copy_(self.running_mean)

@@ -325,11 +325,11 @@ class NormAct(torch.autograd.Function):
         C = x.shape[-1]
         N = x.shape[0]
         rows = x.numel() // C
-        if kind == "bn":
+        if kind in ("bn", "bn_eval"):
             G, P = 1, rows
         else:
             G, P = N, rows // N
-        unbiased = 1 if kind == "cin" else 0
+        unbiased = 1 if kind == "cin" else (2 if kind == "bn_eval" else 0)
         if kind == "cin":
             gp, bp, gstride = gamma.contiguous(), beta.contiguous(), C
             if gp.shape != (N, C):
@@ -340,10 +340,13 @@ class NormAct(torch.autograd.Function):
         st = _stream()
         mean = torch.empty(G * C, device=x.device, dtype=torch.float32)
         rstd = torch.empty(G * C, device=x.device, dtype=torch.float32)
-        nb = _lib.query("acg_norm_workspace_bytes", G, P, C)
-        ws = workspace(nb)
-        _lib.call("acg_norm_stats", _ptr(x), G, P, C, eps, unbiased, _ptr(mean), _ptr(rstd), _ptr(run_mean), _ptr(run_var),
-                  momentum, _ptr(ws), nb, st)
+        if kind == "bn_eval":  # running statistics (real length) -> padded mean / rstd
+            _lib.call("acg_bn_eval_stats", _ptr(run_mean), _ptr(run_var), run_mean.numel(), C, eps, _ptr(mean), _ptr(rstd), st)
+        else:
+            nb = _lib.query("acg_norm_workspace_bytes", G, P, C)
+            ws = workspace(nb)
+            _lib.call("acg_norm_stats", _ptr(x), G, P, C, eps, unbiased, _ptr(mean), _ptr(rstd), _ptr(run_mean),
+                      _ptr(run_var), momentum, _ptr(ws), nb, st)
         y = torch.empty_like(x)
         if res is not None:
             res = res.contiguous()

@@ -115,11 +115,15 @@ size_t acg_norm_workspace_bytes(int G, size_t P, int C);
  * (BatchNorm) they are updated with momentum (running_var takes the unbiased variance). */
 int acg_norm_stats(const float *x, int G, size_t P, int C, float eps, int unbiased, float *mean, float *rstd,
                    float *run_mean, float *run_var, float momentum, void *workspace, size_t ws_bytes, void *stream);
+/* BatchNorm eval mode: mean/rstd (length Cp) from the running buffers (length C) */
+int acg_bn_eval_stats(const float *run_mean, const float *run_var, int C, int Cp, float eps, float *mean, float *rstd,
+                      void *stream);
 /* y = act((x-mean)*rstd*gamma + beta [+ res]); gamma/beta indexed [g*gstride + c] (gstride 0 or C) */
 int acg_norm_apply(const float *x, const float *mean, const float *rstd, const float *gamma, const float *beta,
                    int gstride, const float *res, float *y, int G, size_t P, int C, int act, void *stream);
 /* backward: dy (w.r.t. y), y, x -> dx, dres (if has_res; = dy*act'(y)), dgamma/dbeta
- * ([C] summed over groups when gstride==0, else [G*C]). unbiased as in acg_norm_stats. */
+ * ([C] summed over groups when gstride==0, else [G*C]). unbiased as in acg_norm_stats; unbiased == 2 means the
+ * statistics were constants (BatchNorm eval mode): dx = gamma*rstd*dy*act'. */
 int acg_norm_bwd(const float *dy, const float *y, const float *x, const float *mean, const float *rstd,
                  const float *gamma, int gstride, float *dx, float *dres, float *dgamma, float *dbeta, int G,
                  size_t P, int C, int act, int unbiased, void *workspace, size_t ws_bytes, void *stream);

@@ -201,6 +201,47 @@ class AugStep(object):
         return losses, visuals, gnorms
 
 
+def _sup(self, real_A, real_B, prior_z_B, eps=None):
+    """model.py:541-604 supervised_train_instance (paired step, --supervised)."""
+    o = self.opt
+    A = T(np.asarray(real_A, self.dtype)); B = T(np.asarray(real_B, self.dtype)); Z = T(np.asarray(prior_z_B, self.dtype))
+    bs = A.v.shape[0]
+    mu, lv = self.netE_B.forward(ops.cat_channels(A, B) if o.enc_A_B else B)                 # model.py:543-547
+    if o.stoch_enc:
+        post_z = ops.gauss_reparametrize(mu, lv, eps)
+    else:
+        post_z = ops.reshape(mu, (bs, mu.v.shape[1], 1, 1))
+        lv = ops.scale(lv, 0.0)
+    lf, lt, _, _ = discriminate(self.netD_z_B, post_z.detach(), Z)                            # model.py:555-557
+    loss_D_z_B = _half_sum(lf, lt)
+    zero_grad(self.optimizer_D_B.params)
+    backward(loss_D_z_B)
+    gn_D_z = clip_grad_norm(self.netD_z_B.parameters(), o.max_gnorm)
+    self.optimizer_D_B.step()
+    pred_B = self.netG_A_B.forward(A, post_z)
+    pred_A = self.netG_B_A.forward(B)
+    loss_sup_A = ops.l1_loss(pred_A, A); loss_sup_B = ops.l1_loss(pred_B, B)
+    loss_G_z = criterion_gan(self.netD_z_B.forward(post_z), True)
+    kld = ops.mean0(ops.kld_std_gauss(mu, lv))
+    loss_G = ops.add(ops.scale(loss_sup_A, o.lambda_sup_A), ops.scale(loss_sup_B, o.lambda_sup_B))
+    if o.stoch_enc:
+        loss_G = ops.add(loss_G, ops.scale(kld, o.lambda_z_B))
+    if o.z_gan and not o.stoch_enc:
+        loss_G = ops.add(loss_G, loss_G_z)
+    zero_grad(self.optimizer_G_A.params); zero_grad(self.optimizer_G_B.params)
+    backward(loss_G)
+    gn_G_A_B = clip_grad_norm(self.netG_A_B.parameters(), o.max_gnorm)
+    gn_G_B_A = clip_grad_norm(self.netG_B_A.parameters(), o.max_gnorm)
+    gn_E = clip_grad_norm(self.netE_B.parameters(), o.max_gnorm)
+    self.optimizer_G_A.step(); self.optimizer_G_B.step()
+    return OrderedDict([("S_A", _f(loss_sup_A)), ("S_B", _f(loss_sup_B)), ("KLD_z_B", _f(kld)), ("D_z_B", _f(loss_D_z_B)),
+                        ("gnorm_G_A_B", gn_G_A_B), ("gnorm_G_B_A", gn_G_B_A), ("gnorm_E_B", gn_E),
+                        ("gnorm_D_z_B", gn_D_z)])                                              # model.py:596-604
+
+
+AugStep.supervised_train_instance = _sup
+
+
 class StochStep(object):
     """model.py:75-208 StochCycleGAN (no encoder / latent discriminator; works at any S)."""
 

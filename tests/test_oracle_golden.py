@@ -137,3 +137,16 @@ def test_step_matches_reference(name):
                     assert int(b) == int(arr["final/buf/%s/%s" % (n, k)])
                 else:
                     assert rel_err(b, arr["final/buf/%s/%s" % (n, k)]) < 2e-3, (n, k)
+
+
+def test_supervised_step_matches_reference():
+    """oracle AugStep.supervised_train_instance vs the reference's (model.py:541-604)"""
+    arr, meta = load("sup_aug_small_s64")
+    opt = step.Opt(**meta["opt"])
+    m = step.AugStep(opt, dtype=np.float32)
+    m.load({n: recipe.values_for(net.shapes, n, meta["seed"], meta["flavour"]) for n, net in m.nets().items()})
+    vals = m.supervised_train_instance(arr["real_A"], arr["real_B"], arr["prior_z_B"])
+    assert list(vals.keys()) == meta["keys"]
+    assert np.allclose(list(vals.values()), arr["values"], rtol=5e-4, atol=2e-6), dict(zip(meta["keys"], zip(vals.values(), arr["values"])))
+    fb = m.netG_A_B.forward(T(arr["probe_A"]), T(arr["probe_z"])).v
+    assert rel_err(fb, arr["probe_fake_B_after"]) < 5e-3  # weights after the paired step

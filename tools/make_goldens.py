@@ -292,6 +292,43 @@ if __name__ == "__main__":
     make_step_goldens()
 
 
+def sup_case(name, opt_kw, N, S, seed=0, flavour="rich"):
+    """AugmentedCycleGAN.supervised_train_instance (model.py:541-604); it too raises IndexError at its reporting
+    line after all compute, so values come from recorders (call order: criterionGAN D_z fake/true, then G_z;
+    l1 sup_A, sup_B; clips D_z, G_A_B, G_B_A, E)."""
+    opt = ref_opt(**opt_kw)
+    gan, l1s, gns, encs = [], [], [], []
+    orig_l1, orig_clip, orig_crit = rmodel.F.l1_loss, torch.nn.utils.clip_grad_norm, rmodel.criterion_GAN
+    rmodel.F.l1_loss = lambda a, b, *k, **kw: (lambda v: (l1s.append(float(v)), v)[1])(orig_l1(a, b, *k, **kw))
+    rmodel.criterion_GAN = lambda p, r, use_sigmoid=True: (lambda v: (gan.append(float(v)), v)[1])(orig_crit(p, r, use_sigmoid=use_sigmoid))
+    torch.nn.utils.clip_grad_norm = lambda ps, mx, *k, **kw: (lambda v: (gns.append(float(v)), v)[1])(orig_clip(ps, mx, *k, **kw))
+    try:
+        m = rmodel.AugmentedCycleGAN(opt, testing=True)
+        names = ["netG_A_B", "netG_B_A", "netD_A", "netD_B", "netE_B", "netD_z_B"]
+        for n in names:
+            load_recipe(getattr(m, n), n, seed, flavour)
+        f = m.netE_B.forward
+        m.netE_B.forward = lambda *a: (lambda o: (encs.append(o[0].detach().numpy().copy()), o)[1])(f(*a))
+        A, B, z = recipe.inputs(seed + 40, N, opt.input_nc, opt.output_nc, S, opt.nlatent)
+        try:
+            m.supervised_train_instance(torch.from_numpy(A.copy()), torch.from_numpy(B.copy()), torch.from_numpy(z.copy()))
+            raise RuntimeError("reference unexpectedly returned")
+        except IndexError:
+            pass
+        mu = encs[0].astype(np.float64)
+        vals = OrderedDict([("S_A", l1s[0]), ("S_B", l1s[1]), ("KLD_z_B", float((0.5 * (mu ** 2).sum(1)).mean())),
+                            ("D_z_B", 0.5 * (gan[0] + gan[1])), ("gnorm_G_A_B", gns[1]), ("gnorm_G_B_A", gns[2]),
+                            ("gnorm_E_B", gns[3]), ("gnorm_D_z_B", gns[0])])
+        with torch.no_grad():
+            probe = recipe.inputs(seed + 41, 2, opt.input_nc, opt.output_nc, S, opt.nlatent)
+            post = m.netG_A_B.model(torch.from_numpy(probe[0]), torch.from_numpy(probe[2])).numpy().copy()
+        save(name, dict(real_A=A, real_B=B, prior_z_B=z, values=np.array(list(vals.values()), np.float64),
+                        probe_A=probe[0], probe_z=probe[2], probe_fake_B_after=post),
+             kind="sup", seed=seed, flavour=flavour, N=N, S=S, opt=dict(opt_kw), keys=list(vals.keys()))
+    finally:
+        rmodel.F.l1_loss, rmodel.criterion_GAN, torch.nn.utils.clip_grad_norm = orig_l1, orig_crit, orig_clip
+
+
 def make_key_fixture():
     """state_dict keys + shapes of the reference's six networks at default widths."""
     nets = dict(netG_A_B=rnet.define_stochastic_G(16, 3, 3, 32), netG_B_A=rnet.define_G(3, 3, 32),
@@ -303,3 +340,4 @@ def make_key_fixture():
 
 if __name__ == "__main__":
     make_key_fixture()
+    sup_case("sup_aug_small_s64", dict(input_nc=3, output_nc=3, ngf=8, nef=8, ndf=8, nlatent=4), N=4, S=64)
