@@ -5,6 +5,7 @@ Import as `dtgan_amd` (repo-root shim `dtgan_amd.py`; the directory name carries
 (`import model, networks, modules`) so the reference's train.py-style callers drop in.
 """
 from . import _lib, dist, model, modules, networks, ops  # noqa: F401
+from . import dataloader, evaluate, options  # noqa: F401  (driver side; `train` is imported on demand)
 from .model import AugmentedCycleGAN, AugmentedCycleGAN_Model, StochCycleGAN  # noqa: F401
 
 __version__ = "0.1.0"
