@@ -308,6 +308,40 @@ extern "C" int acg_norm_apply(const float *x, const float *mean, const float *rs
     return ACG_OK;
 }
 
+// local reduction only: sums[(g*2+{0,1})*C + c] = sum_p gy, sum_p gy*xhat (what SyncBN all-reduces across ranks)
+extern "C" int acg_norm_bwd_sums(const float *dy, const float *y, const float *x, const float *mean, const float *rstd,
+                                 float *sums, int G, size_t P, int C, int act, void *ws, size_t ws_bytes, void *stream)
+{
+    int rc = check_norm(G, P, C, "acg_norm_bwd_sums");
+    if (rc) return rc;
+    if (ws == nullptr || ws_bytes < acg_norm_workspace_bytes(G, P, C)) {
+        acg_set_error("acg_norm_bwd_sums: workspace too small");
+        return ACG_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = nchunks_of(P);
+    hipLaunchKernelGGL(norm_bwd_partial, dim3(nch, G), dim3(256), 0, st, dy, y, x, mean, rstd, (long long)P, C, nch, act,
+                       (float *)ws);
+    hipLaunchKernelGGL(norm_bwd_final, dim3(acg_cdiv((long)G * C, 256)), dim3(256), 0, st, (const float *)ws, G, C, nch, sums);
+    ACG_CHECK_LAUNCH("norm_bwd_sums");
+    return ACG_OK;
+}
+
+// apply with externally supplied (e.g. all-reduced) sums and the matching total pixel count Ptot
+extern "C" int acg_norm_bwd_apply(const float *dy, const float *y, const float *x, const float *mean, const float *rstd,
+                                  const float *gamma, int gstride, const float *sums, float *dx, float *dres, int G,
+                                  size_t P, size_t Ptot, int C, int act, int unbiased, void *stream)
+{
+    int rc = check_norm(G, P, C, "acg_norm_bwd_apply");
+    if (rc) return rc;
+    const float invP = unbiased == 2 ? 0.f : 1.f / (float)Ptot;
+    const float invD = unbiased == 2 ? 0.f : (unbiased ? 1.f / (float)(Ptot - 1) : invP);
+    hipLaunchKernelGGL(norm_bwd_apply, dim3(ew_blocks((long long)P * (C / 4)), G), dim3(256), 0, (hipStream_t)stream, dy, y, x,
+                       mean, rstd, gamma, gstride, sums, dx, dres, (long long)P, C, act, invP, invD);
+    ACG_CHECK_LAUNCH("norm_bwd_apply");
+    return ACG_OK;
+}
+
 extern "C" int acg_norm_bwd(const float *dy, const float *y, const float *x, const float *mean, const float *rstd,
                             const float *gamma, int gstride, float *dx, float *dres, float *dgamma, float *dbeta,
                             int G, size_t P, int C, int act, int unbiased, void *ws, size_t ws_bytes, void *stream)

@@ -212,6 +212,8 @@ class _Base(object):
 
 
 def _n_blocks(opt):
+    from . import modules
+    modules.SYNC_BN = bool(getattr(opt, 'sync_bn', False))   # extension: BatchNorm statistics over all ranks
     return int(getattr(opt, 'n_blocks', 3))
 
 

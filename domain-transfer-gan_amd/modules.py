@@ -16,6 +16,12 @@ from . import ops
 from .ops import ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, PAD_ZERO, PAD_REFLECT, cpad
 
 USE_PYTORCH_IN = False  # modules.py:9
+SYNC_BN = False         # set by model.py from opt.sync_bn: BatchNorm statistics across all data-parallel ranks
+
+
+def ops_dist_on():
+    import torch.distributed as td
+    return td.is_available() and td.is_initialized() and td.get_world_size() > 1
 
 
 def mark_dirty(net):
@@ -94,6 +100,12 @@ class _BatchNormMixin(_Cached):
         if not self.training:  # eval mode: normalise with the running buffers (model.eval(), train.py:258)
             return ops.NormAct.apply(x, self.weight, self.bias, None, "bn_eval", act, self.eps, g, b,
                                      self.running_mean.contiguous(), self.running_var.contiguous(), 0.0)
+        if SYNC_BN and ops_dist_on():  # statistics over every rank's shard
+            y = ops.SyncBatchNormAct.apply(x, self.weight, self.bias, act, self.eps, g, b, self.running_mean,
+                                           self.running_var, self.momentum)
+            with torch.no_grad():
+                self.num_batches_tracked += 1
+            return y
         rm = torch.zeros(C, device=x.device, dtype=torch.float32)
         rv = torch.ones(C, device=x.device, dtype=torch.float32)
         rm[:self.num_features].copy_(self.running_mean)

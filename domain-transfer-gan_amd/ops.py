@@ -379,6 +379,73 @@ class NormAct(torch.autograd.Function):
         return dx, dg, db, dres, None, None, None, None, None, None, None, None
 
 
+class SyncBatchNormAct(torch.autograd.Function):
+    """BatchNorm (train mode) with statistics over ALL ranks' batches: per-rank (count, mean, M2) from the stats
+    kernel, one all-reduce of [C x 3] floats, Chan-style combination; backward all-reduces the two per-channel sums
+    before the apply pass.  With equal shards this makes N ranks == 1 rank on the concatenated batch."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, act, eps, gamma_p, beta_p, run_mean, run_var, momentum):
+        import torch.distributed as td
+        x = x.contiguous()
+        _check(x, gamma_p, beta_p)
+        C = x.shape[-1]
+        P = x.numel() // C
+        st = _stream()
+        mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(C, device=x.device, dtype=torch.float32)
+        nb = _lib.query("acg_norm_workspace_bytes", 1, P, C)
+        ws = workspace(nb)
+        _lib.call("acg_norm_stats", _ptr(x), 1, P, C, eps, 0, _ptr(mean), _ptr(rstd), None, None, 0.0, _ptr(ws), nb, st)
+        # local biased variance back from rstd, then combine across ranks: E[x], E[x^2] weighted by the pixel counts
+        var = rstd.pow(-2) - eps
+        pack = torch.cat([mean * P, (var + mean * mean) * P, torch.full((1,), float(P), device=x.device)])
+        if td.get_backend() == "gloo" and pack.is_cuda:
+            h = pack.cpu(); td.all_reduce(h); pack = h.to(x.device)
+        else:
+            td.all_reduce(pack)
+        Ptot = float(pack[-1])
+        gmean = pack[:C] / Ptot
+        gvar = (pack[C:2 * C] / Ptot - gmean * gmean).clamp_(min=0.0)
+        grstd = (gvar + eps).rsqrt()
+        if run_mean is not None:
+            nreal = run_mean.numel()
+            with torch.no_grad():
+                run_mean.mul_(1 - momentum).add_(gmean[:nreal], alpha=momentum)
+                run_var.mul_(1 - momentum).add_(gvar[:nreal] * (Ptot / max(Ptot - 1, 1)), alpha=momentum)
+        gmean, grstd = gmean.contiguous(), grstd.contiguous()
+        y = torch.empty_like(x)
+        _lib.call("acg_norm_apply", _ptr(x), _ptr(gmean), _ptr(grstd), _ptr(gamma_p), _ptr(beta_p), 0, None, _ptr(y), 1, P, C,
+                  act, st)
+        ctx.cfg = (act, P, int(Ptot), C, gamma.shape)
+        ctx.save_for_backward(x, y if act != ACT_NONE else None, gmean, grstd, gamma_p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as td
+        x, y, mean, rstd, gp = ctx.saved_tensors
+        act, P, Ptot, C, gshape = ctx.cfg
+        dy = dy.contiguous()
+        st = _stream()
+        sums = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+        nb = _lib.query("acg_norm_workspace_bytes", 1, P, C)
+        ws = workspace(nb)
+        _lib.call("acg_norm_bwd_sums", _ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(sums), 1, P, C, act, _ptr(ws),
+                  nb, st)
+        local = sums.clone()  # parameter gradients stay per-rank (the gradient all-reduce averages them later)
+        if td.get_backend() == "gloo" and sums.is_cuda:
+            h = sums.cpu(); td.all_reduce(h); sums = h.to(x.device)
+        else:
+            td.all_reduce(sums)
+        dx = torch.empty_like(x)
+        _lib.call("acg_norm_bwd_apply", _ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gp), 0, _ptr(sums), _ptr(dx),
+                  None, 1, P, Ptot, C, act, 0, st)
+        # the later gradient all-reduce takes the MEAN over ranks while the single-process gradient is the SUM over all
+        # samples of the global-batch-mean loss; losses here are per-rank means, so local sums are already right.
+        return dx, local[C:][:gshape[0]], local[:C][:gshape[0]], None, None, None, None, None, None, None
+
+
 # ----------------------------------------------------------------------------------------------
 # small dense layers
 # ----------------------------------------------------------------------------------------------

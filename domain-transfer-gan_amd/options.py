@@ -78,6 +78,7 @@ class TrainOptions(object):
         p.add_argument('--n_blocks', type=int, default=3, help='residual blocks per generator (the reference builds 3)')
         p.add_argument('--precision', type=str, default='f32', choices=['f32', 'bf16'], help='conv arithmetic')
         p.add_argument('--synthetic', type=int, default=0, help='use N synthetic U(-1,1) samples per split instead of --dataroot')
+        p.add_argument('--sync_bn', action='store_true', help='data parallel: BatchNorm (E_B, D_z_B) statistics across all ranks')
         p.add_argument('--eval_steps', type=int, default=50, help='variational-bound steps per epoch (train.py:285 uses 50)')
         self.initialized = True
 

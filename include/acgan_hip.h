@@ -128,6 +128,14 @@ int acg_norm_bwd(const float *dy, const float *y, const float *x, const float *m
                  const float *gamma, int gstride, float *dx, float *dres, float *dgamma, float *dbeta, int G,
                  size_t P, int C, int act, int unbiased, void *workspace, size_t ws_bytes, void *stream);
 
+/* the two halves of acg_norm_bwd, for SyncBN: local sums[(g*2+{0,1})*C+c] = (sum gy, sum gy*xhat), then — after the
+ * caller has all-reduced them — the apply pass with the GLOBAL pixel count Ptot. */
+int acg_norm_bwd_sums(const float *dy, const float *y, const float *x, const float *mean, const float *rstd, float *sums,
+                      int G, size_t P, int C, int act, void *workspace, size_t ws_bytes, void *stream);
+int acg_norm_bwd_apply(const float *dy, const float *y, const float *x, const float *mean, const float *rstd,
+                       const float *gamma, int gstride, const float *sums, float *dx, float *dres, int G, size_t P,
+                       size_t Ptot, int C, int act, int unbiased, void *stream);
+
 /* ---- elementwise ---- */
 int acg_act_bwd(const float *dy, const float *y, float *dx, size_t n, int act, void *stream); /* dx = dy*act'(y) */
 int acg_add(const float *a, const float *b, float *out, size_t n, void *stream);

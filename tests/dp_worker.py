@@ -1,5 +1,5 @@
 """Worker for tests/test_hip_dp.py: one data-parallel rank of a StochCycleGAN / AugmentedCycleGAN step.
-usage: dp_worker.py <out.npz> <aug:0|1>   (RANK / WORLD_SIZE / MASTER_* from the environment)"""
+usage: dp_worker.py <out.npz> <aug:0|1|2>   (RANK / WORLD_SIZE / MASTER_* from the environment)"""
 import os
 import sys
 
@@ -20,6 +20,7 @@ out, aug = sys.argv[1], int(sys.argv[2])
 rank, ws = D.init_from_env("gloo") if int(os.environ.get("WORLD_SIZE", "1")) > 1 else (0, 1)
 kw = dict(input_nc=3, output_nc=1, ngf=8, nef=8, ndf=8, nlatent=4, n_blocks=2)
 opt = make_opt(**kw)
+opt.sync_bn = aug == 2   # aug: 0 = StochCycleGAN, 1 = AugmentedCycleGAN (per-rank BatchNorm), 2 = AugmentedCycleGAN + SyncBN
 torch.manual_seed(1 + rank)
 m = (M.AugmentedCycleGAN if aug else M.StochCycleGAN)(opt, testing=True)
 for k, net in m._net_dict().items():

@@ -47,3 +47,15 @@ def test_two_ranks_aug_step0_losses(tmp_path):
     idx = [0, 1, 2, 5, 6, 9, 10, 11, 12]  # Cyc_B (7) runs G_A_B on post_z = mu(E): BatchNorm-dependent too
     assert np.allclose(two["s0/losses"][idx], one["s0/losses"][idx], rtol=2e-4, atol=1e-6)
     assert np.all(np.isfinite(two["s1/losses"]))
+
+
+def test_two_ranks_equal_one_rank_aug_with_syncbn(tmp_path):
+    """SyncBN (opt.sync_bn): BatchNorm statistics of E_B / D_z_B over both ranks' shards -> the FULL Augmented CycleGAN
+    step on 2 ranks equals 1 rank on the concatenated batch, all 13 losses and all 6 gradient norms."""
+    one = _run(tmp_path, 1, 2, 29545)
+    two = _run(tmp_path, 2, 2, 29546)
+    assert np.allclose(two["s0/losses"], one["s0/losses"], rtol=2e-4, atol=1e-6), (two["s0/losses"], one["s0/losses"])
+    assert np.allclose(two["s0/gnorms"][:6], one["s0/gnorms"][:6], rtol=2e-3, atol=1e-6), (two["s0/gnorms"], one["s0/gnorms"])
+    assert np.allclose(two["s1/losses"], one["s1/losses"], rtol=1e-2, atol=1e-5)
+    for k in ("probe_fake_B", "probe_fake_A"):
+        assert np.max(np.abs(two[k] - one[k])) < 1e-2 * np.max(np.abs(one[k])), k
