@@ -91,7 +91,7 @@ def main():
 
     def barrier():
         if ws > 1:
-            torch.distributed.barrier()
+            torch.distributed.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):

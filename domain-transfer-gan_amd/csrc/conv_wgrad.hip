@@ -55,6 +55,20 @@ __global__ __launch_bounds__(256) void wgrad_f32(const float *__restrict__ x, co
     f32x4 rx[XL], rd[DL];
     const bool do_bias = g.bias_from != 0 && tap == 0 && (g.bias_from == 1 ? tci == 0 : tco == 0);
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+    // pixel coordinates of this thread's XL gathered rows: decoded ONCE (two integer divisions), then advanced by KP
+    // pixels per stage with carries — the K dimension is pixels, so a per-stage re-decode would cost ~1.3k VALU
+    // cycles per wave and stage in the same in-order stream that has to issue the MFMAs.
+    int xn[XL], xy[XL], xx[XL];
+#pragma unroll
+    for (int j = 0; j < XL; ++j) {
+        const long long m = mbeg + (tid + 256 * j) / (BCI / 4);
+        const long long mm = m < g.Mtot ? m : 0;
+        xn[j] = (int)(mm / GHW);
+        const int rr = (int)(mm - (long long)xn[j] * GHW);
+        xy[j] = rr / g.Wg;
+        xx[j] = rr - xy[j] * g.Wg;
+    }
     auto load_stage = [&](long long k0) {
 #pragma unroll
         for (int j = 0; j < XL; ++j) {
@@ -72,10 +86,7 @@ __global__ __launch_bounds__(256) void wgrad_f32(const float *__restrict__ x, co
                 ci = 0;
             }
             if (m < mend && cok) {
-                const int n = (int)(m / GHW);
-                const int rr = (int)(m - (long long)n * GHW);
-                const int gy = rr / g.Wg, gx = rr - gy * g.Wg;
-                int iy = gy * g.is + ty, ix = gx * g.is + tx;
+                int iy = xy[j] * g.is + ty, ix = xx[j] * g.is + tx;
                 bool ok = true;
                 if (g.reflect) {
                     iy = iy < 0 ? -iy : iy;
@@ -85,9 +96,12 @@ __global__ __launch_bounds__(256) void wgrad_f32(const float *__restrict__ x, co
                 } else {
                     ok = iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win;
                 }
-                if (ok) v = *(const f32x4 *)(x + (((long long)n * g.Hin + iy) * g.Win + ix) * g.Cin + ci);
+                if (ok) v = *(const f32x4 *)(x + (((long long)xn[j] * g.Hin + iy) * g.Win + ix) * g.Cin + ci);
             }
             rx[j] = v;
+            // advance this row by KP pixels for the next stage
+            xx[j] += KP;
+            while (xx[j] >= g.Wg) { xx[j] -= g.Wg; if (++xy[j] == g.Hg) { xy[j] = 0; ++xn[j]; } }
         }
 #pragma unroll
         for (int j = 0; j < DL; ++j) {
