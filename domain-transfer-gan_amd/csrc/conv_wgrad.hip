@@ -10,9 +10,12 @@
 // results are bitwise reproducible run to run.
 #include "conv_internal.h"
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 template <int BCI, int BCO, int WI, int WJ, int WK, int KP>
 __global__ __launch_bounds__(256) void wgrad_f32(const float *__restrict__ x, const float *__restrict__ dy,
-                                                 float *__restrict__ part, WGeom g, Taps taps)
+                                                 float *__restrict__ part, WGeom g, Taps taps, unsigned x_bytes,
+                                                 unsigned d_bytes)
 {
     constexpr int TI = BCI / WI, TJ = BCO / WJ, MI = TI / 32, MJ = TJ / 32;
     constexpr int XCH = KP * BCI / 4, DCH = KP * BCO / 4;
@@ -43,6 +46,9 @@ __global__ __launch_bounds__(256) void wgrad_f32(const float *__restrict__ x, co
     long long mend = mbeg + g.m_per_split;
     if (mend > g.Mtot) mend = g.Mtot;
     const int GHW = g.Hg * g.Wg;
+    // branch-free gathers: 32-bit offsets into buffer resources; masked lanes use offset 0xFFFFFFFF (-> zeros)
+    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd_ = __builtin_amdgcn_make_buffer_rsrc((void *)dy, 0, d_bytes, 0x00020000);
 
     f32x16 acc[MI][MJ];
 #pragma unroll
@@ -85,18 +91,19 @@ __global__ __launch_bounds__(256) void wgrad_f32(const float *__restrict__ x, co
                 tx = taps.dx[cok ? t : 0];
                 ci = 0;
             }
-            if (m < mend && cok) {
+            {
                 int iy = xy[j] * g.is + ty, ix = xx[j] * g.is + tx;
-                bool ok = true;
+                bool ok = m < mend && cok;
                 if (g.reflect) {
                     iy = iy < 0 ? -iy : iy;
                     iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
                     ix = ix < 0 ? -ix : ix;
                     ix = ix >= g.Win ? 2 * (g.Win - 1) - ix : ix;
                 } else {
-                    ok = iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win;
+                    ok = ok && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
                 }
-                if (ok) v = *(const f32x4 *)(x + (((long long)xn[j] * g.Hin + iy) * g.Win + ix) * g.Cin + ci);
+                const unsigned off = ok ? (unsigned)(((xn[j] * g.Hin + iy) * g.Win + ix) * g.Cin + ci) * 4u : 0xFFFFFFFFu;
+                v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx_, off, 0, 0));
             }
             rx[j] = v;
             // advance this row by KP pixels for the next stage
@@ -108,10 +115,9 @@ __global__ __launch_bounds__(256) void wgrad_f32(const float *__restrict__ x, co
             const int idx = tid + 256 * j;
             const int r = idx / (BCO / 4), c4 = idx - r * (BCO / 4);
             const long long m = k0 + r;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             const int co = co0 + c4 * 4;
-            if (m < mend && co < g.Cg) v = *(const f32x4 *)(dy + m * g.Cg + co);
-            rd[j] = v;
+            const unsigned off = (m < mend && co < g.Cg) ? (unsigned)((int)m * g.Cg + co) * 4u : 0xFFFFFFFFu;
+            rd[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd_, off, 0, 0));
         }
     };
 
@@ -213,12 +219,16 @@ int acg_wgrad_launch(const float *x, const float *dy, float *part, const WGeom &
     if (g_acg_precision == ACG_PREC_BF16) return acg_wgrad_bf16_launch(x, dy, part, g, t, bci, st);
     const int blocks = g.nsplit * (g.thin ? 1 : t.n) * (g.CiP / bci) * (g.CoP / bco);
     dim3 grid(blocks), block(256);
+    const long long nimg = g.Mtot / ((long long)g.Hg * g.Wg);
+    const long long xbytes = nimg * g.Hin * g.Win * g.Cin * 4, dbytes = g.Mtot * g.Cg * 4;
+    ACG_REQUIRE(xbytes < (1LL << 32) && dbytes < (1LL << 32), "wgrad: operand exceeds the 4 GiB buffer-addressing limit");
+    const unsigned xb = (unsigned)xbytes, db = (unsigned)dbytes;
     if (bci == 128)
-        hipLaunchKernelGGL((wgrad_f32<128, 128, 2, 2, 1, 32>), grid, block, 0, st, x, dy, part, g, t);
+        hipLaunchKernelGGL((wgrad_f32<128, 128, 2, 2, 1, 32>), grid, block, 0, st, x, dy, part, g, t, xb, db);
     else if (bci == 64)
-        hipLaunchKernelGGL((wgrad_f32<64, 64, 2, 2, 1, 32>), grid, block, 0, st, x, dy, part, g, t);
+        hipLaunchKernelGGL((wgrad_f32<64, 64, 2, 2, 1, 32>), grid, block, 0, st, x, dy, part, g, t, xb, db);
     else
-        hipLaunchKernelGGL((wgrad_f32<32, 32, 1, 1, 4, 128>), grid, block, 0, st, x, dy, part, g, t);
+        hipLaunchKernelGGL((wgrad_f32<32, 32, 1, 1, 4, 128>), grid, block, 0, st, x, dy, part, g, t, xb, db);
     ACG_CHECK_LAUNCH("wgrad_f32");
     return ACG_OK;
 }
