@@ -12,8 +12,9 @@ extern "C" int acg_set_conv_precision(int prec)
     return ACG_OK;
 }
 static bool use_bf16() { return g_acg_precision == ACG_PREC_BF16 && g_acg_conv_impl == ACG_IMPL_MFMA; }
-// thin-channel K-flattening (fp32 MFMA kernels only): the gathered tensor has <= 4 real channels and K > 1
-static bool thin_ok(int creal, int K) { return creal >= 1 && creal <= 4 && K > 1 && g_acg_conv_impl == ACG_IMPL_MFMA && !use_bf16(); }
+// thin-channel K-flattening (fp32 MFMA kernels): the gathered tensor has <= 4 real channels and K > 1
+// (thin layers use the fp32 thin kernels in BOTH precision modes: they beat the padded bf16 path)
+static bool thin_ok(int creal, int K) { return creal >= 1 && creal <= 4 && K > 1 && g_acg_conv_impl == ACG_IMPL_MFMA; }
 // a layer is treated as thin on exactly one side (3->3 convolutions do not occur on this path and stay regular)
 static bool thin_in(const acg_conv_desc *d) { return thin_ok(d->Cir, d->K) && !thin_ok(d->Cor, d->K); }
 static bool thin_out(const acg_conv_desc *d) { return thin_ok(d->Cor, d->K) && !thin_ok(d->Cir, d->K); }
@@ -252,13 +253,22 @@ extern "C" int acg_pack_conv_weight(const float *w, int Or, int Ir, int K, int C
         //   Cin <= 4 : wf = thin-K (flattened taps, MFMA fwd)   wb = thin-N (VALU data gradient into the image)
         //   Cout <= 4: wf = thin-N (VALU forward)               wb = thin-K (MFMA data gradient gathers thin dy)
         hipStream_t st = (hipStream_t)stream;
+        // the NON-thin operand of a thin layer (only when its kernel is the regular MFMA one) follows the precision mode
+        auto regular = [&](float *of, float *ob) {
+            if (use_bf16())
+                hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(blocks), dim3(256), 0, st, w, Or, Ir, K, Ci, Co, acg_ncols_pad(Co),
+                                   acg_ncols_pad(Ci), (__bf16 *)of, (__bf16 *)ob);
+            else
+                hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, st, w, Or, Ir, K, Ci, Co, acg_ncols_pad(Co),
+                                   acg_ncols_pad(Ci), of, ob);
+        };
         if (thin_i) {
             if (wf) hipLaunchKernelGGL(pack_weight_thin_kernel, dim3(64), dim3(256), 0, st, w, Or, Ir, K * K, acg_ncols_pad(Co), 0, wf);
             if (wb && Co <= 64) hipLaunchKernelGGL(pack_weight_thinN_kernel, dim3(64), dim3(256), 0, st, w, Or, Ir, K * K, Co, 1, wb);
-            else if (wb) hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, st, w, Or, Ir, K, Ci, Co, acg_ncols_pad(Co), acg_ncols_pad(Ci), (float *)nullptr, wb);
+            else if (wb) regular(nullptr, wb);
         } else {
             if (wf && Ci <= 64) hipLaunchKernelGGL(pack_weight_thinN_kernel, dim3(64), dim3(256), 0, st, w, Or, Ir, K * K, Ci, 0, wf);
-            else if (wf) hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, st, w, Or, Ir, K, Ci, Co, acg_ncols_pad(Co), acg_ncols_pad(Ci), wf, (float *)nullptr);
+            else if (wf) regular(wf, nullptr);
             if (wb) hipLaunchKernelGGL(pack_weight_thin_kernel, dim3(64), dim3(256), 0, st, w, Or, Ir, K * K, acg_ncols_pad(Ci), 1, wb);
         }
         ACG_CHECK_LAUNCH("pack_weight_thin_kernel");

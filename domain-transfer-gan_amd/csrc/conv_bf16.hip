@@ -14,10 +14,12 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
-template <int BM, int BN, int WM, int WN, int KC>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int BM, int BN, int WM, int WN, int KC, bool REFLECT>
 __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__ in, const __bf16 *__restrict__ wp,
                                                        const float *__restrict__ bias, float *__restrict__ out,
-                                                       Geom g, Taps taps)
+                                                       Geom g, Taps taps, unsigned in_bytes, unsigned w_bytes)
 {
     constexpr int TM = BM / WM, TN = BN / WN, MB = TM / 32, NB = TN / 32;
     constexpr int NKC = KC / 16;             // 16-wide k-chunks per stage
@@ -44,8 +46,10 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
     const long long m0 = (long long)tile_m * BM;
     const int GHW = g.GH * g.GW;
 
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, w_bytes, 0x00020000);
     const int u = tid % UPR, rrow = tid / UPR;
-    int a_img[AL], a_by[AL], a_bx[AL];
+    int a_row[AL], a_by[AL], a_bx[AL]; // a_row: pixel index of (n, by, bx) [zero pad] or n*Hin [reflect]
     bool a_ok[AL];
 #pragma unroll
     for (int j = 0; j < AL; ++j) {
@@ -55,9 +59,19 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
         const int n = (int)(mm / GHW);
         const int r = (int)(mm - (long long)n * GHW);
         const int gy = r / g.GW, gx = r - gy * g.GW;
-        a_img[j] = n;
         a_by[j] = gy * g.is;
         a_bx[j] = gx * g.is;
+        a_row[j] = REFLECT ? n * g.Hin : (n * g.Hin + a_by[j]) * g.Win + a_bx[j];
+    }
+    unsigned b_voff[BL];
+    int b_lds[BL];
+#pragma unroll
+    for (int i = 0; i < BL; ++i) {
+        const int idx = tid + 256 * i;
+        const int kc = idx / (BN * 2);
+        const int rem = idx - kc * BN * 2;
+        b_voff[i] = (unsigned)(((kc * g.ncols_pad + n0) * 16 + rem * 8) * 2);
+        b_lds[i] = kc * BKS + rem * 8;
     }
     if (tid < BM) {
         const long long m = m0 + tid;
@@ -81,7 +95,7 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
 
     const int S = taps.n * (g.Cin / KC);
     f32x8 ra[AL];
-    f32x4 rb[BL]; // 8 bf16 each
+    u32x4 rb[BL]; // 8 bf16 each
 
     auto load_stage = [&](int s) {
         const int cc = s / taps.n;
@@ -90,30 +104,30 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
         const int ty = taps.dy[t], tx = taps.dx[t], tw = taps.w[t];
 #pragma unroll
         for (int j = 0; j < AL; ++j) {
-            int iy = a_by[j] + ty, ix = a_bx[j] + tx;
+            int pix;
             bool ok = a_ok[j];
-            if (g.reflect) {
+            if (REFLECT) {
+                int iy = a_by[j] + ty, ix = a_bx[j] + tx;
                 iy = iy < 0 ? -iy : iy;
                 iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
                 ix = ix < 0 ? -ix : ix;
                 ix = ix >= g.Win ? 2 * (g.Win - 1) - ix : ix;
+                pix = (a_row[j] + iy) * g.Win + ix;
             } else {
-                ok = ok && iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win;
+                const int iy = a_by[j] + ty, ix = a_bx[j] + tx;
+                ok = ok && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+                pix = a_row[j] + ty * g.Win + tx;
             }
-            f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *(const f32x8 *)(in + (((long long)a_img[j] * g.Hin + iy) * g.Win + ix) * g.Cin + c0 + 8 * u);
-            ra[j] = v;
+            const unsigned off = ok ? (unsigned)(pix * g.Cin + c0 + 8 * u) * 4u : 0xFFFFFFFFu;
+            const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);
+            const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? off + 16u : 0xFFFFFFFFu, 0, 0);
+            const f32x4 flo = __builtin_bit_cast(f32x4, lo), fhi = __builtin_bit_cast(f32x4, hi);
+            ra[j] = (f32x8){flo[0], flo[1], flo[2], flo[3], fhi[0], fhi[1], fhi[2], fhi[3]};
         }
+        const unsigned soff = (unsigned)(((tw * (g.Cin >> 4) + (c0 >> 4)) * g.ncols_pad) * 16) * 2u;
 #pragma unroll
-        for (int i = 0; i < BL; ++i) {
-            const int idx = tid + 256 * i;
-            if (idx < BCH) {
-                const int kc = idx / (BN * 2);
-                const int rem = idx - kc * BN * 2;
-                rb[i] = *(const f32x4 *)(wp + (((long long)tw * (g.Cin >> 4) + (c0 >> 4) + kc) * g.ncols_pad + n0) * 16 +
-                                         rem * 8);
-            }
-        }
+        for (int i = 0; i < BL; ++i)
+            if (tid + 256 * i < BCH) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[i], soff, 0);
     };
 
     load_stage(0);
@@ -123,13 +137,8 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
         for (int j = 0; j < AL; ++j)
             *(bf16x8 *)&As[(u >> 1) * AKS + (rrow + RPP * j) * 16 + (u & 1) * 8] = __builtin_convertvector(ra[j], bf16x8);
 #pragma unroll
-        for (int i = 0; i < BL; ++i) {
-            const int idx = tid + 256 * i;
-            if (idx < BCH) {
-                const int kc = idx / (BN * 2);
-                *(f32x4 *)&Bs[kc * BKS + (idx - kc * BN * 2) * 8] = rb[i];
-            }
-        }
+        for (int i = 0; i < BL; ++i)
+            if (tid + 256 * i < BCH) *(u32x4 *)&Bs[b_lds[i]] = rb[i];
         __syncthreads();
         if (s + 1 < S) load_stage(s + 1);
 #pragma unroll
@@ -166,17 +175,17 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
     }
 }
 
-template <int KC>
+template <int KC, bool REFLECT>
 static void launch_bf16_kc(int bn, dim3 grid, hipStream_t st, const float *in, const __bf16 *wp, const float *bias,
-                           float *out, const Geom &g, const Taps &t)
+                           float *out, const Geom &g, const Taps &t, unsigned inb, unsigned wb)
 {
     dim3 block(256);
     if (bn == 128)
-        hipLaunchKernelGGL((igemm_conv_bf16<128, 128, 2, 2, KC>), grid, block, 0, st, in, wp, bias, out, g, t);
+        hipLaunchKernelGGL((igemm_conv_bf16<128, 128, 2, 2, KC, REFLECT>), grid, block, 0, st, in, wp, bias, out, g, t, inb, wb);
     else if (bn == 64)
-        hipLaunchKernelGGL((igemm_conv_bf16<128, 64, 2, 2, KC>), grid, block, 0, st, in, wp, bias, out, g, t);
+        hipLaunchKernelGGL((igemm_conv_bf16<128, 64, 2, 2, KC, REFLECT>), grid, block, 0, st, in, wp, bias, out, g, t, inb, wb);
     else
-        hipLaunchKernelGGL((igemm_conv_bf16<128, 32, 4, 1, KC>), grid, block, 0, st, in, wp, bias, out, g, t);
+        hipLaunchKernelGGL((igemm_conv_bf16<128, 32, 4, 1, KC, REFLECT>), grid, block, 0, st, in, wp, bias, out, g, t, inb, wb);
 }
 
 int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g0, const Taps &t,
@@ -187,9 +196,22 @@ int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, fl
     g.thin = 0;
     dim3 grid(acg_cdiv(g.Mtot, 128) * (g.ncols_pad / bn));
     const __bf16 *w = (const __bf16 *)wp;
-    if (g.Cin % 64 == 0) launch_bf16_kc<64>(bn, grid, st, in, w, bias, out, g, t);
-    else if (g.Cin % 32 == 0) launch_bf16_kc<32>(bn, grid, st, in, w, bias, out, g, t);
-    else launch_bf16_kc<16>(bn, grid, st, in, w, bias, out, g, t);
+    const long long nimg = g.Mtot / ((long long)g.GH * g.GW);
+    const long long in_bytes = nimg * g.Hin * g.Win * g.Cin * 4;
+    long long nslab = 1;
+    for (int i = 0; i < t.n; ++i) nslab = t.w[i] + 1 > nslab ? t.w[i] + 1 : nslab;
+    const long long w_bytes = nslab * (g.Cin / 16) * g.ncols_pad * 16 * 2;
+    ACG_REQUIRE(in_bytes < (1LL << 32) && w_bytes < (1LL << 32), "igemm_conv_bf16: operand exceeds the 4 GiB buffer-addressing limit");
+    const unsigned inb = (unsigned)in_bytes, wb = (unsigned)w_bytes;
+#define BF16_DISPATCH(KCV)                                                                         \
+    do {                                                                                           \
+        if (g.reflect) launch_bf16_kc<KCV, true>(bn, grid, st, in, w, bias, out, g, t, inb, wb);   \
+        else launch_bf16_kc<KCV, false>(bn, grid, st, in, w, bias, out, g, t, inb, wb);            \
+    } while (0)
+    if (g.Cin % 64 == 0) BF16_DISPATCH(64);
+    else if (g.Cin % 32 == 0) BF16_DISPATCH(32);
+    else BF16_DISPATCH(16);
+#undef BF16_DISPATCH
     ACG_CHECK_LAUNCH("igemm_conv_bf16");
     return ACG_OK;
 }
@@ -203,7 +225,8 @@ int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, fl
 // ------------------------------------------------------------------------------------------------
 template <int BCI, int BCO, int WI, int WJ, int WK, int KP>
 __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, const float *__restrict__ dy,
-                                                  float *__restrict__ part, WGeom g, Taps taps)
+                                                  float *__restrict__ part, WGeom g, Taps taps, unsigned x_bytes,
+                                                  unsigned d_bytes)
 {
     constexpr int TI = BCI / WI, TJ = BCO / WJ, MI = TI / 32, MJ = TJ / 32;
     constexpr int RS = KP + 8;                          // LDS row stride (elements)
@@ -246,6 +269,21 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
     f32x4 rx[XL][8], rd[DL][8];
     const bool do_bias = g.bias_from != 0 && tap == 0 && (g.bias_from == 1 ? tci == 0 : tco == 0);
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd_ = __builtin_amdgcn_make_buffer_rsrc((void *)dy, 0, d_bytes, 0x00020000);
+
+    // first pixel of each of this thread's 8-pixel units, decoded ONCE and advanced by KP per stage with carries
+    int un[XL], uy[XL], ux[XL];
+#pragma unroll
+    for (int l = 0; l < XL; ++l) {
+        const int unit = tid + 256 * l;
+        const long long m = mbeg + (unit / (BCI / 4)) * 8;
+        const long long mm = m < g.Mtot ? m : 0;
+        un[l] = (int)(mm / GHW);
+        const int rr = (int)(mm - (long long)un[l] * GHW);
+        uy[l] = rr / g.Wg;
+        ux[l] = rr - uy[l] * g.Wg;
+    }
 
     auto load_stage = [&](long long k0) {
 #pragma unroll
@@ -253,31 +291,27 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
             const int unit = tid + 256 * l;
             const int c4 = unit % (BCI / 4), pg = unit / (BCI / 4);
             const int ci = ci0 + c4 * 4;
-            long long m = k0 + pg * 8;
-            // decode the first pixel, then walk (gx, gy, n) incrementally
-            const long long mm = m < g.Mtot ? m : 0;
-            int n = (int)(mm / GHW);
-            int rr = (int)(mm - (long long)n * GHW);
-            int gy = rr / g.Wg, gx = rr - gy * g.Wg;
+            const long long m = k0 + pg * 8;
+            int n = un[l], gy = uy[l], gx = ux[l];
+            const bool uok = unit < XU && ci < g.Cin;
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (unit < XU && m + p < mend && ci < g.Cin) {
-                    int iy = gy * g.is + ty, ix = gx * g.is + tx;
-                    bool ok = true;
-                    if (g.reflect) {
-                        iy = iy < 0 ? -iy : iy;
-                        iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
-                        ix = ix < 0 ? -ix : ix;
-                        ix = ix >= g.Win ? 2 * (g.Win - 1) - ix : ix;
-                    } else {
-                        ok = iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win;
-                    }
-                    if (ok) v = *(const f32x4 *)(x + (((long long)n * g.Hin + iy) * g.Win + ix) * g.Cin + ci);
+                int iy = gy * g.is + ty, ix = gx * g.is + tx;
+                bool ok = uok && m + p < mend;
+                if (g.reflect) {
+                    iy = iy < 0 ? -iy : iy;
+                    iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
+                    ix = ix < 0 ? -ix : ix;
+                    ix = ix >= g.Win ? 2 * (g.Win - 1) - ix : ix;
+                } else {
+                    ok = ok && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
                 }
-                rx[l][p] = v;
+                const unsigned off = ok ? (unsigned)(((n * g.Hin + iy) * g.Win + ix) * g.Cin + ci) * 4u : 0xFFFFFFFFu;
+                rx[l][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx_, off, 0, 0));
                 if (++gx == g.Wg) { gx = 0; if (++gy == g.Hg) { gy = 0; ++n; } }
             }
+            ux[l] += KP;
+            while (ux[l] >= g.Wg) { ux[l] -= g.Wg; if (++uy[l] == g.Hg) { uy[l] = 0; ++un[l]; } }
         }
 #pragma unroll
         for (int l = 0; l < DL; ++l) {
@@ -285,11 +319,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
             const int c4 = unit % (BCO / 4), pg = unit / (BCO / 4);
             const int co = co0 + c4 * 4;
             const long long m = k0 + pg * 8;
+            const bool uok = unit < DU && co < g.Cg;
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (unit < DU && m + p < mend && co < g.Cg) v = *(const f32x4 *)(dy + (m + p) * g.Cg + co);
-                rd[l][p] = v;
+                const unsigned off = (uok && m + p < mend) ? (unsigned)((int)(m + p) * g.Cg + co) * 4u : 0xFFFFFFFFu;
+                rd[l][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd_, off, 0, 0));
             }
         }
     };
@@ -416,12 +450,16 @@ int acg_wgrad_bf16_launch(const float *x, const float *dy, float *part, const WG
 {
     const int blocks = g.nsplit * t.n * (g.CiP / bci) * (g.CoP / bci);
     dim3 grid(blocks), block(256);
+    const long long nimg = g.Mtot / ((long long)g.Hg * g.Wg);
+    const long long xbytes = nimg * g.Hin * g.Win * g.Cin * 4, dbytes = g.Mtot * g.Cg * 4;
+    ACG_REQUIRE(xbytes < (1LL << 32) && dbytes < (1LL << 32), "wgrad_bf16: operand exceeds the 4 GiB buffer-addressing limit");
+    const unsigned xb = (unsigned)xbytes, db = (unsigned)dbytes;
     if (bci == 128)
-        hipLaunchKernelGGL((wgrad_bf16<128, 128, 2, 2, 1, 64>), grid, block, 0, st, x, dy, part, g, t);
+        hipLaunchKernelGGL((wgrad_bf16<128, 128, 2, 2, 1, 64>), grid, block, 0, st, x, dy, part, g, t, xb, db);
     else if (bci == 64)
-        hipLaunchKernelGGL((wgrad_bf16<64, 64, 2, 2, 1, 64>), grid, block, 0, st, x, dy, part, g, t);
+        hipLaunchKernelGGL((wgrad_bf16<64, 64, 2, 2, 1, 64>), grid, block, 0, st, x, dy, part, g, t, xb, db);
     else
-        hipLaunchKernelGGL((wgrad_bf16<32, 32, 1, 1, 4, 256>), grid, block, 0, st, x, dy, part, g, t);
+        hipLaunchKernelGGL((wgrad_bf16<32, 32, 1, 1, 4, 256>), grid, block, 0, st, x, dy, part, g, t, xb, db);
     ACG_CHECK_LAUNCH("wgrad_bf16");
     return ACG_OK;
 }
