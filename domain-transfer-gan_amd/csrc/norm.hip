@@ -120,9 +120,12 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float *__restrict
 
 // backward pass 1: per (group, chunk) partial sums of gy and gy*xhat, gy = dy*act'(y)
 // part[((g*nchunks + chunk)*2 + {0:S1,1:S2})*C + c]
+// y == nullptr: the activation mask is recomputed from x (pre = xhat*gamma + beta) instead of read — valid when no
+// residual was added before the activation; saves one tensor stream per pass.
 __global__ __launch_bounds__(256) void norm_bwd_partial(const float *__restrict__ dy, const float *__restrict__ y,
                                                         const float *__restrict__ x, const float *__restrict__ mean,
-                                                        const float *__restrict__ rstd, long long P, int C,
+                                                        const float *__restrict__ rstd, const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta, int gstride, long long P, int C,
                                                         int nchunks, int act, float *__restrict__ part)
 {
     __shared__ float sa[256 * 4], sb[256 * 4];
@@ -138,15 +141,24 @@ __global__ __launch_bounds__(256) void norm_bwd_partial(const float *__restrict_
     if (rl < rows_par) {
         const f32x4 mu = *(const f32x4 *)(mean + g * C + c4 * 4);
         const f32x4 rs = *(const f32x4 *)(rstd + g * C + c4 * 4);
+        f32x4 ga = {0.f, 0.f, 0.f, 0.f}, be = ga;
+        const bool recompute = act != ACG_ACT_NONE && y == nullptr;
+        if (recompute) {
+            ga = *(const f32x4 *)(gamma + g * gstride + c4 * 4);
+            be = *(const f32x4 *)(beta + g * gstride + c4 * 4);
+        }
         for (long long r = r0 + rl; r < r1; r += rows_par) {
             const long long o = base + r * C + c4 * 4;
             f32x4 gy = *(const f32x4 *)(dy + o);
+            const f32x4 xv = *(const f32x4 *)(x + o);
             if (act != ACG_ACT_NONE) {
-                const f32x4 yy = *(const f32x4 *)(y + o);
+                f32x4 yy;
+                if (recompute) yy = (xv - mu) * rs * ga + be;   // same expression as norm_apply_kernel (sign is all we need)
+                else yy = *(const f32x4 *)(y + o);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) gy[k] *= acg_act_grad_from_y(yy[k], act);
             }
-            const f32x4 xh = (*(const f32x4 *)(x + o) - mu) * rs;
+            const f32x4 xh = (xv - mu) * rs;
             s1 += gy;
             s2 += gy * xh;
         }
@@ -205,7 +217,8 @@ __global__ void norm_bwd_params(const float *__restrict__ sums, int G, int C, in
 __global__ __launch_bounds__(256) void norm_bwd_apply(const float *__restrict__ dy, const float *__restrict__ y,
                                                       const float *__restrict__ x, const float *__restrict__ mean,
                                                       const float *__restrict__ rstd,
-                                                      const float *__restrict__ gamma, int gstride,
+                                                      const float *__restrict__ gamma,
+                                                      const float *__restrict__ beta, int gstride,
                                                       const float *__restrict__ sums, float *__restrict__ dx,
                                                       float *__restrict__ dres, long long P, int C, int act,
                                                       float invP, float invD)
@@ -219,17 +232,20 @@ __global__ __launch_bounds__(256) void norm_bwd_apply(const float *__restrict__ 
         const int c = (int)(i % C4) * 4;
         const long long o = base + i * 4;
         f32x4 gy = *(const f32x4 *)(dy + o);
-        if (act != ACG_ACT_NONE) {
-            const f32x4 yy = *(const f32x4 *)(y + o);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) gy[k] *= acg_act_grad_from_y(yy[k], act);
-        }
+        const f32x4 xv = *(const f32x4 *)(x + o);
         const f32x4 mu = *(const f32x4 *)(mean + g * C + c);
         const f32x4 rs = *(const f32x4 *)(rstd + g * C + c);
         const f32x4 ga = *(const f32x4 *)(gamma + g * gstride + c);
+        if (act != ACG_ACT_NONE) {
+            f32x4 yy;
+            if (y == nullptr) yy = (xv - mu) * rs * ga + *(const f32x4 *)(beta + g * gstride + c);
+            else yy = *(const f32x4 *)(y + o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gy[k] *= acg_act_grad_from_y(yy[k], act);
+        }
         const f32x4 s1 = *(const f32x4 *)(sums + (g * 2) * C + c);
         const f32x4 s2 = *(const f32x4 *)(sums + (g * 2 + 1) * C + c);
-        const f32x4 xh = (*(const f32x4 *)(x + o) - mu) * rs;
+        const f32x4 xh = (xv - mu) * rs;
         *(f32x4 *)(dx + o) = ga * rs * (gy - s1 * invP - xh * (s2 * invD));
         if (dres != nullptr) *(f32x4 *)(dres + o) = gy;
     }
@@ -311,6 +327,7 @@ extern "C" int acg_norm_apply(const float *x, const float *mean, const float *rs
 // local reduction only: sums[(g*2+{0,1})*C + c] = sum_p gy, sum_p gy*xhat (what SyncBN all-reduces across ranks)
 extern "C" int acg_norm_bwd_sums(const float *dy, const float *y, const float *x, const float *mean, const float *rstd,
                                  float *sums, int G, size_t P, int C, int act, void *ws, size_t ws_bytes, void *stream)
+// (SyncBN path: always reads y)
 {
     int rc = check_norm(G, P, C, "acg_norm_bwd_sums");
     if (rc) return rc;
@@ -320,8 +337,9 @@ extern "C" int acg_norm_bwd_sums(const float *dy, const float *y, const float *x
     }
     hipStream_t st = (hipStream_t)stream;
     const int nch = nchunks_of(P);
-    hipLaunchKernelGGL(norm_bwd_partial, dim3(nch, G), dim3(256), 0, st, dy, y, x, mean, rstd, (long long)P, C, nch, act,
-                       (float *)ws);
+    ACG_REQUIRE(act == ACG_ACT_NONE || y != nullptr, "acg_norm_bwd_sums: y required");
+    hipLaunchKernelGGL(norm_bwd_partial, dim3(nch, G), dim3(256), 0, st, dy, y, x, mean, rstd, (const float *)nullptr,
+                       (const float *)nullptr, 0, (long long)P, C, nch, act, (float *)ws);
     hipLaunchKernelGGL(norm_bwd_final, dim3(acg_cdiv((long)G * C, 256)), dim3(256), 0, st, (const float *)ws, G, C, nch, sums);
     ACG_CHECK_LAUNCH("norm_bwd_sums");
     return ACG_OK;
@@ -336,15 +354,17 @@ extern "C" int acg_norm_bwd_apply(const float *dy, const float *y, const float *
     if (rc) return rc;
     const float invP = unbiased == 2 ? 0.f : 1.f / (float)Ptot;
     const float invD = unbiased == 2 ? 0.f : (unbiased ? 1.f / (float)(Ptot - 1) : invP);
+    ACG_REQUIRE(act == ACG_ACT_NONE || y != nullptr, "acg_norm_bwd_apply: y required");
     hipLaunchKernelGGL(norm_bwd_apply, dim3(ew_blocks((long long)P * (C / 4)), G), dim3(256), 0, (hipStream_t)stream, dy, y, x,
-                       mean, rstd, gamma, gstride, sums, dx, dres, (long long)P, C, act, invP, invD);
+                       mean, rstd, gamma, (const float *)nullptr, gstride, sums, dx, dres, (long long)P, C, act, invP, invD);
     ACG_CHECK_LAUNCH("norm_bwd_apply");
     return ACG_OK;
 }
 
 extern "C" int acg_norm_bwd(const float *dy, const float *y, const float *x, const float *mean, const float *rstd,
-                            const float *gamma, int gstride, float *dx, float *dres, float *dgamma, float *dbeta,
-                            int G, size_t P, int C, int act, int unbiased, void *ws, size_t ws_bytes, void *stream)
+                            const float *gamma, const float *beta, int gstride, float *dx, float *dres, float *dgamma,
+                            float *dbeta, int G, size_t P, int C, int act, int unbiased, void *ws, size_t ws_bytes,
+                            void *stream)
 {
     int rc = check_norm(G, P, C, "acg_norm_bwd");
     if (rc) return rc;
@@ -358,8 +378,9 @@ extern "C" int acg_norm_bwd(const float *dy, const float *y, const float *x, con
     const int nch = nchunks_of(P);
     float *part = (float *)ws;
     float *sums = part + (size_t)G * nch * 2 * C;
-    hipLaunchKernelGGL(norm_bwd_partial, dim3(nch, G), dim3(256), 0, st, dy, y, x, mean, rstd, (long long)P, C, nch, act,
-                       part);
+    ACG_REQUIRE(act == ACG_ACT_NONE || y != nullptr || beta != nullptr, "acg_norm_bwd: y or beta required for the activation mask");
+    hipLaunchKernelGGL(norm_bwd_partial, dim3(nch, G), dim3(256), 0, st, dy, y, x, mean, rstd, gamma, beta, gstride,
+                       (long long)P, C, nch, act, part);
     hipLaunchKernelGGL(norm_bwd_final, dim3(acg_cdiv((long)G * C, 256)), dim3(256), 0, st, (const float *)part, G, C,
                        nch, sums);
     if (dgamma != nullptr || dbeta != nullptr)
@@ -369,7 +390,7 @@ extern "C" int acg_norm_bwd(const float *dy, const float *y, const float *x, con
     const float invP = unbiased == 2 ? 0.f : 1.f / (float)P;
     const float invD = unbiased == 2 ? 0.f : (unbiased ? 1.f / (float)(P - 1) : invP);
     hipLaunchKernelGGL(norm_bwd_apply, dim3(ew_blocks((long long)P * (C / 4)), G), dim3(256), 0, st, dy, y, x, mean, rstd,
-                       gamma, gstride, (const float *)sums, dx, dres, (long long)P, C, act, invP, invD);
+                       gamma, beta, gstride, (const float *)sums, dx, dres, (long long)P, C, act, invP, invD);
     ACG_CHECK_LAUNCH("norm_bwd");
     return ACG_OK;
 }

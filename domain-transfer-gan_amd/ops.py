@@ -353,12 +353,14 @@ class NormAct(torch.autograd.Function):
         _lib.call("acg_norm_apply", _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gp), _ptr(bp), gstride, _ptr(res), _ptr(y), G, P, C,
                   act, st)
         ctx.cfg = (kind, act, G, P, C, unbiased, gstride, res is not None, gamma.shape)
-        ctx.save_for_backward(x, y if act != ACT_NONE else None, mean, rstd, gp)
+        # without a residual the backward recomputes the activation mask from x (gamma/beta): y is neither saved nor read
+        need_y = act != ACT_NONE and res is not None
+        ctx.save_for_backward(x, y if need_y else None, mean, rstd, gp, bp)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, mean, rstd, gp = ctx.saved_tensors
+        x, y, mean, rstd, gp, bp = ctx.saved_tensors
         kind, act, G, P, C, unbiased, gstride, has_res, gshape = ctx.cfg
         dy = dy.contiguous()
         dx = torch.empty_like(x)
@@ -368,8 +370,8 @@ class NormAct(torch.autograd.Function):
         dbeta = torch.empty(npar, device=x.device, dtype=torch.float32)
         nb = _lib.query("acg_norm_workspace_bytes", G, P, C)
         ws = workspace(nb)
-        _lib.call("acg_norm_bwd", _ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gp), gstride, _ptr(dx), _ptr(dres),
-                  _ptr(dgamma), _ptr(dbeta), G, P, C, act, unbiased, _ptr(ws), nb, _stream())
+        _lib.call("acg_norm_bwd", _ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gp), _ptr(bp), gstride, _ptr(dx),
+                  _ptr(dres), _ptr(dgamma), _ptr(dbeta), G, P, C, act, unbiased, _ptr(ws), nb, _stream())
         if kind == "cin":
             dg, db = dgamma.view(G, C), dbeta.view(G, C)
         else:

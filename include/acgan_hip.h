@@ -122,11 +122,12 @@ int acg_bn_eval_stats(const float *run_mean, const float *run_var, int C, int Cp
 int acg_norm_apply(const float *x, const float *mean, const float *rstd, const float *gamma, const float *beta,
                    int gstride, const float *res, float *y, int G, size_t P, int C, int act, void *stream);
 /* backward: dy (w.r.t. y), y, x -> dx, dres (if has_res; = dy*act'(y)), dgamma/dbeta
- * ([C] summed over groups when gstride==0, else [G*C]). unbiased as in acg_norm_stats; unbiased == 2 means the
+ * ([C] summed over groups when gstride==0, else [G*C]).  y may be NULL when no residual was added: the activation
+ * mask is then recomputed from x with gamma/beta (one tensor stream less per pass). unbiased as in acg_norm_stats; unbiased == 2 means the
  * statistics were constants (BatchNorm eval mode): dx = gamma*rstd*dy*act'. */
 int acg_norm_bwd(const float *dy, const float *y, const float *x, const float *mean, const float *rstd,
-                 const float *gamma, int gstride, float *dx, float *dres, float *dgamma, float *dbeta, int G,
-                 size_t P, int C, int act, int unbiased, void *workspace, size_t ws_bytes, void *stream);
+                 const float *gamma, const float *beta, int gstride, float *dx, float *dres, float *dgamma, float *dbeta,
+                 int G, size_t P, int C, int act, int unbiased, void *workspace, size_t ws_bytes, void *stream);
 
 /* the two halves of acg_norm_bwd, for SyncBN: local sums[(g*2+{0,1})*C+c] = (sum gy, sum gy*xhat), then — after the
  * caller has all-reduced them — the apply pass with the GLOBAL pixel count Ptot. */
