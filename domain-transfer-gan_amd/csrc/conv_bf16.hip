@@ -414,20 +414,22 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
     }
 
     if (WK > 1) {
-        static_assert(WK == 1 || (MI == 1 && MJ == 1), "split-K-in-block only for 32x32 tiles");
+        static_assert(WK == 1 || (MI == 1 && MJ == 1), "split-K-in-block only for 32x32 wave tiles");
+        static_assert(WK == 1 || sizeof(__bf16) * BCI * RS + sizeof(__bf16) * BCO * RS >= (size_t)WI * WJ * (WK - 1) * 1024 * sizeof(float),
+                      "LDS fold space");
         __syncthreads();
-        float *red = (float *)Xs; // needs 3 * 1024 floats = 12 KB
-        static_assert(WK == 1 || sizeof(__bf16) * BCI * RS >= 3 * 1024 * sizeof(float), "LDS reduce space");
+        float *red = (float *)Xs; // Xs and Ds are contiguous static LDS objects of this kernel; the fold may spill into Ds
+        const int grp = wi * WJ + wj;
         if (wk > 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[((wk - 1) * 16 + r) * 64 + lane] = acc[0][0][r];
+            for (int r = 0; r < 16; ++r) red[((grp * (WK - 1) + wk - 1) * 16 + r) * 64 + lane] = acc[0][0][r];
         }
         __syncthreads();
         if (wk == 0) {
 #pragma unroll
             for (int w = 0; w < WK - 1; ++w)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[0][0][r] += red[(w * 16 + r) * 64 + lane];
+                for (int r = 0; r < 16; ++r) acc[0][0][r] += red[((grp * (WK - 1) + w) * 16 + r) * 64 + lane];
         }
         if (wk != 0) return;
     }
@@ -445,10 +447,10 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
             }
 }
 
-int acg_wgrad_bf16_launch(const float *x, const float *dy, float *part, const WGeom &g, const Taps &t, int bci,
+int acg_wgrad_bf16_launch(const float *x, const float *dy, float *part, const WGeom &g, const Taps &t, int bci, int bco,
                           hipStream_t st)
 {
-    const int blocks = g.nsplit * t.n * (g.CiP / bci) * (g.CoP / bci);
+    const int blocks = g.nsplit * t.n * (g.CiP / bci) * (g.CoP / bco);
     dim3 grid(blocks), block(256);
     const long long nimg = g.Mtot / ((long long)g.Hg * g.Wg);
     const long long xbytes = nimg * g.Hin * g.Win * g.Cin * 4, dbytes = g.Mtot * g.Cg * 4;
@@ -456,8 +458,12 @@ int acg_wgrad_bf16_launch(const float *x, const float *dy, float *part, const WG
     const unsigned xb = (unsigned)xbytes, db = (unsigned)dbytes;
     if (bci == 128)
         hipLaunchKernelGGL((wgrad_bf16<128, 128, 2, 2, 1, 64>), grid, block, 0, st, x, dy, part, g, t, xb, db);
-    else if (bci == 64)
+    else if (bci == 64 && bco == 64)
         hipLaunchKernelGGL((wgrad_bf16<64, 64, 2, 2, 1, 64>), grid, block, 0, st, x, dy, part, g, t, xb, db);
+    else if (bci == 32 && bco == 64)
+        hipLaunchKernelGGL((wgrad_bf16<32, 64, 1, 2, 2, 128>), grid, block, 0, st, x, dy, part, g, t, xb, db);
+    else if (bci == 64 && bco == 32)
+        hipLaunchKernelGGL((wgrad_bf16<64, 32, 2, 1, 2, 128>), grid, block, 0, st, x, dy, part, g, t, xb, db);
     else
         hipLaunchKernelGGL((wgrad_bf16<32, 32, 1, 1, 4, 256>), grid, block, 0, st, x, dy, part, g, t, xb, db);
     ACG_CHECK_LAUNCH("wgrad_bf16");

@@ -49,5 +49,5 @@ void acg_wgrad_tiles(int Ci, int Co, int *bci, int *bco);
 extern int g_acg_precision;
 int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g, const Taps &t,
                           int bn, hipStream_t st);
-int acg_wgrad_bf16_launch(const float *x, const float *dy, float *part, const WGeom &g, const Taps &t, int bci,
+int acg_wgrad_bf16_launch(const float *x, const float *dy, float *part, const WGeom &g, const Taps &t, int bci, int bco,
                           hipStream_t st);

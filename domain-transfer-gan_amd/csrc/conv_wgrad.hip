@@ -172,20 +172,23 @@ __global__ __launch_bounds__(256) void wgrad_f32(const float *__restrict__ x, co
     }
 
     if (WK > 1) {
-        // waves hold partial sums of the SAME output tile: fold them through LDS in wave order
-        static_assert(WK == 1 || (MI == 1 && MJ == 1), "split-K-in-block only for 32x32 tiles");
+        // the WK waves of one (wi, wj) sub-tile hold partial sums of the SAME 32x32 outputs: fold them through LDS
+        // in wave order (deterministic)
+        static_assert(WK == 1 || (MI == 1 && MJ == 1), "split-K-in-block only for 32x32 wave tiles");
+        static_assert(WK == 1 || KP * BCI >= WI * WJ * (WK - 1) * 1024, "LDS fold space");
         __syncthreads();
-        float *red = Xs; // >= 3*1024 floats
+        float *red = Xs;
+        const int grp = wi * WJ + wj;
         if (wk > 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[((wk - 1) * 16 + r) * 64 + lane] = acc[0][0][r];
+            for (int r = 0; r < 16; ++r) red[((grp * (WK - 1) + wk - 1) * 16 + r) * 64 + lane] = acc[0][0][r];
         }
         __syncthreads();
         if (wk == 0) {
 #pragma unroll
             for (int w = 0; w < WK - 1; ++w)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[0][0][r] += red[(w * 16 + r) * 64 + lane];
+                for (int r = 0; r < 16; ++r) acc[0][0][r] += red[((grp * (WK - 1) + w) * 16 + r) * 64 + lane];
         }
         if (wk != 0) return;
     }
@@ -205,18 +208,20 @@ __global__ __launch_bounds__(256) void wgrad_f32(const float *__restrict__ x, co
 
 void acg_wgrad_tiles(int Ci, int Co, int *bci, int *bco)
 {
-    // one square tile size per layer: 128 for the dense 128/256-channel layers, 64 mid, 32 for thin ones
-    const int mn = Ci < Co ? Ci : Co;
-    const int t = mn >= 128 ? 128 : (mn >= 64 ? 64 : 32);
-    *bci = t;
-    *bco = t;
+    // 128x128 for the dense 128/256-channel layers, 64x64 mid; thin layers 32x32; 32<->64-channel layers get a
+    // rectangular 32x64 / 64x32 tile (two 32x32 wave tiles, two waves splitting K each)
+    const int mn = Ci < Co ? Ci : Co, mx = Ci < Co ? Co : Ci;
+    if (mn >= 128) { *bci = *bco = 128; return; }
+    if (mn >= 64) { *bci = *bco = 64; return; }
+    if (mn == 32 && mx >= 64) { *bci = Ci == 32 ? 32 : 64; *bco = Co == 32 ? 32 : 64; return; }
+    *bci = *bco = 32;
 }
 
 int acg_wgrad_launch(const float *x, const float *dy, float *part, const WGeom &g, const Taps &t, hipStream_t st)
 {
     int bci, bco;
     acg_wgrad_tiles(g.Cin, g.Cg, &bci, &bco);
-    if (g_acg_precision == ACG_PREC_BF16 && !g.thin) return acg_wgrad_bf16_launch(x, dy, part, g, t, bci, st);
+    if (g_acg_precision == ACG_PREC_BF16 && !g.thin) return acg_wgrad_bf16_launch(x, dy, part, g, t, bci, bco, st);
     const int blocks = g.nsplit * (g.thin ? 1 : t.n) * (g.CiP / bci) * (g.CoP / bco);
     dim3 grid(blocks), block(256);
     const long long nimg = g.Mtot / ((long long)g.Hg * g.Wg);
@@ -225,8 +230,12 @@ int acg_wgrad_launch(const float *x, const float *dy, float *part, const WGeom &
     const unsigned xb = (unsigned)xbytes, db = (unsigned)dbytes;
     if (bci == 128)
         hipLaunchKernelGGL((wgrad_f32<128, 128, 2, 2, 1, 32>), grid, block, 0, st, x, dy, part, g, t, xb, db);
-    else if (bci == 64)
+    else if (bci == 64 && bco == 64)
         hipLaunchKernelGGL((wgrad_f32<64, 64, 2, 2, 1, 32>), grid, block, 0, st, x, dy, part, g, t, xb, db);
+    else if (bci == 32 && bco == 64)
+        hipLaunchKernelGGL((wgrad_f32<32, 64, 1, 2, 2, 64>), grid, block, 0, st, x, dy, part, g, t, xb, db);
+    else if (bci == 64 && bco == 32)
+        hipLaunchKernelGGL((wgrad_f32<64, 32, 2, 1, 2, 64>), grid, block, 0, st, x, dy, part, g, t, xb, db);
     else
         hipLaunchKernelGGL((wgrad_f32<32, 32, 1, 1, 4, 128>), grid, block, 0, st, x, dy, part, g, t, xb, db);
     ACG_CHECK_LAUNCH("wgrad_f32");
