@@ -130,7 +130,8 @@ def main():
         "config": {"workload": "%dx%dx3 synthetic unpaired, %d-resblock G + latent encoder (full Augmented CycleGAN "
                                "train_instance), batch=%d per GPU (global %d)" % (S, S, a.blocks, N, N * ws),
                    "parallelism": "dp%d" % ws, "loss_G_A": round(losses["G_A"], 5)},
-        "roofline": {"bound": "mfma", "kernel": "igemm_conv_%s<128,128,2,2> (resblock 3x3 reflect 128->128 fwd)" % a.precision,
+        "roofline": {"bound": "mfma", "kernel": ("igemm_conv_f32<128,128,2,2,32,REFLECT,!THIN>" if a.precision == "f32" else "igemm_conv_bf16<128,128,2,2,64,REFLECT>")
+                               + " (resblock 3x3 reflect 128->128 fwd)",
                      "achieved": None if achieved is None else round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": None if achieved is None else round(achieved / peak, 4), "traffic": traffic,
                      "launches_timed": len(ms), "avg_launch_ms": round(kern_ms, 4), "flops_per_launch": flops},
