@@ -58,7 +58,6 @@ SIGNATURES = {
     "acg_norm_bwd_sums": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_size_t, c_int, c_int, _P, c_size_t, _P]),
     "acg_norm_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_size_t, c_size_t, c_int, c_int, c_int, _P]),
     "acg_act_bwd": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
-    "acg_add": (c_int, [_P, _P, _P, c_size_t, _P]),
     "acg_linear_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "acg_linear_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "acg_spatial_mean_fwd": (c_int, [_P, _P, c_int, c_size_t, c_int, _P]),

@@ -722,14 +722,12 @@ static size_t wgrad_ws_bytes(const acg_conv_desc *d, int Cx, int Cg, long long M
     const size_t bias_part = (size_t)ns * (CiP > CoP ? CiP : CoP) * sizeof(float);
     size_t total = acg_round_up(part, 256) + acg_round_up(colsum_ws_bytes(Mbig, Cmax) + bias_part, 256);
     if (thin_out(d) && d->stride == 1) { // wgrad_thin_out's partial buffer (its own split plan, <= 512 splits)
-        const size_t tneed = (size_t)512 * 32 * ((d->K * d->K + 7) / 8) * ((d->Ci + 31) / 32 * 32) * sizeof(float);
         const long long Mx = (long long)d->N * d->Hi * d->Wi;
         long long ns2 = 1536 / ((long long)((d->K * d->K + 7) / 8) * ((d->Ci + 31) / 32)), cap = Mx / 1024;
         if (ns2 > cap) ns2 = cap;
         if (ns2 > 512) ns2 = 512;
         if (ns2 < 1) ns2 = 1;
         const size_t t2 = (size_t)(ns2 + 1) * 32 * ((d->K * d->K + 7) / 8) * ((d->Ci + 31) / 32 * 32) * sizeof(float);
-        (void)tneed;
         if (t2 > total) total = t2;
     }
     return total;

@@ -192,7 +192,6 @@ int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, fl
                           int bn, hipStream_t st)
 {
     Geom g = g0;
-    g.tw = 0;
     g.thin = 0;
     dim3 grid(acg_cdiv(g.Mtot, 128) * (g.ncols_pad / bn));
     const __bf16 *w = (const __bf16 *)wp;

@@ -22,7 +22,6 @@ struct Geom {
     int ncols_pad;        // packed-weight column count (multiple of the N tile)
     int thin;             // 1: K flattened over (tap, 4 channels): stage s = taps 8s..8s+7, channels 0..3 of each
     int bk8;              // 8-float k-chunks per packed weight slab (Cin/8; thin: 4*ceil(ntaps/8), single slab)
-    int tw;               // M-tile width for 2-D spatial tiles (0 = flattened pixels); set by the launcher
     long long Mtot;       // N*GH*GW
 };
 

@@ -22,7 +22,7 @@ void acg_set_error(const char *fmt, ...)
 extern "C" const char *acg_last_error(void) { return g_err; }
 extern "C" int acg_version(void) { return ACG_VERSION; }
 
-// ---------------------------------------------------------------- activation backward / add
+// ---------------------------------------------------------------- activation backward
 __global__ void act_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, float *__restrict__ dx,
                                long long n4, int act)
 {
@@ -40,18 +40,6 @@ extern "C" int acg_act_bwd(const float *dy, const float *y, float *dx, size_t n,
     hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, y, dx,
                        (long long)(n / 4), act);
     ACG_CHECK_LAUNCH("act_bwd_kernel");
-    return ACG_OK;
-}
-
-__global__ void add_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ o, long long n4)
-{
-    GRID_STRIDE(i, n4) { *(f32x4 *)(o + i * 4) = *(const f32x4 *)(a + i * 4) + *(const f32x4 *)(b + i * 4); }
-}
-extern "C" int acg_add(const float *a, const float *b, float *out, size_t n, void *stream)
-{
-    ACG_REQUIRE(n % 4 == 0, "acg_add: n %% 4 != 0");
-    hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long long)(n / 4));
-    ACG_CHECK_LAUNCH("add_kernel");
     return ACG_OK;
 }
 

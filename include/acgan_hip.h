@@ -139,7 +139,6 @@ int acg_norm_bwd_apply(const float *dy, const float *y, const float *x, const fl
 
 /* ---- elementwise ---- */
 int acg_act_bwd(const float *dy, const float *y, float *dx, size_t n, int act, void *stream); /* dx = dy*act'(y) */
-int acg_add(const float *a, const float *b, float *out, size_t n, void *stream);
 
 /* ---- small dense layers: nn.Linear (networks.py:406-418), the 1x1 convs on the (N,nl,1,1) latent
  *      inside CondInstanceNorm (modules.py:111-118).  y[N][Op] = act(x[N][I] W[O][I]^T + b); columns

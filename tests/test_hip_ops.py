@@ -284,3 +284,31 @@ def test_linear_and_spatial_mean():
     assert rel(n(sm), a.mean(axis=(1, 2))) < 1e-5
     sm.backward(t(np.ones((2, 16))))
     assert np.allclose(n(at.grad), 1.0 / 15)
+
+
+def test_c_abi_error_convention():
+    """negative status + thread-local message instead of a fault: bad descriptor, unpadded channels, short workspace,
+    unsupported geometry (reflect + stride 2)"""
+    import ctypes
+    from dtgan_amd import _lib, ops
+    lib = _lib.load()
+    x = torch.zeros(1, 8, 8, 16, device="cuda"); y = torch.zeros(1, 8, 8, 16, device="cuda")
+    w = torch.zeros(16 * 16 * 9 * 2, device="cuda")
+    P, st = ops._ptr, ops._stream()
+    bad = _lib.ConvDesc(1, 8, 8, 12, 8, 8, 16, 3, 1, 1, 0, 0, 0)          # Ci not padded to 16
+    assert lib.acg_conv2d_fwd(ctypes.byref(bad), P(x), P(w), None, P(y), 0, st) == -1
+    assert b"padded to 16" in lib.acg_last_error()
+    bad = _lib.ConvDesc(1, 8, 8, 16, 7, 7, 16, 3, 1, 1, 0, 0, 0)          # inconsistent output size
+    assert lib.acg_conv2d_fwd(ctypes.byref(bad), P(x), P(w), None, P(y), 0, st) == -1
+    assert b"inconsistent" in lib.acg_last_error()
+    bad = _lib.ConvDesc(1, 8, 8, 16, 4, 4, 16, 3, 2, 1, 1, 0, 0)          # reflect + stride 2
+    assert lib.acg_conv2d_fwd(ctypes.byref(bad), P(x), P(w), None, P(y), 0, st) == -1
+    ok = _lib.ConvDesc(1, 8, 8, 16, 8, 8, 16, 3, 1, 1, 1, 0, 0)           # reflect dgrad needs a workspace
+    assert lib.acg_conv2d_bwd_data(ctypes.byref(ok), P(y), P(w), P(x), None, 0, st) == -2
+    assert b"workspace" in lib.acg_last_error()
+    assert lib.acg_conv2d_bwd_weight(ctypes.byref(ok), P(x), P(y), P(w), None, 16, 16, None, 0, st) == -1
+    assert lib.acg_norm_stats(P(x), 1, 64, 18, 1e-5, 0, P(y), P(y), None, None, 0.0, P(w), 1 << 20, st) == -1   # C % 4
+    assert lib.acg_set_conv_precision(7) == -1 and lib.acg_set_conv_impl(9) == -1
+    with pytest.raises(_lib.AcgError):
+        _lib.call("acg_adam_step", P(x), P(x), P(x), P(x), 16, None, 1.0, 1e-3, 0.5, 0.999, 1e-8, 0, 0, st)   # step < 1
+    torch.cuda.synchronize()
