@@ -118,10 +118,29 @@ def print_network(net, out_f=None):
 
 
 ##############################################################################
-# Network Classes
+# Network classes — built from layer tables (same module order, hence same state_dict keys, as the reference)
 ##############################################################################
+def _act(kind):
+    return {"relu": lambda: nn.ReLU(True), "lrelu": lambda: nn.LeakyReLU(0.2, True), "tanh": lambda: nn.Tanh()}[kind]()
+
+
+def _generator_layers(norm, input_nc, output_nc, ngf, n_blocks, make_block):
+    """Stem (7x7 reflect, 3x3, 3x3 stride 2) -> n_blocks residual blocks at 4*ngf -> tail (ConvTranspose, 3x3, 7x7 + tanh).
+    `norm(c)` builds the normalisation layer for c channels (InstanceNorm or CondInstanceNorm)."""
+    layers = [nn.ReflectionPad2d(3)]
+    # (cin, cout, kernel, stride, padding) of the three stem convolutions; each is followed by norm + ReLU
+    for cin, cout, k, stride, pad in ((input_nc, ngf, 7, 1, 0), (ngf, 2 * ngf, 3, 1, 1), (2 * ngf, 4 * ngf, 3, 2, 1)):
+        layers += [Conv2d(cin, cout, kernel_size=k, padding=pad, stride=stride, bias=True), norm(cout), _act("relu")]
+    layers += [make_block(4 * ngf) for _ in range(n_blocks)]
+    layers += [ConvTranspose2d(4 * ngf, 2 * ngf, kernel_size=3, stride=2, padding=1, output_padding=1, bias=True),
+               norm(2 * ngf), _act("relu"),
+               Conv2d(2 * ngf, ngf, kernel_size=3, padding=1, stride=1, bias=True), norm(ngf), _act("relu"),
+               Conv2d(ngf, output_nc, kernel_size=7, padding=3), _act("tanh")]       # zero padding here (networks.py:187, 242)
+    return layers
+
+
 class CINResnetGenerator(nn.Module):
-    """networks.py:149-197"""
+    """A -> B generator conditioned on the latent code through CondInstanceNorm — networks.py:149-197"""
 
     def __init__(self, nlatent, input_nc, output_nc, ngf=64, norm_layer=CondInstanceNorm, use_dropout=False,
                  n_blocks=9, gpu_ids=[], padding_type='reflect'):
@@ -129,44 +148,21 @@ class CINResnetGenerator(nn.Module):
         super(CINResnetGenerator, self).__init__()
         self.gpu_ids = gpu_ids
         self.nlatent, self.input_nc, self.output_nc = nlatent, input_nc, output_nc
-        model = [
-            nn.ReflectionPad2d(3),
-            Conv2d(input_nc, ngf, kernel_size=7, padding=0, stride=1, bias=True),
-            norm_layer(ngf, nlatent),
-            nn.ReLU(True),
-            Conv2d(ngf, 2 * ngf, kernel_size=3, padding=1, stride=1, bias=True),
-            norm_layer(2 * ngf, nlatent),
-            nn.ReLU(True),
-            Conv2d(2 * ngf, 4 * ngf, kernel_size=3, padding=1, stride=2, bias=True),
-            norm_layer(4 * ngf, nlatent),
-            nn.ReLU(True)
-        ]
-        for i in range(n_blocks):
-            model += [CINResnetBlock(x_dim=4 * ngf, z_dim=nlatent, padding_type=padding_type, norm_layer=norm_layer,
-                                     use_dropout=use_dropout, use_bias=True)]
-        model += [
-            ConvTranspose2d(4 * ngf, 2 * ngf, kernel_size=3, stride=2, padding=1, output_padding=1, bias=True),
-            norm_layer(2 * ngf, nlatent),
-            nn.ReLU(True),
-            Conv2d(2 * ngf, ngf, kernel_size=3, padding=1, stride=1, bias=True),
-            norm_layer(ngf, nlatent),
-            nn.ReLU(True),
-            Conv2d(ngf, output_nc, kernel_size=7, padding=3),
-            nn.Tanh()
-        ]
-        self.model = TwoInputSequential(*model)
+        block = lambda c: CINResnetBlock(x_dim=c, z_dim=nlatent, padding_type=padding_type, norm_layer=norm_layer,
+                                         use_dropout=use_dropout, use_bias=True)
+        self.model = TwoInputSequential(*_generator_layers(lambda c: norm_layer(c, nlatent), input_nc, output_nc, ngf,
+                                                           n_blocks, block))
 
     def forward_nhwc(self, x, z):
         """x: NHWC C16, z: (N, >=nlatent) -> NHWC C16 (output_nc valid channels)"""
-        y, _ = run_sequence(list(self.model._modules.values()), x, self.input_nc, z)
-        return y
+        return run_sequence(list(self.model._modules.values()), x, self.input_nc, z)[0]
 
     def forward(self, input, noise):
         return self.model(input, noise)
 
 
 class ResnetGenerator(nn.Module):
-    """networks.py:203-252"""
+    """B -> A deterministic generator — networks.py:203-252"""
 
     def __init__(self, input_nc, output_nc, ngf=64, norm_layer=InstanceNorm2d, use_dropout=False, n_blocks=9,
                  gpu_ids=[], padding_type='reflect'):
@@ -174,126 +170,76 @@ class ResnetGenerator(nn.Module):
         super(ResnetGenerator, self).__init__()
         self.gpu_ids = gpu_ids
         self.input_nc, self.output_nc = input_nc, output_nc
-        model = [
-            nn.ReflectionPad2d(3),
-            Conv2d(input_nc, ngf, kernel_size=7, padding=0, stride=1, bias=True),
-            norm_layer(ngf),
-            nn.ReLU(True),
-            Conv2d(ngf, 2 * ngf, kernel_size=3, padding=1, stride=1, bias=True),
-            norm_layer(2 * ngf),
-            nn.ReLU(True),
-            Conv2d(2 * ngf, 4 * ngf, kernel_size=3, padding=1, stride=2, bias=True),
-            norm_layer(4 * ngf),
-            nn.ReLU(True),
-        ]
-        for i in range(n_blocks):
-            model += [ResnetBlock(4 * ngf, padding_type=padding_type, norm_layer=norm_layer, use_dropout=use_dropout,
-                                  use_bias=True)]
-        model += [
-            ConvTranspose2d(4 * ngf, 2 * ngf, kernel_size=3, stride=2, padding=1, output_padding=1, bias=True),
-            norm_layer(2 * ngf),
-            nn.ReLU(True),
-            Conv2d(2 * ngf, ngf, kernel_size=3, padding=1, bias=True),
-            norm_layer(ngf),
-            nn.ReLU(True),
-            Conv2d(ngf, output_nc, kernel_size=7, padding=3),
-            nn.Tanh()
-        ]
-        self.model = Sequential(*model)
+        block = lambda c: ResnetBlock(c, padding_type=padding_type, norm_layer=norm_layer, use_dropout=use_dropout,
+                                      use_bias=True)
+        self.model = Sequential(*_generator_layers(norm_layer, input_nc, output_nc, ngf, n_blocks, block))
 
     def forward_nhwc(self, x):
-        y, _ = run_sequence(list(self.model._modules.values()), x, self.input_nc)
-        return y
+        return run_sequence(list(self.model._modules.values()), x, self.input_nc)[0]
 
     def forward(self, input):
         return self.model(input)
 
 
+def _patch_discriminator(input_nc, ndf, norm_layer, use_sigmoid, specs, head):
+    """specs: (cout multiplier, kernel, stride) of the conv -> [norm] -> LeakyReLU(0.2) stages (the first has no norm);
+    head: (kernel, padding) of the final 1-channel convolution."""
+    seq, cin = [], input_nc
+    for i, (mult, k, stride) in enumerate(specs):
+        seq.append(Conv2d(cin, mult * ndf, kernel_size=k, stride=stride, padding=1, bias=True))
+        if i > 0:
+            seq.append(norm_layer(mult * ndf))
+        seq.append(_act("lrelu"))
+        cin = mult * ndf
+    seq.append(Conv2d(cin, 1, kernel_size=head[0], stride=1, padding=head[1], bias=True))
+    if use_sigmoid:
+        seq.append(nn.Sigmoid())
+    return Sequential(*seq)
+
+
 class _ImageD(nn.Module):
     def forward_nhwc(self, x):
-        y, _ = run_sequence(list(self.model._modules.values()), x, None)
-        return y
+        return run_sequence(list(self.model._modules.values()), x, None)[0]
 
     def forward(self, input):
         return self.model(input)
 
 
 class Discriminator(_ImageD):
-    """D_B — networks.py:308-349"""
+    """D_B — networks.py:308-349: 4x4 convs, strides 2,2,1,1 then a 4x4 pad-1 head"""
 
     def __init__(self, input_nc, ndf=64, norm_layer=BatchNorm2d, use_sigmoid=False, gpu_ids=[]):
         super(Discriminator, self).__init__()
         self.gpu_ids = gpu_ids
-        use_bias = True
-        kw = 4
-        sequence = [
-            Conv2d(input_nc, ndf, kernel_size=kw, stride=2, padding=1, bias=True),
-            nn.LeakyReLU(0.2, True),
-            Conv2d(ndf, 2 * ndf, kernel_size=kw, stride=2, padding=1, bias=use_bias),
-            norm_layer(2 * ndf),
-            nn.LeakyReLU(0.2, True),
-            Conv2d(2 * ndf, 4 * ndf, kernel_size=kw, stride=1, padding=1, bias=use_bias),
-            norm_layer(4 * ndf),
-            nn.LeakyReLU(0.2, True),
-            Conv2d(4 * ndf, 4 * ndf, kernel_size=kw, stride=1, padding=1, bias=use_bias),
-            norm_layer(4 * ndf),
-            nn.LeakyReLU(0.2, True),
-            Conv2d(4 * ndf, 1, kernel_size=kw, stride=1, padding=1)
-        ]
-        if use_sigmoid:
-            sequence += [nn.Sigmoid()]
-        self.model = Sequential(*sequence)
+        self.model = _patch_discriminator(input_nc, ndf, norm_layer, use_sigmoid,
+                                          specs=((1, 4, 2), (2, 4, 2), (4, 4, 1), (4, 4, 1)), head=(4, 1))
 
 
 class Discriminator_edges(_ImageD):
-    """D_A — networks.py:352-393"""
+    """D_A — networks.py:352-393: four 3x3 stride-2 convs then a 4x4 valid head"""
 
     def __init__(self, input_nc, ndf=64, norm_layer=BatchNorm2d, use_sigmoid=False, gpu_ids=[]):
         super(Discriminator_edges, self).__init__()
         self.gpu_ids = gpu_ids
-        use_bias = True
-        kw = 3
-        sequence = [
-            Conv2d(input_nc, ndf, kernel_size=kw, stride=2, padding=1, bias=True),
-            nn.LeakyReLU(0.2, True),
-            Conv2d(ndf, 2 * ndf, kernel_size=kw, stride=2, padding=1, bias=use_bias),
-            norm_layer(2 * ndf),
-            nn.LeakyReLU(0.2, True),
-            Conv2d(2 * ndf, 4 * ndf, kernel_size=kw, stride=2, padding=1, bias=use_bias),
-            norm_layer(4 * ndf),
-            nn.LeakyReLU(0.2, True),
-            Conv2d(4 * ndf, 4 * ndf, kernel_size=kw, stride=2, padding=1, bias=use_bias),
-            norm_layer(4 * ndf),
-            nn.LeakyReLU(0.2, True),
-            Conv2d(4 * ndf, 1, kernel_size=4, stride=1, padding=0, bias=True)
-        ]
-        if use_sigmoid:
-            sequence += [nn.Sigmoid()]
-        self.model = Sequential(*sequence)
+        self.model = _patch_discriminator(input_nc, ndf, norm_layer, use_sigmoid,
+                                          specs=((1, 3, 2), (2, 3, 2), (4, 3, 2), (4, 3, 2)), head=(4, 0))
 
 
 class DiscriminatorLatent(nn.Module):
-    """D_z_B — networks.py:396-433"""
+    """D_z_B — networks.py:396-433: three Linear/BatchNorm1d/LeakyReLU stages and a Linear head"""
 
     def __init__(self, nlatent, ndf, use_sigmoid=False, gpu_ids=[]):
         super(DiscriminatorLatent, self).__init__()
         self.gpu_ids = gpu_ids
         self.nlatent = nlatent
-        sequence = [
-            Linear(nlatent, ndf),
-            BatchNorm1d(ndf),
-            nn.LeakyReLU(0.2, True),
-            Linear(ndf, ndf),
-            BatchNorm1d(ndf),
-            nn.LeakyReLU(0.2, True),
-            Linear(ndf, ndf),
-            BatchNorm1d(ndf),
-            nn.LeakyReLU(0.2, True),
-            Linear(ndf, 1)
-        ]
+        seq, width = [], nlatent
+        for _ in range(3):
+            seq += [Linear(width, ndf), BatchNorm1d(ndf), _act("lrelu")]
+            width = ndf
+        seq.append(Linear(ndf, 1))
         if use_sigmoid:
-            sequence += [nn.Sigmoid()]
-        self.model = Sequential(*sequence)
+            seq.append(nn.Sigmoid())
+        self.model = Sequential(*seq)
 
     def forward_dense(self, z):
         """z: (N, >=nlatent) -> (N, 4) with column 0 valid"""
@@ -306,40 +252,25 @@ class DiscriminatorLatent(nn.Module):
 
 
 class LatentEncoder(nn.Module):
-    """E_B — networks.py:438-482"""
+    """E_B — networks.py:438-482: five conv stages (only the first has a bias and no norm), then two 1x1 heads"""
 
     def __init__(self, nlatent, input_nc, nef, norm_layer, gpu_ids=[]):
         super(LatentEncoder, self).__init__()
         self.gpu_ids = gpu_ids
         self.nlatent = nlatent
-        use_bias = False
-        kw = 3
-        sequence = [
-            Conv2d(input_nc, nef, kernel_size=kw, stride=2, padding=1, bias=True),
-            nn.ReLU(True),
-            Conv2d(nef, 2 * nef, kernel_size=kw, stride=2, padding=1, bias=use_bias),
-            norm_layer(2 * nef),
-            nn.ReLU(True),
-            Conv2d(2 * nef, 4 * nef, kernel_size=kw, stride=2, padding=1, bias=use_bias),
-            norm_layer(4 * nef),
-            nn.ReLU(True),
-            Conv2d(4 * nef, 8 * nef, kernel_size=kw, stride=2, padding=1, bias=use_bias),
-            norm_layer(8 * nef),
-            nn.ReLU(True),
-            Conv2d(8 * nef, 8 * nef, kernel_size=4, stride=1, padding=0, bias=use_bias),
-            norm_layer(8 * nef),
-            nn.ReLU(True),
-        ]
-        self.conv_modules = Sequential(*sequence)
+        seq = [Conv2d(input_nc, nef, kernel_size=3, stride=2, padding=1, bias=True), _act("relu")]
+        # (cin, cout, kernel, stride, padding)
+        for cin, cout, k, stride, pad in ((nef, 2 * nef, 3, 2, 1), (2 * nef, 4 * nef, 3, 2, 1), (4 * nef, 8 * nef, 3, 2, 1),
+                                          (8 * nef, 8 * nef, 4, 1, 0)):
+            seq += [Conv2d(cin, cout, kernel_size=k, stride=stride, padding=pad, bias=False), norm_layer(cout), _act("relu")]
+        self.conv_modules = Sequential(*seq)
         self.enc_mu = Conv2d(8 * nef, nlatent, kernel_size=1, stride=1, padding=0, bias=True)
         self.enc_logvar = Conv2d(8 * nef, nlatent, kernel_size=1, stride=1, padding=0, bias=True)
 
     def forward_nhwc(self, x):
         """x: NHWC C16 -> (mu, logvar), each (N, cpad(nlatent)) with nlatent valid columns"""
-        h, _ = run_sequence(list(self.conv_modules._modules.values()), x, None)
-        mu = ops.SpatialMean.apply(self.enc_mu.forward_nhwc(h))
-        logvar = ops.SpatialMean.apply(self.enc_logvar.forward_nhwc(h))
-        return mu, logvar
+        h = run_sequence(list(self.conv_modules._modules.values()), x, None)[0]
+        return ops.SpatialMean.apply(self.enc_mu.forward_nhwc(h)), ops.SpatialMean.apply(self.enc_logvar.forward_nhwc(h))
 
     def forward(self, input):
         mu, logvar = self.forward_nhwc(ops.ToNHWC.apply(input))

@@ -16,98 +16,109 @@ def create_sub_dirs(opt, sub_dirs):
         setattr(opt, sub_dir, dir_path)
 
 
+# flag table: (name, kind, default, help).  kind is a type, a ("choice", type, values) tuple, or "flag".
+# Values and order follow options.py:20-85 of the reference; the last group is new here.
+_T = [
+    ("dataroot", str, None, "path to data (trainA/B.npz, testA/B.npz)"),
+    ("checkpoints_dir", str, "./checkpoints/", "models are saved here"),
+    # data
+    ("input_nc", int, 3, "# of input image channels"),
+    ("output_nc", int, 3, "# of output image channels"),
+    ("grid_size", int, 256, "resolution of input/output grids"),
+    ("numpy_data", ("choice", int, [0, 1]), 1, "use numpy data"),
+    # experiment
+    ("seed", int, None, "manual seed"),
+    ("model", ("choice", str, ["cycle_gan", "stoch_cycle_gan", "aug_cycle_gan"]), "aug_cycle_gan", "which model to train"),
+    ("gpu_ids", str, "0", 'gpu ids: e.g. 0  0,1,2 (only "on the GPU" matters here; -1 is rejected later: no CPU path)'),
+    # supervised training
+    ("supervised", "flag", False, "also run the paired step"),
+    ("sup_frac", float, 0.1, "fraction of training data for supervised training"),
+    ("lambda_sup_A", float, 0.1, "weight for supervised loss (B -> A)"),
+    ("lambda_sup_B", float, 0.1, "weight for supervised loss (A -> B)"),
+    # training
+    ("batchSize", int, 32, "input batch size"),
+    ("continue_train", "flag", False, "reload <expr_dir>/<which_epoch> before training"),
+    ("which_epoch", str, "latest", "checkpoint name to resume from"),
+    ("epoch_count", int, 1, "the starting epoch count"),
+    ("niter", int, 25, "# of epochs at starting learning rate"),
+    ("niter_decay", int, 25, "# of epochs to linearly decay learning rate to zero"),
+    ("beta1", float, 0.5, "momentum term of adam"),
+    ("lr", float, 0.0002, "initial learning rate for adam"),
+    # model
+    ("ngf", int, 32, "# of gen filters in first conv layer"),
+    ("nef", int, 32, "# of encoder filters in first conv layer"),
+    ("ndf", int, 64, "# of discrim filters in first conv layer"),
+    ("nlatent", int, 16, "# of latent code dimensions"),
+    ("which_model_netD", str, "basic", "(accepted, unused — as in the reference)"),
+    ("which_model_netG", str, "resnet", "(accepted, unused — as in the reference)"),
+    ("norm", str, "instance", "instance or batch normalization"),
+    ("use_dropout", "flag", False, "not implemented by the HIP path"),
+    ("max_gnorm", float, 500., "max grad norm to which it will be clipped"),
+    ("stoch_enc", "flag", False, "use a stochastic encoder"),
+    ("z_gan", ("choice", int, [0, 1]), 1, "use a GAN on z_B"),
+    ("enc_A_B", ("choice", int, [0, 1]), 1, "encoder of z_B conditioned on both A and B"),
+    ("no_lsgan", "flag", False, "vanilla GAN (the reference's BCE branch is broken; raises here)"),
+    ("lambda_A", float, 1.0, "weight for cycle loss (A -> B -> A)"),
+    ("lambda_B", float, 1.0, "weight for cycle loss (B -> A -> B)"),
+    ("lambda_z_B", float, 0.025, "weight for the latent cycle loss"),
+    # monitoring
+    ("monitor_gnorm", bool, True, "monitor grad norms (type=bool as in options.py:77: any string is True)"),
+    ("display_freq", int, 5000, "frequency of PNG dumps"),
+    ("print_freq", int, 100, "frequency of log lines"),
+    ("save_epoch_freq", int, 5, "frequency of saving checkpoints at the end of epochs"),
+    ("num_multi", int, 10, "the number of z_B used to generate different B"),
+    ("eval_A_freq", int, 1, "frequency of evaluating on A"),
+    ("eval_B_freq", int, 1, "frequency of evaluating on B"),
+    # additions of this implementation
+    ("n_blocks", int, 3, "residual blocks per generator (the reference builds 3)"),
+    ("precision", ("choice", str, ["f32", "bf16"]), "f32", "conv arithmetic"),
+    ("synthetic", int, 0, "use N synthetic U(-1,1) samples per split instead of --dataroot"),
+    ("sync_bn", "flag", False, "data parallel: BatchNorm (E_B, D_z_B) statistics across all ranks"),
+    ("eval_steps", int, 50, "variational-bound steps per epoch (train.py:285 uses 50)"),
+]
+
+
 class TrainOptions(object):
     def __init__(self):
         self.parser = argparse.ArgumentParser()
         self.initialized = False
 
     def initialize(self):
-        p = self.parser
-        p.add_argument('--dataroot', type=str, default=None, help='path to data (trainA/B.npz, testA/B.npz)')
-        p.add_argument('--name', type=str, required=True, help='name of the experiment')
-        p.add_argument('--checkpoints_dir', type=str, default='./checkpoints/', help='models are saved here')
-        # data
-        p.add_argument('--input_nc', type=int, default=3)
-        p.add_argument('--output_nc', type=int, default=3)
-        p.add_argument('--grid_size', type=int, default=256)
-        p.add_argument('--numpy_data', type=int, choices=[0, 1], default=1)
-        # exp
-        p.add_argument('--seed', type=int)
-        p.add_argument('--model', type=str, choices=['cycle_gan', 'stoch_cycle_gan', 'aug_cycle_gan'], default='aug_cycle_gan')
-        p.add_argument('--gpu_ids', type=str, default='0', help='gpu ids: e.g. 0  0,1,2 (only "on the GPU" matters here)')
-        # supervised training
-        p.add_argument('--supervised', action='store_true')
-        p.add_argument('--sup_frac', type=float, default=0.1)
-        p.add_argument('--lambda_sup_A', type=float, default=0.1)
-        p.add_argument('--lambda_sup_B', type=float, default=0.1)
-        # training
-        p.add_argument('--batchSize', type=int, default=32)
-        p.add_argument('--continue_train', action='store_true', help='reload <expr_dir>/<which_epoch> before training')
-        p.add_argument('--which_epoch', type=str, default='latest')
-        p.add_argument('--epoch_count', type=int, default=1)
-        p.add_argument('--niter', type=int, default=25)
-        p.add_argument('--niter_decay', type=int, default=25)
-        p.add_argument('--beta1', type=float, default=0.5)
-        p.add_argument('--lr', type=float, default=0.0002)
-        # model
-        p.add_argument('--ngf', type=int, default=32)
-        p.add_argument('--nef', type=int, default=32)
-        p.add_argument('--ndf', type=int, default=64)
-        p.add_argument('--nlatent', type=int, default=16)
-        p.add_argument('--which_model_netD', type=str, default='basic')
-        p.add_argument('--which_model_netG', type=str, default='resnet')
-        p.add_argument('--norm', type=str, default='instance')
-        p.add_argument('--use_dropout', action='store_true')
-        p.add_argument('--max_gnorm', type=float, default=500.)
-        p.add_argument('--stoch_enc', action='store_true')
-        p.add_argument('--z_gan', type=int, default=1, choices=[0, 1])
-        p.add_argument('--enc_A_B', type=int, default=1, choices=[0, 1])
-        p.add_argument('--no_lsgan', action='store_true')
-        p.add_argument('--lambda_A', type=float, default=1.0)
-        p.add_argument('--lambda_B', type=float, default=1.0)
-        p.add_argument('--lambda_z_B', type=float, default=0.025)
-        # monitoring
-        p.add_argument('--monitor_gnorm', type=bool, default=True)   # type=bool as in options.py:77 (any string is True)
-        p.add_argument('--display_freq', type=int, default=5000)
-        p.add_argument('--print_freq', type=int, default=100)
-        p.add_argument('--save_epoch_freq', type=int, default=5)
-        p.add_argument('--num_multi', type=int, default=10)
-        p.add_argument('--eval_A_freq', type=int, default=1)
-        p.add_argument('--eval_B_freq', type=int, default=1)
-        # additions
-        p.add_argument('--n_blocks', type=int, default=3, help='residual blocks per generator (the reference builds 3)')
-        p.add_argument('--precision', type=str, default='f32', choices=['f32', 'bf16'], help='conv arithmetic')
-        p.add_argument('--synthetic', type=int, default=0, help='use N synthetic U(-1,1) samples per split instead of --dataroot')
-        p.add_argument('--sync_bn', action='store_true', help='data parallel: BatchNorm (E_B, D_z_B) statistics across all ranks')
-        p.add_argument('--eval_steps', type=int, default=50, help='variational-bound steps per epoch (train.py:285 uses 50)')
+        self.parser.add_argument("--name", type=str, required=True, help="name of the experiment")
+        for name, kind, default, text in _T:
+            if kind == "flag":
+                self.parser.add_argument("--" + name, action="store_true", help=text)
+            elif isinstance(kind, tuple):
+                self.parser.add_argument("--" + name, type=kind[1], choices=kind[2], default=default, help=text)
+            else:
+                self.parser.add_argument("--" + name, type=kind, default=default, help=text)
         self.initialized = True
 
     def parse(self, sub_dirs=None, argv=None):
         if not self.initialized:
             self.initialize()
-        self.opt = self.parser.parse_args(argv)
-        if self.opt.dataroot is None and not self.opt.synthetic:
-            self.parser.error('--dataroot is required (or --synthetic N)')
-        ids = [int(s) for s in self.opt.gpu_ids.split(',')]
-        self.opt.gpu_ids = [i for i in ids if i >= 0]                       # options.py:92-97
-        if len(self.opt.gpu_ids) > 0 and torch.cuda.is_available():
-            local = int(os.environ.get('LOCAL_RANK', self.opt.gpu_ids[0]))
+        opt = self.opt = self.parser.parse_args(argv)
+        if opt.dataroot is None and not opt.synthetic:
+            self.parser.error("--dataroot is required (or --synthetic N)")
+        opt.gpu_ids = [i for i in (int(tok) for tok in opt.gpu_ids.split(",")) if i >= 0]      # options.py:92-97
+        if opt.gpu_ids and torch.cuda.is_available():
+            local = int(os.environ.get("LOCAL_RANK", opt.gpu_ids[0]))
             torch.cuda.set_device(local)
-            self.opt.gpu_ids = [local]
-        expr_dir = os.path.join(self.opt.checkpoints_dir, self.opt.name)
-        self.opt.expr_dir = expr_dir
-        args = vars(self.opt)
-        lines = ['------------ Options -------------'] + ['%s: %s' % (str(k), str(v)) for k, v in sorted(args.items())] + \
-                ['-------------- End ----------------']
-        print('\n'.join(lines))
-        os.makedirs(expr_dir, exist_ok=True)
-        with open(os.path.join(expr_dir, 'opt.txt'), 'wt') as f:          # options.py:119-124
-            f.write('\n'.join(lines) + '\n')
-        with open(os.path.join(expr_dir, 'opt.pkl'), 'wb') as f:          # options.py:126-128
+            opt.gpu_ids = [local]
+        opt.expr_dir = os.path.join(opt.checkpoints_dir, opt.name)
+        os.makedirs(opt.expr_dir, exist_ok=True)
+        args = vars(opt)
+        banner = ["------------ Options -------------"]
+        banner += ["%s: %s" % (str(k), str(args[k])) for k in sorted(args)]
+        banner += ["-------------- End ----------------"]
+        print("\n".join(banner))
+        with open(os.path.join(opt.expr_dir, "opt.txt"), "wt") as f:                          # options.py:119-124
+            f.write("\n".join(banner) + "\n")
+        with open(os.path.join(opt.expr_dir, "opt.pkl"), "wb") as f:                          # options.py:126-128
             pickle.dump(args, f)
         if sub_dirs is not None:
-            create_sub_dirs(self.opt, sub_dirs)
-        return self.opt
+            create_sub_dirs(opt, sub_dirs)
+        return opt
 
 
 class TestOptions(object):

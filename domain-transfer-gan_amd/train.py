@@ -95,155 +95,176 @@ def visualize_multi(opt, real_A, model, eidx, uidx):
     copyfile(save_path, os.path.join(opt.vis_latest, 'multi.png'))
 
 
-def _to_dev(batch, use_gpu):
-    a, b = batch['A'], batch['B']
-    return (a.cuda(), b.cuda()) if use_gpu else (a, b)
+def _cuda(t, on):
+    return t.cuda() if on else t
 
 
-def _shard(t, rank, ws):
-    n = t.size(0) // ws
-    return t[rank * n:(rank + 1) * n] if ws > 1 else t
+class Trainer(object):
+    """One training run: data -> model -> epochs of train_instance (+ optional paired step) -> per-epoch checkpoint,
+    evaluation, best-model tracking and LR decay.  Rank 0 owns all files; every rank trains on its shard of each batch."""
 
+    BEST = ('best_dev_mse_A', 'best_test_mse_A', 'best_dev_bpp_B', 'best_test_bpp_B')
 
-def train_model(argv=None):
-    opt = TrainOptions().parse(sub_dirs=['vis_multi', 'vis_cycle', 'vis_latest', 'train_vis_cycle'], argv=argv)
-    rank, ws = D.init_from_env()
-    out_f = open("%s/results.txt" % opt.expr_dir, 'a' if opt.continue_train else 'w') if rank == 0 else None
-    use_gpu = len(opt.gpu_ids) > 0
-    ops.set_precision(opt.precision)
-    if opt.seed is not None:
-        print("using random seed:", opt.seed)
-        random.seed(opt.seed); np.random.seed(opt.seed); torch.manual_seed(opt.seed)      # train.py:102-108
-        if use_gpu:
-            torch.cuda.manual_seed_all(opt.seed)
+    def __init__(self, argv=None):
+        self.opt = opt = TrainOptions().parse(sub_dirs=['vis_multi', 'vis_cycle', 'vis_latest', 'train_vis_cycle'], argv=argv)
+        self.rank, self.ws = D.init_from_env()
+        self.gpu = len(opt.gpu_ids) > 0
+        self.log_f = open("%s/results.txt" % opt.expr_dir, 'a' if opt.continue_train else 'w') if self.rank == 0 else None
+        ops.set_precision(opt.precision)
+        if opt.seed is not None:                                                         # train.py:102-108
+            print("using random seed:", opt.seed)
+            random.seed(opt.seed); np.random.seed(opt.seed); torch.manual_seed(opt.seed)
+            if self.gpu:
+                torch.cuda.manual_seed_all(opt.seed)
+        self._data()
+        self._model()
+        self.total_steps = 0
+        self.results = {k: sys.float_info.max for k in self.BEST}
+        self.history_mse_A, self.history_ubo_B = [], []
+        if self.rank == 0:
+            save_results(opt.expr_dir, self.results)
+        create_sub_dirs(opt, ['vis_pred_B'])
 
-    if opt.synthetic:
-        trainA, trainB, devA, devB, testA, testB = synthetic_data(opt.synthetic, opt.input_nc, opt.output_nc, opt.grid_size,
-                                                                  opt.seed or 0)
-    else:
-        trainA, trainB, devA, devB, testA, testB = load_numpy_data(opt.dataroot, grid_size=opt.grid_size)
-    train_dataset = UnalignedIterator(trainA, trainB, batch_size=opt.batchSize)
-    print_log(out_f, '#training images = %d' % len(train_dataset))
-    test_dataset = AlignedIterator(testA, testB, batch_size=100)
-    print_log(out_f, '#test images = %d' % len(test_dataset))
-    dev_dataset = AlignedIterator(devA, devB, batch_size=100)
-    print_log(out_f, '#dev images = %d' % len(dev_dataset))
-    dev_cycle = itertools.cycle(AlignedIterator(devA, devB, batch_size=25))
-    if opt.supervised:
-        sup_size = int(len(trainA) * opt.sup_frac)
-        sup_train_dataset = itertools.cycle(AlignedIterator(trainA[:sup_size], trainB[:sup_size], batch_size=opt.batchSize))
-        print_log(out_f, '#supervised images = %d' % sup_size)
+    def log(self, msg):
+        print_log(self.log_f, msg)
 
-    vis_inf = False
-    if opt.model == 'stoch_cycle_gan':
-        model = StochCycleGAN(opt)
-    elif opt.model == 'cycle_gan':
-        model = StochCycleGAN(opt, ignore_noise=True)
-    elif opt.model == 'aug_cycle_gan':
-        model = AugmentedCycleGAN(opt)
-        create_sub_dirs(opt, ['vis_inf'])
-        vis_inf = True
-    else:
-        raise NotImplementedError('Specified model is not implemented.')
-    print_log(out_f, "model [%s] was created" % (model.__class__.__name__))
-    if opt.continue_train:
-        chk = os.path.join(opt.expr_dir, opt.which_epoch)
-        model.load(chk)
-        print_log(out_f, "continue_train: loaded %s" % chk)
+    # ---------------------------------------------------------------- setup
+    def _data(self):
+        o = self.opt
+        if o.synthetic:
+            arrays = synthetic_data(o.synthetic, o.input_nc, o.output_nc, o.grid_size, o.seed or 0)
+        else:
+            arrays = load_numpy_data(o.dataroot, grid_size=o.grid_size)
+        trainA, trainB, devA, devB, testA, testB = arrays
+        self.train_it = UnalignedIterator(trainA, trainB, batch_size=o.batchSize)
+        self.test_it = AlignedIterator(testA, testB, batch_size=100)
+        self.dev_it = AlignedIterator(devA, devB, batch_size=100)
+        self.dev_cycle = itertools.cycle(AlignedIterator(devA, devB, batch_size=25))
+        for label, it in (('training', self.train_it), ('test', self.test_it), ('dev', self.dev_it)):
+            self.log('#%s images = %d' % (label, len(it)))
+        self.sup_it = None
+        if o.supervised:
+            n_sup = int(len(trainA) * o.sup_frac)
+            self.sup_it = itertools.cycle(AlignedIterator(trainA[:n_sup], trainB[:n_sup], batch_size=o.batchSize))
+            self.log('#supervised images = %d' % n_sup)
 
-    total_steps = 0
-    print_start_time = time.time()
-    results = {k: sys.float_info.max for k in ('best_dev_mse_A', 'best_test_mse_A', 'best_dev_bpp_B', 'best_test_bpp_B')}
-    if rank == 0:
-        save_results(opt.expr_dir, results)
-    history_mse_A, history_ubo_B = [], []
-    create_sub_dirs(opt, ['vis_pred_B'])
+    def _model(self):
+        o = self.opt
+        if o.model == 'aug_cycle_gan':
+            self.model = AugmentedCycleGAN(o)
+            create_sub_dirs(o, ['vis_inf'])
+        elif o.model in ('stoch_cycle_gan', 'cycle_gan'):
+            self.model = StochCycleGAN(o, ignore_noise=(o.model == 'cycle_gan'))
+        else:
+            raise NotImplementedError('Specified model is not implemented.')
+        self.log("model [%s] was created" % self.model.__class__.__name__)
+        if o.continue_train:
+            chk = os.path.join(o.expr_dir, o.which_epoch)
+            self.model.load(chk)
+            self.log("continue_train: loaded %s" % chk)
 
-    for epoch in range(opt.epoch_count, opt.niter + opt.niter_decay + 1):
-        epoch_start_time = time.time()
-        epoch_iter = 0
-        for i, data in enumerate(train_dataset):
+    # ---------------------------------------------------------------- one epoch
+    def _shard(self, t):
+        if self.ws == 1:
+            return t
+        n = t.size(0) // self.ws
+        return t[self.rank * n:(self.rank + 1) * n]
+
+    def _visualize(self, real_A, visuals, epoch, it):
+        o, m = self.opt, self.model
+        visualize_cycle(o, real_A, visuals, epoch, it, train=True)
+        batch = next(self.dev_cycle)
+        dA, dB = _cuda(batch['A'], self.gpu), _cuda(batch['B'], self.gpu)
+        dz = dA.new_empty((dA.size(0), o.nlatent, 1, 1)).normal_(0, 1)
+        with torch.no_grad():
+            visualize_cycle(o, dA, m.generate_cycle(dA, dB, dz), epoch, it, train=False)
+        visualize_multi(o, dA, m, epoch, it)
+
+    def train_epoch(self, epoch):
+        o, m = self.opt, self.model
+        seen = 0
+        for data in self.train_it:
             real_A, real_B = data['A'], data['B']
             if real_A.size(0) != real_B.size(0):
                 continue
-            prior_z_B = real_A.new_empty((real_A.size(0), opt.nlatent, 1, 1)).normal_(0, 1)      # train.py:193
-            total_steps += opt.batchSize
-            epoch_iter += opt.batchSize
-            real_A, real_B, prior_z_B = _shard(real_A, rank, ws), _shard(real_B, rank, ws), _shard(prior_z_B, rank, ws)
-            if use_gpu:
-                real_A, real_B, prior_z_B = real_A.cuda(), real_B.cuda(), prior_z_B.cuda()
-            out = model.train_instance(real_A, real_B, prior_z_B)
-            losses, visuals = out[0], out[1]
-            gnorms = out[2] if opt.monitor_gnorm else None
-            if opt.supervised:
-                sd = next(sup_train_dataset)
-                sA, sB = _to_dev({'A': _shard(sd['A'], rank, ws), 'B': _shard(sd['B'], rank, ws)}, use_gpu)
-                sup_losses = model.supervised_train_instance(sA, sB, prior_z_B[:sA.size(0)])
+            prior_z_B = real_A.new_empty((real_A.size(0), o.nlatent, 1, 1)).normal_(0, 1)  # train.py:193
+            self.total_steps += o.batchSize
+            seen += o.batchSize
+            real_A, real_B, prior_z_B = (_cuda(self._shard(t), self.gpu) for t in (real_A, real_B, prior_z_B))
+            out = m.train_instance(real_A, real_B, prior_z_B)
+            sup_losses = None
+            if self.sup_it is not None:
+                sd = next(self.sup_it)
+                sA, sB = _cuda(self._shard(sd['A']), self.gpu), _cuda(self._shard(sd['B']), self.gpu)
+                sup_losses = m.supervised_train_instance(sA, sB, prior_z_B[:sA.size(0)])
+            if self.total_steps % o.display_freq == 0 and self.rank == 0:
+                self._visualize(real_A, out[1], epoch, seen // o.batchSize)
+            if self.total_steps % o.print_freq == 0:
+                t = (time.time() - self.tick) / o.batchSize                            # seconds per image, train.py:243
+                self.log(format_log(epoch, seen, out[0], t))
+                if sup_losses is not None:
+                    self.log(format_log(epoch, seen, sup_losses, t, prefix=False))
+                if o.monitor_gnorm:
+                    self.log(format_log(epoch, seen, out[2], t, prefix=False) + "\n")
+                self.tick = time.time()
 
-            if total_steps % opt.display_freq == 0 and rank == 0:
-                visualize_cycle(opt, real_A, visuals, epoch, epoch_iter // opt.batchSize, train=True)
-                dA, dB = _to_dev(next(dev_cycle), use_gpu)
-                dz = dA.new_empty((dA.size(0), opt.nlatent, 1, 1)).normal_(0, 1)
-                with torch.no_grad():
-                    dev_visuals = model.generate_cycle(dA, dB, dz)
-                visualize_cycle(opt, dA, dev_visuals, epoch, epoch_iter // opt.batchSize, train=False)
-                visualize_multi(opt, dA, model, epoch, epoch_iter // opt.batchSize)
+    # ---------------------------------------------------------------- per-epoch evaluation (rank 0)
+    def _track_best(self, epoch, line, dev, test, dev_key, test_key, chk, fname, banner):
+        o = self.opt
+        lines = [line]
+        if dev < self.results[dev_key]:
+            with open(os.path.join(o.expr_dir, fname), 'w') as f:
+                f.write(line + '\n')
+            self.results[dev_key], self.results[test_key] = dev, test
+            self.model.save(chk)
+            save_results(o.expr_dir, self.results)
+            lines.append(banner)
+        self.log("\n".join(["-" * 60] + lines + ["-" * 60]))
 
-            if total_steps % opt.print_freq == 0:
-                t = (time.time() - print_start_time) / opt.batchSize
-                print_log(out_f, format_log(epoch, epoch_iter, losses, t))
-                if opt.supervised:
-                    print_log(out_f, format_log(epoch, epoch_iter, sup_losses, t, prefix=False))
-                if opt.monitor_gnorm:
-                    print_log(out_f, format_log(epoch, epoch_iter, gnorms, t, prefix=False) + "\n")
-                print_start_time = time.time()
+    def evaluate(self, epoch):
+        o, m = self.opt, self.model
+        if epoch % o.eval_A_freq == 0:
+            t0 = time.time()
+            dev, test = eval_mse_A(self.dev_it, m, self.gpu), eval_mse_A(self.test_it, m, self.gpu)
+            self.history_mse_A.append((dev, test))
+            np.save("%s/history_mse_A" % o.expr_dir, self.history_mse_A)
+            line = "[%d] DEV_MSE_A: %.4f, TEST_MSE_A: %.4f, TIME: %.4f" % (epoch, dev, test, time.time() - t0)
+            self._track_best(epoch, line, dev, test, 'best_dev_mse_A', 'best_test_mse_A', 'best_A', 'best_mse_A.txt',
+                             "*** BEST DEV A ***")
+        if epoch % o.eval_B_freq == 0:
+            t0 = time.time()
+            steps = 1 if o.model == 'cycle_gan' else o.eval_steps                      # train.py:281-285
+            d_ubo, d_bpp, d_kld = eval_ubo_B(self.dev_it, m, steps, self.gpu)
+            t_ubo, t_bpp, t_kld = eval_ubo_B(self.test_it, m, steps, self.gpu)
+            self.history_ubo_B.append((d_ubo, d_bpp, d_kld, t_ubo, t_bpp, t_kld))
+            np.save("%s/history_ubo_B" % o.expr_dir, self.history_ubo_B)
+            line = "[%d] DEV_BPP_B: %.4f, TEST_BPP_B: %.4f, TIME: %.4f" % (epoch, d_bpp, t_bpp, time.time() - t0)
+            self._track_best(epoch, line, d_bpp, t_bpp, 'best_dev_bpp_B', 'best_test_bpp_B', 'best_B', 'best_bpp_B.txt',
+                             "*** BEST BPP B ***")
 
-        if epoch % opt.save_epoch_freq == 0 and rank == 0:
-            print_log(out_f, 'saving the model at the end of epoch %d, iters %d' % (epoch, total_steps))
-            model.save('latest')
+    def run(self):
+        o = self.opt
+        self.tick = time.time()
+        last = o.niter + o.niter_decay
+        for epoch in range(o.epoch_count, last + 1):
+            t0 = time.time()
+            self.train_epoch(epoch)
+            if self.rank == 0:
+                if epoch % o.save_epoch_freq == 0:
+                    self.log('saving the model at the end of epoch %d, iters %d' % (epoch, self.total_steps))
+                    self.model.save('latest')
+                self.evaluate(epoch)
+            self.log('End of epoch %d / %d \t Time Taken: %d sec' % (epoch, last, time.time() - t0))
+            if epoch > o.niter:
+                self.model.update_learning_rate()
+        if self.log_f is not None:
+            self.log_f.close()
+        return self.model
 
-        if epoch % opt.eval_A_freq == 0 and rank == 0:
-            t = time.time()
-            dev_mse_A = eval_mse_A(dev_dataset, model, use_gpu)
-            test_mse_A = eval_mse_A(test_dataset, model, use_gpu)
-            t = time.time() - t
-            history_mse_A.append((dev_mse_A, test_mse_A))
-            np.save("%s/history_mse_A" % opt.expr_dir, history_mse_A)
-            res = ["[%d] DEV_MSE_A: %.4f, TEST_MSE_A: %.4f, TIME: %.4f" % (epoch, dev_mse_A, test_mse_A, t)]
-            if dev_mse_A < results['best_dev_mse_A']:
-                with open("%s/best_mse_A.txt" % opt.expr_dir, 'w') as f:
-                    f.write(res[0] + '\n')
-                results['best_dev_mse_A'], results['best_test_mse_A'] = dev_mse_A, test_mse_A
-                model.save('best_A')
-                save_results(opt.expr_dir, results)
-                res += ["*** BEST DEV A ***"]
-            print_log(out_f, "\n".join(["-" * 60] + res + ["-" * 60]))
 
-        if epoch % opt.eval_B_freq == 0 and rank == 0:
-            t = time.time()
-            steps = 1 if opt.model == 'cycle_gan' else opt.eval_steps
-            dev_ubo_B, dev_bpp_B, dev_kld_B = eval_ubo_B(dev_dataset, model, steps, use_gpu)
-            test_ubo_B, test_bpp_B, test_kld_B = eval_ubo_B(test_dataset, model, steps, use_gpu)
-            t = time.time() - t
-            history_ubo_B.append((dev_ubo_B, dev_bpp_B, dev_kld_B, test_ubo_B, test_bpp_B, test_kld_B))
-            np.save("%s/history_ubo_B" % opt.expr_dir, history_ubo_B)
-            res = ["[%d] DEV_BPP_B: %.4f, TEST_BPP_B: %.4f, TIME: %.4f" % (epoch, dev_bpp_B, test_bpp_B, t)]
-            if dev_bpp_B < results['best_dev_bpp_B']:
-                with open("%s/best_bpp_B.txt" % opt.expr_dir, 'w') as f:
-                    f.write(res[0] + '\n')
-                results['best_dev_bpp_B'], results['best_test_bpp_B'] = dev_bpp_B, test_bpp_B
-                save_results(opt.expr_dir, results)
-                model.save('best_B')
-                res += ["*** BEST BPP B ***"]
-            print_log(out_f, "\n".join(["-" * 60] + res + ["-" * 60]))
-
-        print_log(out_f, 'End of epoch %d / %d \t Time Taken: %d sec' % (epoch, opt.niter + opt.niter_decay,
-                                                                        time.time() - epoch_start_time))
-        if epoch > opt.niter:
-            model.update_learning_rate()
-    if out_f is not None:
-        out_f.close()
-    return model
+def train_model(argv=None):
+    """entry point with the reference's name (train.py:96)"""
+    return Trainer(argv).run()
 
 
 if __name__ == "__main__":
