@@ -7,8 +7,12 @@
 Workload at N = 1 (BASELINE.json configs[2], the configuration the metric is quoted on): 256x256x3 synthetic
 unpaired batches, 9-resblock generators + latent encoder + latent discriminator (the full Augmented CycleGAN
 step: AugmentedCycleGAN.train_instance), 32 (A,B) pairs per GPU, weak scaling (global batch = 32 N).
-One "image" = one (A,B) pair consumed by train_instance (train.py:195).  Arithmetic: fp32 on the exact-fp32
-matrix pipe (v_mfma_f32_32x32x2_f32) — a HIGHER precision than the bf16 the config names.
+One "image" = one (A,B) pair consumed by train_instance (train.py:195).  Arithmetic (--precision): tensors, norms,
+losses and Adam are fp32 throughout; the convolution products run on the matrix cores as
+  bf16x3 (default) fp32 operands split hi + lo into bf16, three bf16 MFMAs per product, fp32 accumulate: 16-bit
+                   operand mantissas (the config names plain bf16 = 8), parity-tested at the 1e-3 bar;
+  f32              exact fp32 products on v_mfma_f32_32x32x2_f32 (strict mode, 1/16 of the bf16 MFMA rate);
+  bf16             operands rounded to bf16 (what the config names; NOT inside the parity bar, reported for reference).
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel: the 3x3 reflect-pad 128->128 resblock
 convolution forward, timed live with HIP events on its launch stream) and `cpu_baseline` (the oracle "port"
@@ -64,8 +68,8 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--blocks", type=int, default=9)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
-                    help="conv arithmetic: f32 = exact-fp32 MFMA (parity path, default); bf16 = bf16 operands, fp32 accumulate")
+    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"],
+                    help="conv arithmetic, see the module docstring")
     a = ap.parse_args()
 
     import dtgan_amd
@@ -116,22 +120,29 @@ def main():
     kern_ms = sum(ms) / max(len(ms), 1)
     flops = 2.0 * N * (S // 2) * (S // 2) * 128 * 128 * 9
     achieved = flops / (kern_ms * 1e-3) / 1e12 if ms else None
-    peak = 157.3 if a.precision == "f32" else 2500.0   # dense MFMA peaks (MI355X_MICROARCH.md)
+    # dense MFMA peaks (MI355X_MICROARCH.md): fp32 157.3, bf16 2500 TFLOP/s; bf16x3 issues 3 bf16 MFMAs per
+    # algorithmic product, so its ceiling for ALGORITHMIC flops is 2500 / 3
+    peak = {"f32": 157.3, "bf16x3": round(2500.0 / 3, 1), "bf16": 2500.0}[a.precision]
+    kname = {"f32": "igemm_conv_f32<128,128,2,2,32,REFLECT,!THIN>", "bf16x3": "igemm_conv_bf16<128,128,2,2,32,REFLECT,SPLIT>",
+             "bf16": "igemm_conv_bf16<128,128,2,2,64,REFLECT,!SPLIT>"}[a.precision]
+    dtype = {"f32": "f32", "bf16x3": "f32 tensors; conv products as 3 bf16 MFMAs on hi/lo-split fp32 operands (~2^-17 operand rounding), fp32 accumulate",
+             "bf16": "bf16 (MFMA operands; fp32 accumulate and fp32 tensors)"}[a.precision]
     traffic = None
-    tj = os.path.join(ROOT, "profiles", "r01_resblock_conv_traffic.json")
-    if os.path.exists(tj) and (N, S) == (32, 256) and a.precision == "f32":
+    # measured by tools/profile_traffic.sh + tools/summarize_traffic.py (separate --pmc passes), committed per kernel
+    tj = os.path.join(ROOT, "profiles", {"f32": "r01_c_resblock_conv_traffic_f32.json",
+                                         "bf16x3": "r01_d_resblock_conv_traffic_bf16x3.json"}.get(a.precision, "-"))
+    if os.path.exists(tj) and (N, S) == (32, 256):
         traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
     out = {
         "metric": "training images/sec, 256x256 Augmented CycleGAN step, 1/2/4/8 MI355X",
         "value": round(ws * N * a.steps / dt, 3), "unit": "images/s", "n_gpus": ws, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if a.precision == "f32" else "bf16 (MFMA operands; fp32 accumulate and fp32 tensors)", "data": "synthetic",
+        "dtype": dtype, "data": "synthetic",
         "config": {"workload": "%dx%dx3 synthetic unpaired, %d-resblock G + latent encoder (full Augmented CycleGAN "
                                "train_instance), batch=%d per GPU (global %d)" % (S, S, a.blocks, N, N * ws),
                    "parallelism": "dp%d" % ws, "loss_G_A": round(losses["G_A"], 5)},
-        "roofline": {"bound": "mfma", "kernel": ("igemm_conv_f32<128,128,2,2,32,REFLECT,!THIN>" if a.precision == "f32" else "igemm_conv_bf16<128,128,2,2,64,REFLECT>")
-                               + " (resblock 3x3 reflect 128->128 fwd)",
+        "roofline": {"bound": "mfma", "kernel": kname + " (resblock 3x3 reflect 128->128 fwd)",
                      "achieved": None if achieved is None else round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": None if achieved is None else round(achieved / peak, 4), "traffic": traffic,
                      "launches_timed": len(ms), "avg_launch_ms": round(kern_ms, 4), "flops_per_launch": flops},

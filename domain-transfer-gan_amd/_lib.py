@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libacgan_hip.so")
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 IMPL_MFMA, IMPL_DIRECT = 0, 1
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 
 c_int, c_float, c_size_t, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
 

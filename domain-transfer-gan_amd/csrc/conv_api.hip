@@ -4,14 +4,15 @@
 #include "conv_internal.h"
 
 int g_acg_conv_impl = ACG_IMPL_MFMA;
-int g_acg_precision = ACG_PREC_F32;
+int g_acg_precision = ACG_PREC_BF16X3;
 extern "C" int acg_set_conv_precision(int prec)
 {
-    ACG_REQUIRE(prec == ACG_PREC_F32 || prec == ACG_PREC_BF16, "acg_set_conv_precision: unknown precision %d", prec);
+    ACG_REQUIRE(prec == ACG_PREC_F32 || prec == ACG_PREC_BF16 || prec == ACG_PREC_BF16X3, "acg_set_conv_precision: unknown precision %d", prec);
     g_acg_precision = prec;
     return ACG_OK;
 }
-static bool use_bf16() { return g_acg_precision == ACG_PREC_BF16 && g_acg_conv_impl == ACG_IMPL_MFMA; }
+// packed weights are bf16 (hi, and for BF16X3 also lo right behind it) whenever the bf16 matrix pipe is used
+static bool use_bf16() { return g_acg_precision != ACG_PREC_F32 && g_acg_conv_impl == ACG_IMPL_MFMA; }
 // thin-channel K-flattening (fp32 MFMA kernels): the gathered tensor has <= 4 real channels and K > 1
 // (thin layers use the fp32 thin kernels in BOTH precision modes: they beat the padded bf16 path)
 static bool thin_ok(int creal, int K) { return creal >= 1 && creal <= 4 && K > 1 && g_acg_conv_impl == ACG_IMPL_MFMA; }
@@ -62,8 +63,9 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, int Or, int Ir, 
 }
 
 // bf16 packing: wf16 [tap][Ci/16][CoP][16], wb16 [tap][Co/16][CiP][16] (same element counts, half the bytes)
+// split != 0: also write lo = bf16(w - float(hi)) at [n_elems ...) of each buffer (the buffers are sized in floats)
 __global__ void pack_weight_bf16_kernel(const float *__restrict__ w, int Or, int Ir, int K, int Ci, int Co, int CoP,
-                                        int CiP, __bf16 *__restrict__ wf, __bf16 *__restrict__ wb)
+                                        int CiP, __bf16 *__restrict__ wf, __bf16 *__restrict__ wb, int split)
 {
     const int KK = K * K;
     const long long nf = (long long)KK * (Ci / 16) * CoP * 16;
@@ -78,7 +80,10 @@ __global__ void pack_weight_bf16_kernel(const float *__restrict__ w, int Or, int
             const int cb = (int)(r % (Ci / 16)); r /= (Ci / 16);
             const int tap = (int)r;
             const int ci = cb * 16 + c16;
-            wf[i] = (__bf16)((co < Or && ci < Ir) ? w[((long long)co * Ir + ci) * KK + tap] : 0.f);
+            const float v = (co < Or && ci < Ir) ? w[((long long)co * Ir + ci) * KK + tap] : 0.f;
+            const __bf16 hi = (__bf16)v;
+            wf[i] = hi;
+            if (split) wf[nf + i] = (__bf16)(v - (float)hi);
         } else {
             if (wb == nullptr) continue;
             long long r = i - nf;
@@ -87,7 +92,10 @@ __global__ void pack_weight_bf16_kernel(const float *__restrict__ w, int Or, int
             const int cb = (int)(r % (Co / 16)); r /= (Co / 16);
             const int tap = (int)r;
             const int co = cb * 16 + c16;
-            wb[i - nf] = (__bf16)((co < Or && ci < Ir) ? w[((long long)co * Ir + ci) * KK + tap] : 0.f);
+            const float v = (co < Or && ci < Ir) ? w[((long long)co * Ir + ci) * KK + tap] : 0.f;
+            const __bf16 hi = (__bf16)v;
+            wb[i - nf] = hi;
+            if (split) wb[nb + i - nf] = (__bf16)(v - (float)hi);
         }
     }
 }
@@ -257,7 +265,7 @@ extern "C" int acg_pack_conv_weight(const float *w, int Or, int Ir, int K, int C
         auto regular = [&](float *of, float *ob) {
             if (use_bf16())
                 hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(blocks), dim3(256), 0, st, w, Or, Ir, K, Ci, Co, acg_ncols_pad(Co),
-                                   acg_ncols_pad(Ci), (__bf16 *)of, (__bf16 *)ob);
+                                   acg_ncols_pad(Ci), (__bf16 *)of, (__bf16 *)ob, (int)(g_acg_precision == ACG_PREC_BF16X3));
             else
                 hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, st, w, Or, Ir, K, Ci, Co, acg_ncols_pad(Co),
                                    acg_ncols_pad(Ci), of, ob);
@@ -276,7 +284,8 @@ extern "C" int acg_pack_conv_weight(const float *w, int Or, int Ir, int K, int C
     }
     if (use_bf16())
         hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Or, Ir, K, Ci, Co,
-                           acg_ncols_pad(Co), acg_ncols_pad(Ci), (__bf16 *)wf, (__bf16 *)wb);
+                           acg_ncols_pad(Co), acg_ncols_pad(Ci), (__bf16 *)wf, (__bf16 *)wb,
+                           (int)(g_acg_precision == ACG_PREC_BF16X3));
     else
         hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Or, Ir, K, Ci, Co,
                            acg_ncols_pad(Co), acg_ncols_pad(Ci), wf, wb);
@@ -560,6 +569,7 @@ static void fwd_geom(const acg_conv_desc *d, Geom *g, Taps *t, int act)
     g->reflect = d->pad_mode == ACG_PAD_REFLECT; g->act = act; g->ncols_pad = acg_ncols_pad(d->Co);
     g->Mtot = (long long)d->N * d->Ho * d->Wo;
     g->thin = thin_in(d) ? 1 : 0;
+    g->w_elems = (long long)acg_packed_wf_elems(d->K, d->Ci, d->Co);
     t->n = 0;
     for (int kh = 0; kh < d->K; ++kh)
         for (int kw = 0; kw < d->K; ++kw) {
@@ -577,6 +587,7 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
     g.Hin = d->Ho; g.Win = d->Wo; g.Cin = d->Co;
     g.Cout = d->Ci; g.reflect = 0; g.act = act; g.ncols_pad = acg_ncols_pad(d->Ci); g.is = 1;
     g.thin = (d->stride == 1 && thin_out(d)) ? 1 : 0;
+    g.w_elems = (long long)acg_packed_wb_elems(d->K, d->Ci, d->Co);
     const int p = d->pad, K = d->K;
     if (d->stride == 1) {
         const bool refl = d->pad_mode == ACG_PAD_REFLECT && p > 0;

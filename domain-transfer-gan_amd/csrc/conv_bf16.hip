@@ -16,10 +16,13 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int BM, int BN, int WM, int WN, int KC, bool REFLECT>
+// SPLIT: operands as bf16 hi + lo, products hi*hi + hi*lo + lo*hi (fp32-grade: ~2^-16 per product).  The lo images
+// live behind the hi images in LDS; packed weights carry their lo part at +w_lo_off elements.
+template <int BM, int BN, int WM, int WN, int KC, bool REFLECT, bool SPLIT>
 __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__ in, const __bf16 *__restrict__ wp,
                                                        const float *__restrict__ bias, float *__restrict__ out,
-                                                       Geom g, Taps taps, unsigned in_bytes, unsigned w_bytes)
+                                                       Geom g, Taps taps, unsigned in_bytes, unsigned w_bytes,
+                                                       unsigned w_lo_bytes)
 {
     constexpr int TM = BM / WM, TN = BN / WN, MB = TM / 32, NB = TN / 32;
     constexpr int NKC = KC / 16;             // 16-wide k-chunks per stage
@@ -31,8 +34,9 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
     constexpr int AKS = BM * 16 + 16, BKS = BN * 16 + 16; // k-chunk strides (bf16 elements), +32 B pad
     static_assert(WM * WN == 4 && AL >= 1 && MB >= 1 && NB >= 1, "tile config");
 
-    __shared__ __attribute__((aligned(16))) __bf16 As[NKC * AKS];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[NKC * BKS];
+    constexpr int NIMG = SPLIT ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) __bf16 As[NIMG * NKC * AKS];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[NIMG * NKC * BKS];
     __shared__ long long out_off[BM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
 
     const int S = taps.n * (g.Cin / KC);
     f32x8 ra[AL];
-    u32x4 rb[BL]; // 8 bf16 each
+    u32x4 rb[BL], rbl[BL]; // 8 bf16 each (hi, lo)
 
     auto load_stage = [&](int s) {
         const int cc = s / taps.n;
@@ -127,34 +131,56 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
         const unsigned soff = (unsigned)(((tw * (g.Cin >> 4) + (c0 >> 4)) * g.ncols_pad) * 16) * 2u;
 #pragma unroll
         for (int i = 0; i < BL; ++i)
-            if (tid + 256 * i < BCH) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[i], soff, 0);
+            if (tid + 256 * i < BCH) {
+                rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[i], soff, 0);
+                if (SPLIT) rbl[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[i], soff + w_lo_bytes, 0);
+            }
     };
 
     load_stage(0);
     for (int s = 0; s < S; ++s) {
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < AL; ++j)
-            *(bf16x8 *)&As[(u >> 1) * AKS + (rrow + RPP * j) * 16 + (u & 1) * 8] = __builtin_convertvector(ra[j], bf16x8);
+        for (int j = 0; j < AL; ++j) {
+            const int a_at = (u >> 1) * AKS + (rrow + RPP * j) * 16 + (u & 1) * 8;
+            const bf16x8 hi = __builtin_convertvector(ra[j], bf16x8);
+            *(bf16x8 *)&As[a_at] = hi;
+            if (SPLIT) // residual of the RNE rounding, itself rounded to bf16: x = hi + lo + O(2^-17 |x|)
+                *(bf16x8 *)&As[NKC * AKS + a_at] = __builtin_convertvector(ra[j] - __builtin_convertvector(hi, f32x8), bf16x8);
+        }
 #pragma unroll
         for (int i = 0; i < BL; ++i)
-            if (tid + 256 * i < BCH) *(u32x4 *)&Bs[b_lds[i]] = rb[i];
+            if (tid + 256 * i < BCH) {
+                *(u32x4 *)&Bs[b_lds[i]] = rb[i];
+                if (SPLIT) *(u32x4 *)&Bs[NKC * BKS + b_lds[i]] = rbl[i];
+            }
         __syncthreads();
         if (s + 1 < S) load_stage(s + 1);
 #pragma unroll
         for (int kc = 0; kc < NKC; ++kc) {
-            bf16x8 a[MB], b[NB];
+            bf16x8 a[MB], b[NB], al[MB], bl[NB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const int at = kc * AKS + (wm * TM + i * 32 + (lane & 31)) * 16 + (lane >> 5) * 8;
+                a[i] = *(const bf16x8 *)&As[at];
+                if (SPLIT) al[i] = *(const bf16x8 *)&As[NKC * AKS + at];
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int bt = kc * BKS + (wn * TN + j * 32 + (lane & 31)) * 16 + (lane >> 5) * 8;
+                b[j] = *(const bf16x8 *)&Bs[bt];
+                if (SPLIT) bl[j] = *(const bf16x8 *)&Bs[NKC * BKS + bt];
+            }
 #pragma unroll
             for (int i = 0; i < MB; ++i)
-                a[i] = *(const bf16x8 *)&As[kc * AKS + (wm * TM + i * 32 + (lane & 31)) * 16 + (lane >> 5) * 8];
 #pragma unroll
-            for (int j = 0; j < NB; ++j)
-                b[j] = *(const bf16x8 *)&Bs[kc * BKS + (wn * TN + j * 32 + (lane & 31)) * 16 + (lane >> 5) * 8];
-#pragma unroll
-            for (int i = 0; i < MB; ++i)
-#pragma unroll
-                for (int j = 0; j < NB; ++j)
+                for (int j = 0; j < NB; ++j) {
+                    if (SPLIT) { // small cross terms first, the leading term last
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
         }
     }
 
@@ -175,41 +201,44 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
     }
 }
 
-template <int KC, bool REFLECT>
+template <int KC, bool REFLECT, bool SPLIT>
 static void launch_bf16_kc(int bn, dim3 grid, hipStream_t st, const float *in, const __bf16 *wp, const float *bias,
-                           float *out, const Geom &g, const Taps &t, unsigned inb, unsigned wb)
+                           float *out, const Geom &g, const Taps &t, unsigned inb, unsigned wb, unsigned wlo)
 {
     dim3 block(256);
     if (bn == 128)
-        hipLaunchKernelGGL((igemm_conv_bf16<128, 128, 2, 2, KC, REFLECT>), grid, block, 0, st, in, wp, bias, out, g, t, inb, wb);
+        hipLaunchKernelGGL((igemm_conv_bf16<128, 128, 2, 2, KC, REFLECT, SPLIT>), grid, block, 0, st, in, wp, bias, out, g, t, inb, wb, wlo);
     else if (bn == 64)
-        hipLaunchKernelGGL((igemm_conv_bf16<128, 64, 2, 2, KC, REFLECT>), grid, block, 0, st, in, wp, bias, out, g, t, inb, wb);
+        hipLaunchKernelGGL((igemm_conv_bf16<128, 64, 2, 2, KC, REFLECT, SPLIT>), grid, block, 0, st, in, wp, bias, out, g, t, inb, wb, wlo);
     else
-        hipLaunchKernelGGL((igemm_conv_bf16<128, 32, 4, 1, KC, REFLECT>), grid, block, 0, st, in, wp, bias, out, g, t, inb, wb);
+        hipLaunchKernelGGL((igemm_conv_bf16<128, 32, 4, 1, KC, REFLECT, SPLIT>), grid, block, 0, st, in, wp, bias, out, g, t, inb, wb, wlo);
 }
 
+// n_w_elems: element count of the packed weight array (hi part); the lo part of BF16X3 sits right behind it
 int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g0, const Taps &t,
-                          int bn, hipStream_t st)
+                          int bn, long long n_w_elems, hipStream_t st)
 {
     Geom g = g0;
     g.thin = 0;
     dim3 grid(acg_cdiv(g.Mtot, 128) * (g.ncols_pad / bn));
     const __bf16 *w = (const __bf16 *)wp;
+    const bool split = g_acg_precision == ACG_PREC_BF16X3;
     const long long nimg = g.Mtot / ((long long)g.GH * g.GW);
     const long long in_bytes = nimg * g.Hin * g.Win * g.Cin * 4;
-    long long nslab = 1;
-    for (int i = 0; i < t.n; ++i) nslab = t.w[i] + 1 > nslab ? t.w[i] + 1 : nslab;
-    const long long w_bytes = nslab * (g.Cin / 16) * g.ncols_pad * 16 * 2;
+    const long long w_bytes = n_w_elems * 2 * (split ? 2 : 1);
     ACG_REQUIRE(in_bytes < (1LL << 32) && w_bytes < (1LL << 32), "igemm_conv_bf16: operand exceeds the 4 GiB buffer-addressing limit");
-    const unsigned inb = (unsigned)in_bytes, wb = (unsigned)w_bytes;
-#define BF16_DISPATCH(KCV)                                                                         \
-    do {                                                                                           \
-        if (g.reflect) launch_bf16_kc<KCV, true>(bn, grid, st, in, w, bias, out, g, t, inb, wb);   \
-        else launch_bf16_kc<KCV, false>(bn, grid, st, in, w, bias, out, g, t, inb, wb);            \
+    const unsigned inb = (unsigned)in_bytes, wb = (unsigned)w_bytes, wlo = (unsigned)(n_w_elems * 2);
+#define BF16_DISPATCH(KCV, SP)                                                                              \
+    do {                                                                                                    \
+        if (g.reflect) launch_bf16_kc<KCV, true, SP>(bn, grid, st, in, w, bias, out, g, t, inb, wb, wlo);   \
+        else launch_bf16_kc<KCV, false, SP>(bn, grid, st, in, w, bias, out, g, t, inb, wb, wlo);            \
     } while (0)
-    if (g.Cin % 64 == 0) BF16_DISPATCH(64);
-    else if (g.Cin % 32 == 0) BF16_DISPATCH(32);
-    else BF16_DISPATCH(16);
+    if (split) { // hi+lo images double the LDS: 32-channel stages keep 3-4 blocks per CU
+        if (g.Cin % 32 == 0) BF16_DISPATCH(32, true);
+        else BF16_DISPATCH(16, true);
+    } else if (g.Cin % 64 == 0) BF16_DISPATCH(64, false);
+    else if (g.Cin % 32 == 0) BF16_DISPATCH(32, false);
+    else BF16_DISPATCH(16, false);
 #undef BF16_DISPATCH
     ACG_CHECK_LAUNCH("igemm_conv_bf16");
     return ACG_OK;
@@ -222,7 +251,8 @@ int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, fl
 // whole 512-B pixel rows across the wave) and writes four 16-byte [channel][8 pixels] fragments.
 // LDS images: Xs[ci][KP + 8], Ds[co][KP + 8] (bf16; +16 B row pad -> conflict-free ds_read_b128).
 // ------------------------------------------------------------------------------------------------
-template <int BCI, int BCO, int WI, int WJ, int WK, int KP>
+// SPLIT: both operands as bf16 hi + lo (lo images behind the hi images), x_lo*d_hi + x_hi*d_lo + x_hi*d_hi.
+template <int BCI, int BCO, int WI, int WJ, int WK, int KP, bool SPLIT>
 __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, const float *__restrict__ dy,
                                                   float *__restrict__ part, WGeom g, Taps taps, unsigned x_bytes,
                                                   unsigned d_bytes)
@@ -235,8 +265,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
     constexpr int DOFF = (XU + DU <= 256) ? XU : 0;     // threads [XU, XU+DU) load the dy units when both fit
     static_assert(WI * WJ * WK == 4 && MI >= 1 && MJ >= 1 && KW % 16 == 0, "tile config");
 
-    __shared__ __attribute__((aligned(16))) __bf16 Xs[BCI * RS];
-    __shared__ __attribute__((aligned(16))) __bf16 Ds[BCO * RS];
+    constexpr int NIMG = SPLIT ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) __bf16 Xs[NIMG * BCI * RS];
+    __shared__ __attribute__((aligned(16))) __bf16 Ds[NIMG * BCO * RS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave % WK, wj = (wave / WK) % WJ, wi = wave / (WK * WJ);
@@ -337,7 +368,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
                     f32x8 v;
 #pragma unroll
                     for (int p = 0; p < 8; ++p) v[p] = rx[l][p][c];
-                    *(bf16x8 *)&Xs[(c4 * 4 + c) * RS + pg * 8] = __builtin_convertvector(v, bf16x8);
+                    const bf16x8 hi = __builtin_convertvector(v, bf16x8);
+                    *(bf16x8 *)&Xs[(c4 * 4 + c) * RS + pg * 8] = hi;
+                    if (SPLIT)
+                        *(bf16x8 *)&Xs[BCI * RS + (c4 * 4 + c) * RS + pg * 8] =
+                            __builtin_convertvector(v - __builtin_convertvector(hi, f32x8), bf16x8);
                 }
             }
         }
@@ -351,7 +386,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
                     f32x8 v;
 #pragma unroll
                     for (int p = 0; p < 8; ++p) v[p] = rd[l][p][c];
-                    *(bf16x8 *)&Ds[(c4 * 4 + c) * RS + pg * 8] = __builtin_convertvector(v, bf16x8);
+                    const bf16x8 hi = __builtin_convertvector(v, bf16x8);
+                    *(bf16x8 *)&Ds[(c4 * 4 + c) * RS + pg * 8] = hi;
+                    if (SPLIT)
+                        *(bf16x8 *)&Ds[BCO * RS + (c4 * 4 + c) * RS + pg * 8] =
+                            __builtin_convertvector(v - __builtin_convertvector(hi, f32x8), bf16x8);
                 }
             }
         }
@@ -378,16 +417,29 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
         if (k0 + KP < mend) load_stage(k0 + KP);
 #pragma unroll
         for (int kk = wk * KW; kk < (wk + 1) * KW; kk += 16) {
-            bf16x8 a[MI], bb[MJ];
+            bf16x8 a[MI], bb[MJ], al[MI], bl[MJ];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = *(const bf16x8 *)&Xs[(wi * TI + i * 32 + (lane & 31)) * RS + kk + (lane >> 5) * 8];
+            for (int i = 0; i < MI; ++i) {
+                const int at = (wi * TI + i * 32 + (lane & 31)) * RS + kk + (lane >> 5) * 8;
+                a[i] = *(const bf16x8 *)&Xs[at];
+                if (SPLIT) al[i] = *(const bf16x8 *)&Xs[BCI * RS + at];
+            }
 #pragma unroll
-            for (int j = 0; j < MJ; ++j) bb[j] = *(const bf16x8 *)&Ds[(wj * TJ + j * 32 + (lane & 31)) * RS + kk + (lane >> 5) * 8];
+            for (int j = 0; j < MJ; ++j) {
+                const int bt = (wj * TJ + j * 32 + (lane & 31)) * RS + kk + (lane >> 5) * 8;
+                bb[j] = *(const bf16x8 *)&Ds[bt];
+                if (SPLIT) bl[j] = *(const bf16x8 *)&Ds[BCO * RS + bt];
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < MJ; ++j)
+                for (int j = 0; j < MJ; ++j) {
+                    if (SPLIT) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bb[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bb[j], acc[i][j], 0, 0, 0);
+                }
         }
     }
 
@@ -455,16 +507,18 @@ int acg_wgrad_bf16_launch(const float *x, const float *dy, float *part, const WG
     const long long xbytes = nimg * g.Hin * g.Win * g.Cin * 4, dbytes = g.Mtot * g.Cg * 4;
     ACG_REQUIRE(xbytes < (1LL << 32) && dbytes < (1LL << 32), "wgrad_bf16: operand exceeds the 4 GiB buffer-addressing limit");
     const unsigned xb = (unsigned)xbytes, db = (unsigned)dbytes;
-    if (bci == 128)
-        hipLaunchKernelGGL((wgrad_bf16<128, 128, 2, 2, 1, 64>), grid, block, 0, st, x, dy, part, g, t, xb, db);
-    else if (bci == 64 && bco == 64)
-        hipLaunchKernelGGL((wgrad_bf16<64, 64, 2, 2, 1, 64>), grid, block, 0, st, x, dy, part, g, t, xb, db);
-    else if (bci == 32 && bco == 64)
-        hipLaunchKernelGGL((wgrad_bf16<32, 64, 1, 2, 2, 128>), grid, block, 0, st, x, dy, part, g, t, xb, db);
-    else if (bci == 64 && bco == 32)
-        hipLaunchKernelGGL((wgrad_bf16<64, 32, 2, 1, 2, 128>), grid, block, 0, st, x, dy, part, g, t, xb, db);
-    else
-        hipLaunchKernelGGL((wgrad_bf16<32, 32, 1, 1, 4, 256>), grid, block, 0, st, x, dy, part, g, t, xb, db);
+#define WG_BF16(BCI_, BCO_, WI_, WJ_, WK_, KP_)                                                                          \
+    do {                                                                                                                 \
+        if (split) hipLaunchKernelGGL((wgrad_bf16<BCI_, BCO_, WI_, WJ_, WK_, KP_, true>), grid, block, 0, st, x, dy, part, g, t, xb, db); \
+        else hipLaunchKernelGGL((wgrad_bf16<BCI_, BCO_, WI_, WJ_, WK_, KP_, false>), grid, block, 0, st, x, dy, part, g, t, xb, db);      \
+    } while (0)
+    const bool split = g_acg_precision == ACG_PREC_BF16X3;
+    if (bci == 128) WG_BF16(128, 128, 2, 2, 1, 64);
+    else if (bci == 64 && bco == 64) WG_BF16(64, 64, 2, 2, 1, 64);
+    else if (bci == 32 && bco == 64) WG_BF16(32, 64, 1, 2, 2, 128);
+    else if (bci == 64 && bco == 32) WG_BF16(64, 32, 2, 1, 2, 128);
+    else WG_BF16(32, 32, 1, 1, 4, 256);
+#undef WG_BF16
     ACG_CHECK_LAUNCH("wgrad_bf16");
     return ACG_OK;
 }

@@ -236,7 +236,7 @@ int acg_igemm_launch(const float *in, const float *wp, const float *bias, float 
     if (g0.Mtot <= 0 || t.n <= 0) return ACG_OK;
     Geom g = g0;
     const int bn = bn_for(g.Cout);
-    if (g_acg_precision == ACG_PREC_BF16 && g_acg_conv_impl == ACG_IMPL_MFMA && !g0.thin) return acg_igemm_bf16_launch(in, wp, bias, out, g0, t, bn, st);
+    if (g_acg_precision != ACG_PREC_F32 && g_acg_conv_impl == ACG_IMPL_MFMA && !g0.thin) return acg_igemm_bf16_launch(in, wp, bias, out, g0, t, bn, g0.w_elems, st);
     const long long nimg = g.Mtot / ((long long)g.GH * g.GW);
     const long long in_bytes = nimg * g.Hin * g.Win * g.Cin * 4;
     ACG_REQUIRE(in_bytes < (1LL << 32), "igemm_conv: gathered tensor of %lld bytes exceeds the 4 GiB buffer-addressing limit", in_bytes);

@@ -20,6 +20,7 @@ struct Geom {
     int reflect;          // 1: mirror out-of-range coordinates (ReflectionPad2d), 0: zeros
     int act;
     int ncols_pad;        // packed-weight column count (multiple of the N tile)
+    long long w_elems;    // element count of the packed weight array (bf16 modes: where the lo part starts)
     int thin;             // 1: K flattened over (tap, 4 channels): stage s = taps 8s..8s+7, channels 0..3 of each
     int bk8;              // 8-float k-chunks per packed weight slab (Cin/8; thin: 4*ceil(ntaps/8), single slab)
     long long Mtot;       // N*GH*GW
@@ -47,6 +48,6 @@ void acg_wgrad_tiles(int Ci, int Co, int *bci, int *bco);
 
 extern int g_acg_precision;
 int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g, const Taps &t,
-                          int bn, hipStream_t st);
+                          int bn, long long n_w_elems, hipStream_t st);
 int acg_wgrad_bf16_launch(const float *x, const float *dy, float *part, const WGeom &g, const Taps &t, int bci, int bco,
                           hipStream_t st);

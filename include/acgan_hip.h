@@ -39,7 +39,7 @@ typedef enum {
 typedef enum { ACG_ACT_NONE = 0, ACG_ACT_RELU = 1, ACG_ACT_LRELU = 2 /* slope 0.2 */, ACG_ACT_TANH = 3 } acg_act;
 typedef enum { ACG_PAD_ZERO = 0, ACG_PAD_REFLECT = 1 } acg_pad_mode;
 typedef enum { ACG_IMPL_MFMA = 0, ACG_IMPL_DIRECT = 1 } acg_conv_impl;
-typedef enum { ACG_PREC_F32 = 0, ACG_PREC_BF16 = 1 } acg_precision;
+typedef enum { ACG_PREC_F32 = 0, ACG_PREC_BF16 = 1, ACG_PREC_BF16X3 = 2 } acg_precision;
 
 /* Geometry of one nn.Conv2d (or of the Conv2d whose adjoint an nn.ConvTranspose2d is).
  * Ci / Co are the STORED (padded-to-16) channel counts of the NHWC tensors. */
@@ -57,9 +57,12 @@ const char *acg_last_error(void);
  * (MFMA implicit GEMM = product path; DIRECT = naive one-thread-per-output kernels kept
  * as an on-device cross-check).  Both are HIP kernels; there is no CPU path. */
 int acg_set_conv_impl(int impl);
-/* arithmetic of the MFMA convolution kernels: ACG_PREC_F32 (default; exact fp32 FMA chain on
- * v_mfma_f32_32x32x2_f32 — the parity path) or ACG_PREC_BF16 (operands rounded to bf16 in LDS, fp32
- * accumulate on v_mfma_f32_32x32x16_bf16 — throughput mode).  Tensors stay fp32 in HBM either way.
+/* arithmetic of the MFMA convolution kernels (tensors stay fp32 in HBM in every mode):
+ *  ACG_PREC_BF16X3 (default) each fp32 operand is split into bf16 hi + lo on its way into LDS and every product is
+ *                  formed as lo*hi + hi*lo + hi*hi by three v_mfma_f32_32x32x16_bf16 with fp32 accumulation: operands
+ *                  keep 16 mantissa bits (~4e-6 rms error per convolution), inside the 1e-3 parity bar, at bf16 rate;
+ *  ACG_PREC_F32    exact fp32 FMA chain on v_mfma_f32_32x32x2_f32 — the strict mode;
+ *  ACG_PREC_BF16   operands rounded to bf16, fp32 accumulate — throughput mode, NOT a parity path.
  * Packed weights must be re-packed (acg_pack_conv_weight) after a switch. */
 int acg_set_conv_precision(int prec);
 

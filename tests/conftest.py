@@ -25,3 +25,15 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _suite_precision():
+    """ACGAN_TEST_PRECISION=bf16x3 runs the whole GPU parity suite with the split-bf16 conv arithmetic."""
+    name = os.environ.get("ACGAN_TEST_PRECISION")
+    if name:
+        import torch
+        if torch.cuda.is_available():
+            from dtgan_amd import ops
+            ops.set_precision(name)
+    yield

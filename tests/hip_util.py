@@ -31,3 +31,31 @@ def load_recipe(net, net_name, seed, flavour):
     from dtgan_amd.modules import mark_dirty
     mark_dirty(net)
     return net
+
+
+def l2rel(a, b):
+    """norm-wise relative error: robust to the isolated pointwise differences a flipped ReLU mask produces"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+# Two conv arithmetic modes are parity paths (DESIGN.md "Arithmetic"):
+#   f32    — v_mfma_f32_32x32x2_f32, every product exact fp32: the tight bounds pin indexing and fusion logic;
+#   bf16x3 — fp32 operands split hi+lo into bf16, three bf16 MFMAs per product (operands carry 16 mantissa bits,
+#            ~4e-6 rms per conv measured by tools/precision_probe.py): held to the north-star bar itself,
+#            1e-3 relative on activations and losses.
+PRECISIONS = ["f32", "bf16x3"]
+
+
+class precision(object):
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        from dtgan_amd import ops
+        self.before = ops.get_precision()
+        ops.set_precision(self.name)
+
+    def __exit__(self, *a):
+        from dtgan_amd import ops
+        ops.set_precision(self.before)

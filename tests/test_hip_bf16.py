@@ -20,9 +20,10 @@ from golden_util import load  # noqa: E402
 @pytest.fixture(autouse=True)
 def bf16_mode():
     from dtgan_amd import ops
+    before = ops.get_precision()
     ops.set_precision("bf16")
     yield
-    ops.set_precision("f32")
+    ops.set_precision(before)
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "k%ds%dp%d%s_%dto%d_%dx%dx%d" % c)

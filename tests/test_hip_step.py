@@ -2,9 +2,10 @@
 (a) the golden fixtures captured from the reference itself and (b) the fp32 oracle run on this box.
 
 Bar (BASELINE.json north star): generator activations and losses within 1e-3 relative of the reference
-CPU path.  Step 0 is a pure function of the inputs and is held to 2e-4 (losses) / 1e-3 (gradient norms) /
-1e-4 (images); later steps inherit Adam's amplification of rounding noise on ~zero-gradient tensors
-(see tests/test_oracle_golden.py) and are held to 1e-2 / 6e-2 / 5e-3.
+CPU path.  Step 0 is a pure function of the inputs.  Exact-fp32 arithmetic holds it to 2e-4 (losses) / 1e-3
+(gradient norms) / 1e-4 (images); the split-bf16 arithmetic (16-bit operand mantissas, hip_util.PRECISIONS) to
+the bar itself: 1e-3 losses and images, 3e-3 gradient norms.  Later steps inherit Adam's amplification of rounding
+noise on ~zero-gradient tensors (see tests/test_oracle_golden.py): 1e-2 / 6e-2 / 5e-3, and 2e-2 / 6e-2 / 2e-2.
 """
 import argparse
 
@@ -36,8 +37,21 @@ def build_model(meta):
     return m
 
 
+STEP_TOL = {  # precision -> ((loss, gnorm, image) at step 0, the same after Adam updates)
+    "f32": ((2e-4, 1e-3, 1e-4), (1e-2, 6e-2, 5e-3)),
+    "bf16x3": ((1e-3, 3e-3, 1e-3), (2e-2, 6e-2, 2e-2)),
+}
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
 @pytest.mark.parametrize("name", names("step"))
-def test_train_instance_matches_reference_golden(name):
+def test_train_instance_matches_reference_golden(name, prec):
+    from hip_util import precision
+    with precision(prec):
+        _check_steps(name, prec)
+
+
+def _check_steps(name, prec):
     from hip_util import t, n, rel
     arr, meta = load(name)
     m = build_model(meta)
@@ -46,7 +60,7 @@ def test_train_instance_matches_reference_golden(name):
         losses, visuals, gnorms = m.train_instance(A, B, z)
         assert list(losses.keys()) == meta["loss_keys"]
         assert list(gnorms.keys()) == meta["gnorm_keys"]
-        lt, gt, vt = (2e-4, 1e-3, 1e-4) if st == 0 else (1e-2, 6e-2, 5e-3)
+        lt, gt, vt = STEP_TOL[prec][0 if st == 0 else 1]
         got, ref = np.array(list(losses.values())), arr["s%d/losses" % st]
         assert np.allclose(got, ref, rtol=lt, atol=2e-6), (st, dict(zip(meta["loss_keys"], zip(got, ref))))
         gg, gr = np.array(list(gnorms.values())), arr["s%d/gnorms" % st]
@@ -57,9 +71,16 @@ def test_train_instance_matches_reference_golden(name):
             assert visuals[k].shape == visuals["real_A" if k.endswith("A") else "real_B"].shape
 
 
-def test_step_against_oracle_with_6_blocks():
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_step_against_oracle_with_6_blocks(prec):
     """BASELINE config-1 shape with the north star's n_blocks=6 (the reference itself only builds 3):
     HIP path vs the oracle run here, incl. post-step generator output (i.e. the applied update)."""
+    from hip_util import precision
+    with precision(prec):
+        _check_6_blocks(prec)
+
+
+def _check_6_blocks(prec):
     from hip_util import t, n, rel, load_recipe
     from dtgan_amd import model as M
     from oracle import recipe, step
@@ -73,13 +94,14 @@ def test_step_against_oracle_with_6_blocks():
     A, B, z = recipe.inputs(5, 4, 1, 1, 64, 4)  # batch >= 3: BatchNorm over E's 1x1 map
     l1, v1, g1 = m.train_instance(t(A), t(B), t(z))
     l0, v0, g0 = o.train_instance(A, B, z)
-    assert np.allclose(list(l1.values()), list(l0.values()), rtol=2e-4, atol=2e-6), (l1, l0)
-    assert np.allclose(list(g1.values()), list(g0.values()), rtol=1e-3, atol=1e-6), (g1, g0)
+    (lt, gt, vt), (_, _, vt1) = STEP_TOL[prec]
+    assert np.allclose(list(l1.values()), list(l0.values()), rtol=lt, atol=2e-6), (l1, l0)
+    assert np.allclose(list(g1.values()), list(g0.values()), rtol=gt, atol=1e-6), (g1, g0)
     for k in ("fake_A", "fake_B", "rec_A", "rec_B"):
-        assert rel(n(v1[k]), v0[k]) < 1e-4, k
+        assert rel(n(v1[k]), v0[k]) < vt, k
     # weights after the step: compare the generators' outputs on a fresh batch
     A2, B2, z2 = recipe.inputs(6, 4, 1, 1, 64, 4)
     from oracle.tape import T
     fb = n(m.predict_B(t(A2), t(z2)))
     fbo = o.netG_A_B.forward(T(A2), T(z2)).v
-    assert rel(fb, fbo) < 5e-3
+    assert rel(fb, fbo) < vt1

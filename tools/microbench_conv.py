@@ -39,7 +39,7 @@ def main():
     ops.set_precision(a.precision)
     st = ops._stream()
     for name, N, H, W, Ci, Co, K, s, p, mode, Cir, Cor in SHAPES:
-        if a.only and a.only not in name:
+        if a.only and not any(o in name for o in a.only.split(",")):
             continue
         d = ops.conv_desc(N, H, W, Ci, Co, K, s, p, mode, Cir, Cor)
         x = torch.randn((N, H, W, Ci), device=dev)
