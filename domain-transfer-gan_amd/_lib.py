@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libacgan_hip.so")
+# ACGAN_HIP_LIB: load another build of the SAME library (A/B timing of kernel changes on one GPU box)
+LIB_PATH = os.environ.get("ACGAN_HIP_LIB") or os.path.join(_HERE, "libacgan_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1

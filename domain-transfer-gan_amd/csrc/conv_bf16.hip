@@ -10,6 +10,7 @@
 // This is the throughput mode (`acg_set_conv_precision(ACG_PREC_BF16)`); the fp32 kernels remain the
 // parity path (1e-3 bar).  Error model: each product carries two 2^-9 roundings, sums stay fp32.
 #include "conv_internal.h"
+#include <cstdlib>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
@@ -31,12 +32,19 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
     constexpr int AL = BM / RPP;             // units per thread per stage
     constexpr int BCH = NKC * BN * 2;        // 16-byte chunks in the B tile
     constexpr int BL = (BCH + 255) / 256;
-    constexpr int AKS = BM * 16 + 16, BKS = BN * 16 + 16; // k-chunk strides (bf16 elements), +32 B pad
+    // LDS images are planes of 8 consecutive k: [k8][row][8 bf16], rows 16 B apart.  ds_read_b128 serves a wave in
+    // four 16-lane groups ({0-3,12-15,20-27}, ...) over a 256-B bank row: 32 consecutive rows of one plane put every
+    // group on 16 distinct 16-byte slots (a [row][16 k] image with 32-B rows is 2-way conflicted: 42 % of the LDS
+    // cycles by SQ_LDS_BANK_CONFLICT).  ds_write_b128 goes by 8 contiguous lanes over a 128-B bank row: the plane
+    // pads put the (rows x planes) / (columns x 2 planes) that a lane group stores on 8 distinct slots.
+    constexpr int NK8 = KC / 8;
+    constexpr int APL = BM * 8 + (NK8 == 4 ? 16 : NK8 == 8 ? 8 : 32), BPL = BN * 8 + 32; // plane strides (bf16 elements)
     static_assert(WM * WN == 4 && AL >= 1 && MB >= 1 && NB >= 1, "tile config");
 
     constexpr int NIMG = SPLIT ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) __bf16 As[NIMG * NKC * AKS];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[NIMG * NKC * BKS];
+    constexpr int A_IMG = NK8 * APL, B_IMG = NK8 * BPL; // one hi (or lo) image
+    __shared__ __attribute__((aligned(16))) __bf16 As[NIMG * A_IMG];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[NIMG * B_IMG];
     __shared__ long long out_off[BM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
         const int kc = idx / (BN * 2);
         const int rem = idx - kc * BN * 2;
         b_voff[i] = (unsigned)(((kc * g.ncols_pad + n0) * 16 + rem * 8) * 2);
-        b_lds[i] = kc * BKS + rem * 8;
+        b_lds[i] = (kc * 2 + (rem & 1)) * BPL + (rem >> 1) * 8; // chunk = (column rem/2, k-half rem&1)
     }
     if (tid < BM) {
         const long long m = m0 + tid;
@@ -105,7 +113,8 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
         const int cc = s / taps.n;
         const int t = s - cc * taps.n;
         const int c0 = cc * KC;
-        const int ty = taps.dy[t], tx = taps.dx[t], tw = taps.w[t];
+        const int pk = taps.pk[t]; // scalar load: (dy, dx, weight slab) of this stage
+        const int ty = (pk << 24) >> 24, tx = (pk << 16) >> 24, tw = pk >> 16;
 #pragma unroll
         for (int j = 0; j < AL; ++j) {
             int pix;
@@ -142,17 +151,22 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < AL; ++j) {
-            const int a_at = (u >> 1) * AKS + (rrow + RPP * j) * 16 + (u & 1) * 8;
-            const bf16x8 hi = __builtin_convertvector(ra[j], bf16x8);
-            *(bf16x8 *)&As[a_at] = hi;
-            if (SPLIT) // residual of the RNE rounding, itself rounded to bf16: x = hi + lo + O(2^-17 |x|)
-                *(bf16x8 *)&As[NKC * AKS + a_at] = __builtin_convertvector(ra[j] - __builtin_convertvector(hi, f32x8), bf16x8);
+            const int a_at = u * APL + (rrow + RPP * j) * 8;
+            const float v[8] = {ra[j][0], ra[j][1], ra[j][2], ra[j][3], ra[j][4], ra[j][5], ra[j][6], ra[j][7]};
+            if (SPLIT) {
+                acg_u32x4 hi, lo;
+                acg_split8(v, hi, lo);
+                *(acg_u32x4 *)&As[a_at] = hi;
+                *(acg_u32x4 *)&As[A_IMG + a_at] = lo;
+            } else {
+                *(acg_u32x4 *)&As[a_at] = acg_round8(v);
+            }
         }
 #pragma unroll
         for (int i = 0; i < BL; ++i)
             if (tid + 256 * i < BCH) {
                 *(u32x4 *)&Bs[b_lds[i]] = rb[i];
-                if (SPLIT) *(u32x4 *)&Bs[NKC * BKS + b_lds[i]] = rbl[i];
+                if (SPLIT) *(u32x4 *)&Bs[B_IMG + b_lds[i]] = rbl[i];
             }
         __syncthreads();
         if (s + 1 < S) load_stage(s + 1);
@@ -161,15 +175,15 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
             bf16x8 a[MB], b[NB], al[MB], bl[NB];
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
-                const int at = kc * AKS + (wm * TM + i * 32 + (lane & 31)) * 16 + (lane >> 5) * 8;
+                const int at = (kc * 2 + (lane >> 5)) * APL + (wm * TM + i * 32 + (lane & 31)) * 8;
                 a[i] = *(const bf16x8 *)&As[at];
-                if (SPLIT) al[i] = *(const bf16x8 *)&As[NKC * AKS + at];
+                if (SPLIT) al[i] = *(const bf16x8 *)&As[A_IMG + at];
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                const int bt = kc * BKS + (wn * TN + j * 32 + (lane & 31)) * 16 + (lane >> 5) * 8;
+                const int bt = (kc * 2 + (lane >> 5)) * BPL + (wn * TN + j * 32 + (lane & 31)) * 8;
                 b[j] = *(const bf16x8 *)&Bs[bt];
-                if (SPLIT) bl[j] = *(const bf16x8 *)&Bs[NKC * BKS + bt];
+                if (SPLIT) bl[j] = *(const bf16x8 *)&Bs[B_IMG + bt];
             }
 #pragma unroll
             for (int i = 0; i < MB; ++i)
@@ -233,6 +247,8 @@ int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, fl
         if (g.reflect) launch_bf16_kc<KCV, true, SP>(bn, grid, st, in, w, bias, out, g, t, inb, wb, wlo);   \
         else launch_bf16_kc<KCV, false, SP>(bn, grid, st, in, w, bias, out, g, t, inb, wb, wlo);            \
     } while (0)
+    static const bool no_ws = getenv("ACG_NO_WS") != nullptr; // A/B switch for the wave-specialised kernel
+    if (split && bn == 128 && g.Cin % 32 == 0 && !no_ws) return acg_igemm_x3_ws_launch(in, wp, bias, out, g0, t, n_w_elems, st);
     if (split) { // hi+lo images double the LDS: 32-channel stages keep 3-4 blocks per CU
         if (g.Cin % 32 == 0) BF16_DISPATCH(32, true);
         else BF16_DISPATCH(16, true);
@@ -258,7 +274,13 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
                                                   unsigned d_bytes)
 {
     constexpr int TI = BCI / WI, TJ = BCO / WJ, MI = TI / 32, MJ = TJ / 32;
-    constexpr int RS = KP + 8;                          // LDS row stride (elements)
+    // LDS rows hold KP pixels of one channel.  KP == 64 (128-B rows): the eight 16-byte pixel groups of a row are
+    // XOR-permuted by g(row) = (row>>2 & 3) | ((row>>1 ^ row>>4) & 1) << 2, which makes BOTH the transposed
+    // ds_write_b128 (8-lane groups, rows 4 apart) and the fragment ds_read_b128 (16-lane groups) conflict-free — a
+    // padded linear row leaves the stores 4-way conflicted (60 % of the LDS cycles).  Other KP: +16 B row pad.
+    constexpr bool SWZ = KP == 64;
+    constexpr int RS = SWZ ? KP : KP + 8;               // LDS row stride (elements)
+#define ACG_WG_AT(row, pgq) ((row) * RS + (((pgq) ^ (SWZ ? ((((row) >> 2) & 3) | (((((row) >> 1) ^ ((row) >> 4)) & 1) << 2)) : 0)) * 8))
     constexpr int XU = (KP / 8) * (BCI / 4), DU = (KP / 8) * (BCO / 4); // 8-pixel x 4-channel units
     constexpr int XL = (XU + 255) / 256, DL = (DU + 255) / 256;
     constexpr int KW = KP / WK;                         // pixels of a stage per wave
@@ -324,21 +346,50 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
             const long long m = k0 + pg * 8;
             int n = un[l], gy = uy[l], gx = ux[l];
             const bool uok = unit < XU && ci < g.Cin;
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                int iy = gy * g.is + ty, ix = gx * g.is + tx;
-                bool ok = uok && m + p < mend;
+            // the 8 pixels of a unit are consecutive output positions: when no lane's unit crosses a row end (always
+            // so for W % 8 == 0), the row part of the address is formed once and each pixel costs a few VALU ops
+            const bool in_row = gx + 8 <= g.Wg && m + 8 <= mend;
+            if (__builtin_amdgcn_ballot_w64(uok && !in_row) == 0) {
+                int iy = gy * g.is + ty;
+                bool oky = uok && in_row;
                 if (g.reflect) {
                     iy = iy < 0 ? -iy : iy;
                     iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
-                    ix = ix < 0 ? -ix : ix;
-                    ix = ix >= g.Win ? 2 * (g.Win - 1) - ix : ix;
                 } else {
-                    ok = ok && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+                    oky = oky && (unsigned)iy < (unsigned)g.Hin;
                 }
-                const unsigned off = ok ? (unsigned)(((n * g.Hin + iy) * g.Win + ix) * g.Cin + ci) * 4u : 0xFFFFFFFFu;
-                rx[l][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx_, off, 0, 0));
-                if (++gx == g.Wg) { gx = 0; if (++gy == g.Hg) { gy = 0; ++n; } }
+                const int rowbase = (n * g.Hin + iy) * g.Win;
+                const int ix0 = gx * g.is + tx;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    int ix = ix0 + p * g.is;
+                    bool ok = oky;
+                    if (g.reflect) {
+                        ix = ix < 0 ? -ix : ix;
+                        ix = ix >= g.Win ? 2 * (g.Win - 1) - ix : ix;
+                    } else {
+                        ok = ok && (unsigned)ix < (unsigned)g.Win;
+                    }
+                    const unsigned off = ok ? (unsigned)((rowbase + ix) * g.Cin + ci) * 4u : 0xFFFFFFFFu;
+                    rx[l][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx_, off, 0, 0));
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    int iy = gy * g.is + ty, ix = gx * g.is + tx;
+                    bool ok = uok && m + p < mend;
+                    if (g.reflect) {
+                        iy = iy < 0 ? -iy : iy;
+                        iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
+                        ix = ix < 0 ? -ix : ix;
+                        ix = ix >= g.Win ? 2 * (g.Win - 1) - ix : ix;
+                    } else {
+                        ok = ok && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+                    }
+                    const unsigned off = ok ? (unsigned)(((n * g.Hin + iy) * g.Win + ix) * g.Cin + ci) * 4u : 0xFFFFFFFFu;
+                    rx[l][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx_, off, 0, 0));
+                    if (++gx == g.Wg) { gx = 0; if (++gy == g.Hg) { gy = 0; ++n; } }
+                }
             }
             ux[l] += KP;
             while (ux[l] >= g.Wg) { ux[l] -= g.Wg; if (++uy[l] == g.Hg) { uy[l] = 0; ++un[l]; } }
@@ -350,9 +401,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
             const int co = co0 + c4 * 4;
             const long long m = k0 + pg * 8;
             const bool uok = unit < DU && co < g.Cg;
+            const bool full = m + 8 <= mend;
+            const unsigned base = (unsigned)((int)m * g.Cg + co) * 4u, step = (unsigned)g.Cg * 4u;
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
-                const unsigned off = (uok && m + p < mend) ? (unsigned)((int)(m + p) * g.Cg + co) * 4u : 0xFFFFFFFFu;
+                const unsigned off = (uok && (full || m + p < mend)) ? base + p * step : 0xFFFFFFFFu;
                 rd[l][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd_, off, 0, 0));
             }
         }
@@ -365,14 +418,17 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
                 const int c4 = unit % (BCI / 4), pg = unit / (BCI / 4);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    f32x8 v;
+                    float v[8];
 #pragma unroll
                     for (int p = 0; p < 8; ++p) v[p] = rx[l][p][c];
-                    const bf16x8 hi = __builtin_convertvector(v, bf16x8);
-                    *(bf16x8 *)&Xs[(c4 * 4 + c) * RS + pg * 8] = hi;
-                    if (SPLIT)
-                        *(bf16x8 *)&Xs[BCI * RS + (c4 * 4 + c) * RS + pg * 8] =
-                            __builtin_convertvector(v - __builtin_convertvector(hi, f32x8), bf16x8);
+                    if (SPLIT) {
+                        acg_u32x4 hi, lo;
+                        acg_split8(v, hi, lo);
+                        *(acg_u32x4 *)&Xs[ACG_WG_AT(c4 * 4 + c, pg)] = hi;
+                        *(acg_u32x4 *)&Xs[BCI * RS + ACG_WG_AT(c4 * 4 + c, pg)] = lo;
+                    } else {
+                        *(acg_u32x4 *)&Xs[ACG_WG_AT(c4 * 4 + c, pg)] = acg_round8(v);
+                    }
                 }
             }
         }
@@ -383,14 +439,17 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
                 const int c4 = unit % (BCO / 4), pg = unit / (BCO / 4);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    f32x8 v;
+                    float v[8];
 #pragma unroll
                     for (int p = 0; p < 8; ++p) v[p] = rd[l][p][c];
-                    const bf16x8 hi = __builtin_convertvector(v, bf16x8);
-                    *(bf16x8 *)&Ds[(c4 * 4 + c) * RS + pg * 8] = hi;
-                    if (SPLIT)
-                        *(bf16x8 *)&Ds[BCO * RS + (c4 * 4 + c) * RS + pg * 8] =
-                            __builtin_convertvector(v - __builtin_convertvector(hi, f32x8), bf16x8);
+                    if (SPLIT) {
+                        acg_u32x4 hi, lo;
+                        acg_split8(v, hi, lo);
+                        *(acg_u32x4 *)&Ds[ACG_WG_AT(c4 * 4 + c, pg)] = hi;
+                        *(acg_u32x4 *)&Ds[BCO * RS + ACG_WG_AT(c4 * 4 + c, pg)] = lo;
+                    } else {
+                        *(acg_u32x4 *)&Ds[ACG_WG_AT(c4 * 4 + c, pg)] = acg_round8(v);
+                    }
                 }
             }
         }
@@ -420,13 +479,13 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
             bf16x8 a[MI], bb[MJ], al[MI], bl[MJ];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                const int at = (wi * TI + i * 32 + (lane & 31)) * RS + kk + (lane >> 5) * 8;
+                const int at = ACG_WG_AT(wi * TI + i * 32 + (lane & 31), (kk >> 3) + (lane >> 5));
                 a[i] = *(const bf16x8 *)&Xs[at];
                 if (SPLIT) al[i] = *(const bf16x8 *)&Xs[BCI * RS + at];
             }
 #pragma unroll
             for (int j = 0; j < MJ; ++j) {
-                const int bt = (wj * TJ + j * 32 + (lane & 31)) * RS + kk + (lane >> 5) * 8;
+                const int bt = ACG_WG_AT(wj * TJ + j * 32 + (lane & 31), (kk >> 3) + (lane >> 5));
                 bb[j] = *(const bf16x8 *)&Ds[bt];
                 if (SPLIT) bl[j] = *(const bf16x8 *)&Ds[BCO * RS + bt];
             }

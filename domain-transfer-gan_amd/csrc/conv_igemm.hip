@@ -136,9 +136,10 @@ __global__ __launch_bounds__(256) void igemm_conv_f32(const float *__restrict__ 
             const int cc = s / taps.n;
             const int t = s - cc * taps.n;
             c0 = cc * KC;
-            ty = taps.dy[t];
-            tx = taps.dx[t];
-            tw = taps.w[t];
+            const int pk = taps.pk[t];
+            ty = (pk << 24) >> 24;
+            tx = (pk << 16) >> 24;
+            tw = pk >> 16;
         }
         const int coff = THIN ? 0 : c0 + 4 * q;
 #pragma unroll
@@ -230,11 +231,12 @@ static void launch_v(int bn, dim3 grid, hipStream_t st, const float *in, const f
         hipLaunchKernelGGL((igemm_conv_f32<128, 32, 4, 1, KC, REFLECT, THIN>), grid, block, 0, st, in, wp, bias, out, g, t, inb, wb);
 }
 
-int acg_igemm_launch(const float *in, const float *wp, const float *bias, float *out, const Geom &g0, const Taps &t,
+int acg_igemm_launch(const float *in, const float *wp, const float *bias, float *out, const Geom &g0, const Taps &t0,
                      hipStream_t st)
 {
-    if (g0.Mtot <= 0 || t.n <= 0) return ACG_OK;
+    if (g0.Mtot <= 0 || t0.n <= 0) return ACG_OK;
     Geom g = g0;
+    const Taps t = acg_taps_pack(t0);
     const int bn = bn_for(g.Cout);
     if (g_acg_precision != ACG_PREC_F32 && g_acg_conv_impl == ACG_IMPL_MFMA && !g0.thin) return acg_igemm_bf16_launch(in, wp, bias, out, g0, t, bn, g0.w_elems, st);
     const long long nimg = g.Mtot / ((long long)g.GH * g.GW);

@@ -9,7 +9,19 @@ struct Taps {
     short dy[64];
     short dx[64];
     short w[64];
+    // (dy & 0xff) | (dx & 0xff) << 8 | w << 16 per tap: ONE dword the kernels fetch with a scalar load per stage
+    // (16-bit array elements go through vector memory and leave the weight-slab offset in a VGPR).  Filled by
+    // acg_taps_pack() in the launchers.
+    int pk[64];
 };
+
+static inline Taps acg_taps_pack(const Taps &t)
+{
+    Taps r = t;
+    for (int i = 0; i < 64; ++i)
+        r.pk[i] = i < t.n ? ((t.dy[i] & 0xff) | ((t.dx[i] & 0xff) << 8) | ((int)t.w[i] << 16)) : 0;
+    return r;
+}
 
 struct Geom {
     int Hin, Win, Cin;    // gathered tensor (K-channels = Cin, multiple of 16)
@@ -47,7 +59,39 @@ int acg_wgrad_launch(const float *x, const float *dy, float *part, const WGeom &
 void acg_wgrad_tiles(int Ci, int Co, int *bci, int *bco);
 
 extern int g_acg_precision;
+int acg_igemm_x3_ws_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g, const Taps &t,
+                           long long n_w_elems, hipStream_t st);
 int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g, const Taps &t,
                           int bn, long long n_w_elems, hipStream_t st);
 int acg_wgrad_bf16_launch(const float *x, const float *dy, float *part, const WGeom &g, const Taps &t, int bci, int bco,
                           hipStream_t st);
+
+#ifdef __HIPCC__
+// bf16x3 operand split of 8 fp32 values: hi = RNE bf16(x), lo = RNE bf16(x - hi), each returned as 8 packed bf16
+// (x = hi + lo + O(2^-17 |x|)).  Written pairwise so every conversion is one v_cvt_pk_bf16_f32 and the residuals one
+// v_pk_add_f32: 20 VALU instructions per 8 values (a whole-vector __builtin_convertvector on gathered scalars
+// compiles to one conversion per element).
+typedef unsigned acg_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void acg_split8(const float (&v)[8], acg_u32x4 &hi, acg_u32x4 &lo)
+{
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[2 * q], v[2 * q + 1]}, bf16x2_t));
+        const float ha = __builtin_bit_cast(float, h << 16), hb = __builtin_bit_cast(float, h & 0xffff0000u);
+        hi[q] = h;
+        lo[q] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[2 * q] - ha, v[2 * q + 1] - hb}, bf16x2_t));
+    }
+}
+__device__ __forceinline__ acg_u32x4 acg_round8(const float (&v)[8]) // bf16 mode: the hi part only
+{
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    acg_u32x4 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        r[q] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[2 * q], v[2 * q + 1]}, bf16x2_t));
+    return r;
+}
+#endif

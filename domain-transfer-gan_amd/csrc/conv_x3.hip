@@ -1,0 +1,233 @@
+// Wave-specialised implicit-GEMM convolution for the bf16x3 arithmetic (ACG_PREC_BF16X3), 128x128 output tiles.
+//
+// The single-role kernel (conv_bf16.hip) runs its phases one after the other inside every wave — split the fp32
+// operands (VALU), store them to LDS, barrier, read fragments, issue MFMAs — and rocprofv3 counters show the three
+// pipes each busy about a third of the time (profiles/r01_d_*).  Here a workgroup of 8 waves divides the work:
+//   waves 0-3  consumers: ds_read fragments + v_mfma_f32_32x32x16_bf16 only (2x2 waves x 64x64 outputs);
+//   waves 4-7  producers: buffer loads, hi/lo split, LDS stores for the NEXT stage into the other LDS buffer.
+// One s_barrier per stage hands a filled buffer to the consumers and a drained one back to the producers, so the
+// matrix pipe, the VALU and the LDS work of consecutive stages overlap on every SIMD (one wave of each role per SIMD
+// and per resident workgroup; two workgroups per CU).
+#include "common.h"
+#include "conv_internal.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int BM = 128, BN = 128, KC = 32, NKC = KC / 16, NK8 = KC / 8;
+// LDS images are planes of 8 consecutive k: [k8][row][8 bf16], rows 16 B apart.  ds_read_b128 serves a wave in four
+// 16-lane groups ({0-3,12-15,20-27}, ...) over a 256-B bank row: 32 consecutive rows of one plane put every group on
+// 16 distinct 16-byte slots (a [row][16 k] image with 32-B rows is 2-way conflicted: measured 42 % of LDS cycles).
+// ds_write_b128 goes by 8 contiguous lanes over a 128-B bank row: the plane pads (A +32 B, B +64 B) put the
+// (2 rows x 4 planes) resp. (4 columns x 2 planes) a lane group stores on 8 distinct slots.
+constexpr int APL = BM * 8 + 16, BPL = BN * 8 + 32;   // plane strides (bf16 elements)
+constexpr int A_IMG = NK8 * APL, B_IMG = NK8 * BPL;   // one hi (or lo) image
+constexpr int BUF = 2 * A_IMG + 2 * B_IMG;            // A hi, A lo, B hi, B lo
+}
+
+template <bool REFLECT>
+__global__ __launch_bounds__(512) void igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
+                                                        const float *__restrict__ bias, float *__restrict__ out,
+                                                        Geom g, Taps taps, unsigned in_bytes, unsigned w_bytes,
+                                                        unsigned w_lo_bytes)
+{
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF];
+    __shared__ long long out_off[BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int tiles_n = g.ncols_pad / BN;
+    const int tile_n = swz % tiles_n, tile_m = swz / tiles_n;
+    const int n0 = tile_n * BN;
+    const long long m0 = (long long)tile_m * BM;
+    const int GHW = g.GH * g.GW;
+    const int S = taps.n * (g.Cin / KC);
+
+    if (tid < BM) {
+        const long long m = m0 + tid;
+        long long off = -1;
+        if (m < g.Mtot) {
+            const int n = (int)(m / GHW);
+            const int r = (int)(m - (long long)n * GHW);
+            const int gy = r / g.GW, gx = r - gy * g.GW;
+            off = (((long long)n * g.Hout + (gy * g.os + g.oy0)) * g.Wout + (gx * g.os + g.ox0)) * g.Cout;
+        }
+        out_off[tid] = off;
+    }
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producers
+        const int pt = tid - 256;
+        constexpr int UPR = KC / 8, RPP = 256 / UPR, AL = BM / RPP; // 4 units per pixel row, 64 rows per pass, 2 passes
+        constexpr int BCH = NKC * BN * 2, BL = BCH / 256;           // 16-byte chunks of the B tile: 2 per thread
+        const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, in_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, w_bytes, 0x00020000);
+        const int u = pt % UPR, rrow = pt / UPR;
+        int a_row[AL], a_by[AL], a_bx[AL];
+        bool a_ok[AL];
+#pragma unroll
+        for (int j = 0; j < AL; ++j) {
+            const long long m = m0 + rrow + RPP * j;
+            a_ok[j] = m < g.Mtot;
+            const long long mm = a_ok[j] ? m : 0;
+            const int n = (int)(mm / GHW);
+            const int r = (int)(mm - (long long)n * GHW);
+            const int gy = r / g.GW, gx = r - gy * g.GW;
+            a_by[j] = gy * g.is;
+            a_bx[j] = gx * g.is;
+            a_row[j] = REFLECT ? n * g.Hin : (n * g.Hin + a_by[j]) * g.Win + a_bx[j];
+        }
+        unsigned b_voff[BL];
+        int b_lds[BL];
+#pragma unroll
+        for (int i = 0; i < BL; ++i) {
+            const int idx = pt + 256 * i;
+            const int kc = idx / (BN * 2);
+            const int rem = idx - kc * BN * 2;
+            b_voff[i] = (unsigned)(((kc * g.ncols_pad + n0) * 16 + rem * 8) * 2);
+            b_lds[i] = (kc * 2 + (rem & 1)) * BPL + (rem >> 1) * 8; // chunk = (column rem/2, k-half rem&1)
+        }
+        f32x8 ra[AL];
+        u32x4 rb[BL], rbl[BL];
+        auto load_stage = [&](int s) {
+            const int cc = s / taps.n;
+            const int t = s - cc * taps.n;
+            const int c0 = cc * KC;
+            const int pk = taps.pk[t];
+            const int ty = (pk << 24) >> 24, tx = (pk << 16) >> 24, tw = pk >> 16;
+#pragma unroll
+            for (int j = 0; j < AL; ++j) {
+                int pix;
+                bool ok = a_ok[j];
+                if (REFLECT) {
+                    int iy = a_by[j] + ty, ix = a_bx[j] + tx;
+                    iy = iy < 0 ? -iy : iy;
+                    iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
+                    ix = ix < 0 ? -ix : ix;
+                    ix = ix >= g.Win ? 2 * (g.Win - 1) - ix : ix;
+                    pix = (a_row[j] + iy) * g.Win + ix;
+                } else {
+                    const int iy = a_by[j] + ty, ix = a_bx[j] + tx;
+                    ok = ok && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+                    pix = a_row[j] + ty * g.Win + tx;
+                }
+                const unsigned off = ok ? (unsigned)(pix * g.Cin + c0 + 8 * u) * 4u : 0xFFFFFFFFu;
+                const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);
+                const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? off + 16u : 0xFFFFFFFFu, 0, 0);
+                const f32x4 flo = __builtin_bit_cast(f32x4, lo), fhi = __builtin_bit_cast(f32x4, hi);
+                ra[j] = (f32x8){flo[0], flo[1], flo[2], flo[3], fhi[0], fhi[1], fhi[2], fhi[3]};
+            }
+            const unsigned soff = (unsigned)(((tw * (g.Cin >> 4) + (c0 >> 4)) * g.ncols_pad) * 16) * 2u;
+#pragma unroll
+            for (int i = 0; i < BL; ++i) {
+                rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[i], soff, 0);
+                rbl[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[i], soff + w_lo_bytes, 0);
+            }
+        };
+        load_stage(0);
+        for (int s = 0; s < S; ++s) {
+            __bf16 *As = lds + (s & 1) * BUF, *Bs = As + 2 * A_IMG;
+#pragma unroll
+            for (int j = 0; j < AL; ++j) {
+                const int a_at = u * APL + (rrow + RPP * j) * 8;
+                const float v[8] = {ra[j][0], ra[j][1], ra[j][2], ra[j][3], ra[j][4], ra[j][5], ra[j][6], ra[j][7]};
+                acg_u32x4 hi, lo;
+                acg_split8(v, hi, lo);
+                *(acg_u32x4 *)&As[a_at] = hi;
+                *(acg_u32x4 *)&As[A_IMG + a_at] = lo;
+            }
+#pragma unroll
+            for (int i = 0; i < BL; ++i) {
+                *(u32x4 *)&Bs[b_lds[i]] = rb[i];
+                *(u32x4 *)&Bs[B_IMG + b_lds[i]] = rbl[i];
+            }
+            if (s + 1 < S) load_stage(s + 1);
+            __syncthreads(); // buffer s&1 is full; the consumers have drained buffer (s+1)&1
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    __builtin_amdgcn_s_setprio(2);
+    const int wm = wave >> 1, wn = wave & 1;
+    constexpr int TM = 64, TN = 64, MB = 2, NB = 2;
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int s = 0; s < S; ++s) {
+        __syncthreads();
+        const __bf16 *As = lds + (s & 1) * BUF, *Bs = As + 2 * A_IMG;
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            bf16x8 a[MB], b[NB], al[MB], bl[NB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const int at = (kc * 2 + (lane >> 5)) * APL + (wm * TM + i * 32 + (lane & 31)) * 8;
+                a[i] = *(const bf16x8 *)&As[at];
+                al[i] = *(const bf16x8 *)&As[A_IMG + at];
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int bt = (kc * 2 + (lane >> 5)) * BPL + (wn * TN + j * 32 + (lane & 31)) * 8;
+                b[j] = *(const bf16x8 *)&Bs[bt];
+                bl[j] = *(const bf16x8 *)&Bs[B_IMG + bt];
+            }
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) { // small cross terms first, the leading term last
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int co = n0 + wn * TN + j * 32 + (lane & 31);
+        const bool cok = co < g.Cout;
+        const float bv = (bias != nullptr && cok) ? bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const long long off = out_off[row];
+                if (cok && off >= 0) out[off + co] = acg_apply_act(acc[i][j][r] + bv, g.act);
+            }
+        }
+    }
+}
+
+// same contract as acg_igemm_bf16_launch for bn == 128, Cin % 32 == 0, ACG_PREC_BF16X3
+int acg_igemm_x3_ws_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g0, const Taps &t,
+                           long long n_w_elems, hipStream_t st)
+{
+    Geom g = g0;
+    g.thin = 0;
+    dim3 grid(acg_cdiv(g.Mtot, BM) * (g.ncols_pad / BN));
+    const long long nimg = g.Mtot / ((long long)g.GH * g.GW);
+    const long long in_bytes = nimg * g.Hin * g.Win * g.Cin * 4;
+    const long long w_bytes = n_w_elems * 2 * 2;
+    ACG_REQUIRE(in_bytes < (1LL << 32) && w_bytes < (1LL << 32), "igemm_conv_x3_ws: operand exceeds the 4 GiB buffer-addressing limit");
+    const unsigned inb = (unsigned)in_bytes, wb = (unsigned)w_bytes, wlo = (unsigned)(n_w_elems * 2);
+    if (g.reflect)
+        hipLaunchKernelGGL((igemm_conv_x3_ws<true>), grid, dim3(512), 0, st, in, (const __bf16 *)wp, bias, out, g, t, inb, wb, wlo);
+    else
+        hipLaunchKernelGGL((igemm_conv_x3_ws<false>), grid, dim3(512), 0, st, in, (const __bf16 *)wp, bias, out, g, t, inb, wb, wlo);
+    ACG_CHECK_LAUNCH("igemm_conv_x3_ws");
+    return ACG_OK;
+}
