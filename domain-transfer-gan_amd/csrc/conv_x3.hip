@@ -3,7 +3,8 @@
 // The single-role kernel (conv_bf16.hip) runs its phases one after the other inside every wave — split the fp32
 // operands (VALU), store them to LDS, barrier, read fragments, issue MFMAs — and rocprofv3 counters show the three
 // pipes each busy about a third of the time (profiles/r01_d_*).  Here a workgroup of 8 waves divides the work:
-//   waves 0-3  consumers: ds_read fragments + v_mfma_f32_32x32x16_bf16 only (2x2 waves x 64x64 outputs);
+//   waves 0-3  consumers: ds_read fragments + v_mfma_f32_16x16x32_bf16 only (2x2 waves x 64x64 outputs; this shape
+//              ran 3-4 % faster than 32x32x16 at equal cycles: the chip holds a higher clock on it);
 //   waves 4-7  producers: buffer loads, hi/lo split, LDS stores for the NEXT stage into the other LDS buffer.
 // One s_barrier per stage hands a filled buffer to the consumers and a drained one back to the producers, so the
 // matrix pipe, the VALU and the LDS work of consecutive stages overlap on every SIMD (one wave of each role per SIMD
@@ -14,19 +15,20 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
-constexpr int BM = 128, BN = 128, KC = 32, NKC = KC / 16, NK8 = KC / 8;
-// LDS images are planes of 8 consecutive k: [k8][row][8 bf16], rows 16 B apart.  ds_read_b128 serves a wave in four
-// 16-lane groups ({0-3,12-15,20-27}, ...) over a 256-B bank row: 32 consecutive rows of one plane put every group on
-// 16 distinct 16-byte slots (a [row][16 k] image with 32-B rows is 2-way conflicted: measured 42 % of LDS cycles).
-// ds_write_b128 goes by 8 contiguous lanes over a 128-B bank row: the plane pads (A +32 B, B +64 B) put the
-// (2 rows x 4 planes) resp. (4 columns x 2 planes) a lane group stores on 8 distinct slots.
-constexpr int APL = BM * 8 + 16, BPL = BN * 8 + 32;   // plane strides (bf16 elements)
+constexpr int BM = 128, BN = 128, KC = 32, NK8 = KC / 8;
+// LDS images are planes of 8 consecutive k: [k8][row][8 bf16], rows 16 B apart, planes 2 KB (256-B aligned).
+// v_mfma_f32_16x16x32_bf16 wants row l&15 of plane l>>4 in lane l, and ds_read_b128 serves a wave in four 16-lane
+// groups ({0-3,12-15,20-27}, ...) over a 256-B bank row, so a group spans two planes: XOR-permuting the rows of plane p
+// by 2p keeps {rows 0-3,12-15 of plane 2q} U {rows 4-11 of plane 2q+1} on 16 distinct 16-byte slots, and the 8-lane
+// groups of ds_write_b128 (2 rows x 4 planes for A, 8 columns of one plane for B) on 8 distinct slots of their 128-B row:
+// SQ_LDS_BANK_CONFLICT = 0 (a [row][16 k] image with 32-B rows is 2-way conflicted: 42 % of the LDS cycles).
+constexpr int APL = BM * 8, BPL = BN * 8;             // plane strides (bf16 elements)
 constexpr int A_IMG = NK8 * APL, B_IMG = NK8 * BPL;   // one hi (or lo) image
 constexpr int BUF = 2 * A_IMG + 2 * B_IMG;            // A hi, A lo, B hi, B lo
+__device__ __forceinline__ int lds_at(int plane, int row, int pl) { return plane * pl + ((row ^ (2 * plane)) * 8); }
 }
 
 template <bool REFLECT>
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(512) void igemm_conv_x3_ws(const float *__restrict_
         // ------------------------------------------------------------------ producers
         const int pt = tid - 256;
         constexpr int UPR = KC / 8, RPP = 256 / UPR, AL = BM / RPP; // 4 units per pixel row, 64 rows per pass, 2 passes
-        constexpr int BCH = NKC * BN * 2, BL = BCH / 256;           // 16-byte chunks of the B tile: 2 per thread
+        constexpr int BCH = NK8 * BN, BL = BCH / 256;               // 16-byte chunks of the B tile: 2 per thread
         const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, in_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, w_bytes, 0x00020000);
         const int u = pt % UPR, rrow = pt / UPR;
@@ -88,10 +90,9 @@ __global__ __launch_bounds__(512) void igemm_conv_x3_ws(const float *__restrict_
 #pragma unroll
         for (int i = 0; i < BL; ++i) {
             const int idx = pt + 256 * i;
-            const int kc = idx / (BN * 2);
-            const int rem = idx - kc * BN * 2;
-            b_voff[i] = (unsigned)(((kc * g.ncols_pad + n0) * 16 + rem * 8) * 2);
-            b_lds[i] = (kc * 2 + (rem & 1)) * BPL + (rem >> 1) * 8; // chunk = (column rem/2, k-half rem&1)
+            const int plane = idx / BN, col = idx - plane * BN; // 8 consecutive lanes store 8 columns of ONE plane
+            b_voff[i] = (unsigned)((((plane >> 1) * g.ncols_pad + n0 + col) * 16 + (plane & 1) * 8) * 2);
+            b_lds[i] = lds_at(plane, col, BPL);
         }
         f32x8 ra[AL];
         u32x4 rb[BL], rbl[BL];
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(512) void igemm_conv_x3_ws(const float *__restrict_
             __bf16 *As = lds + (s & 1) * BUF, *Bs = As + 2 * A_IMG;
 #pragma unroll
             for (int j = 0; j < AL; ++j) {
-                const int a_at = u * APL + (rrow + RPP * j) * 8;
+                const int a_at = lds_at(u, rrow + RPP * j, APL);
                 const float v[8] = {ra[j][0], ra[j][1], ra[j][2], ra[j][3], ra[j][4], ra[j][5], ra[j][6], ra[j][7]};
                 acg_u32x4 hi, lo;
                 acg_split8(v, hi, lo);
@@ -156,59 +157,51 @@ __global__ __launch_bounds__(512) void igemm_conv_x3_ws(const float *__restrict_
     // ---------------------------------------------------------------------- consumers
     __builtin_amdgcn_s_setprio(2);
     const int wm = wave >> 1, wn = wave & 1;
-    constexpr int TM = 64, TN = 64, MB = 2, NB = 2;
-    f32x16 acc[MB][NB];
+    constexpr int TM = 64, TN = 64;
+    f32x4 acc[4][4];
 #pragma unroll
-    for (int i = 0; i < MB; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < NB; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int pl = lane >> 4, lr = lane & 15;
     for (int s = 0; s < S; ++s) {
         __syncthreads();
         const __bf16 *As = lds + (s & 1) * BUF, *Bs = As + 2 * A_IMG;
+        bf16x8 a[4], al[4], b[4], bl[4];
 #pragma unroll
-        for (int kc = 0; kc < NKC; ++kc) {
-            bf16x8 a[MB], b[NB], al[MB], bl[NB];
-#pragma unroll
-            for (int i = 0; i < MB; ++i) {
-                const int at = (kc * 2 + (lane >> 5)) * APL + (wm * TM + i * 32 + (lane & 31)) * 8;
-                a[i] = *(const bf16x8 *)&As[at];
-                al[i] = *(const bf16x8 *)&As[A_IMG + at];
-            }
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int bt = (kc * 2 + (lane >> 5)) * BPL + (wn * TN + j * 32 + (lane & 31)) * 8;
-                b[j] = *(const bf16x8 *)&Bs[bt];
-                bl[j] = *(const bf16x8 *)&Bs[B_IMG + bt];
-            }
-#pragma unroll
-            for (int i = 0; i < MB; ++i)
-#pragma unroll
-                for (int j = 0; j < NB; ++j) { // small cross terms first, the leading term last
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], b[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-                }
+        for (int i = 0; i < 4; ++i) {
+            const int at = lds_at(pl, wm * TM + i * 16 + lr, APL);
+            a[i] = *(const bf16x8 *)&As[at];
+            al[i] = *(const bf16x8 *)&As[A_IMG + at];
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int bt = lds_at(pl, wn * TN + j * 16 + lr, BPL);
+            b[j] = *(const bf16x8 *)&Bs[bt];
+            bl[j] = *(const bf16x8 *)&Bs[B_IMG + bt];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], b[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
     }
     __builtin_amdgcn_s_setprio(0);
-
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int co = n0 + wn * TN + j * 32 + (lane & 31);
+    for (int j = 0; j < 4; ++j) {
+        const int co = n0 + wn * TN + j * 16 + lr;
         const bool cok = co < g.Cout;
         const float bv = (bias != nullptr && cok) ? bias[co] : 0.f;
 #pragma unroll
-        for (int i = 0; i < MB; ++i) {
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const long long off = out_off[row];
+            for (int r = 0; r < 4; ++r) {
+                const long long off = out_off[wm * TM + i * 16 + 4 * pl + r];
                 if (cok && off >= 0) out[off + co] = acg_apply_act(acc[i][j][r] + bv, g.act);
             }
-        }
     }
 }
 
