@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
                     } else {
                         ok = ok && (unsigned)ix < (unsigned)g.Win;
                     }
-                    const unsigned off = ok ? (unsigned)((rowbase + ix) * g.Cin + ci) * 4u : 0xFFFFFFFFu;
+                    const unsigned off = acg_masked_off((unsigned)((rowbase + ix) * g.Cin + ci) * 4u, ok);
                     rx[l][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx_, off, 0, 0));
                 }
             } else {
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
                     } else {
                         ok = ok && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
                     }
-                    const unsigned off = ok ? (unsigned)(((n * g.Hin + iy) * g.Win + ix) * g.Cin + ci) * 4u : 0xFFFFFFFFu;
+                    const unsigned off = acg_masked_off((unsigned)(((n * g.Hin + iy) * g.Win + ix) * g.Cin + ci) * 4u, ok);
                     rx[l][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx_, off, 0, 0));
                     if (++gx == g.Wg) { gx = 0; if (++gy == g.Hg) { gy = 0; ++n; } }
                 }
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
             const unsigned base = (unsigned)((int)m * g.Cg + co) * 4u, step = (unsigned)g.Cg * 4u;
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
-                const unsigned off = (uok && (full || m + p < mend)) ? base + p * step : 0xFFFFFFFFu;
+                const unsigned off = acg_masked_off(base + p * step, uok && (full || m + p < mend));
                 rd[l][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd_, off, 0, 0));
             }
         }

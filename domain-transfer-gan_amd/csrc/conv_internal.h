@@ -72,6 +72,15 @@ int acg_wgrad_bf16_launch(const float *x, const float *dy, float *part, const WG
 // v_pk_add_f32: 20 VALU instructions per 8 values (a whole-vector __builtin_convertvector on gathered scalars
 // compiles to one conversion per element).
 typedef unsigned acg_u32x4 __attribute__((ext_vector_type(4)));
+// byte offset of a buffer load, or 0xFFFFFFFF (range-checked by the buffer resource -> zeros) for a masked lane.
+// Bit arithmetic on purpose: with `ok ? off : ~0u` LLVM sinks the load into both arms of a branch and separates the two
+// copies with s_waitcnt vmcnt(0) (same destination registers), so every load of a stage pays a full memory latency —
+// measured on the weight-gradient loaders: 0.89 -> 0.72 ms.
+__device__ __forceinline__ unsigned acg_masked_off(unsigned off, bool ok)
+{
+    const unsigned keep = 0u - (unsigned)ok;
+    return (off & keep) | ~keep;
+}
 __device__ __forceinline__ void acg_split8(const float (&v)[8], acg_u32x4 &hi, acg_u32x4 &lo)
 {
     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));

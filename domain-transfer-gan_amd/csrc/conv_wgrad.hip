@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void wgrad_f32(const float *__restrict__ x, co
                 } else {
                     ok = ok && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
                 }
-                const unsigned off = ok ? (unsigned)(((xn[j] * g.Hin + iy) * g.Win + ix) * g.Cin + ci) * 4u : 0xFFFFFFFFu;
+                const unsigned off = acg_masked_off((unsigned)(((xn[j] * g.Hin + iy) * g.Win + ix) * g.Cin + ci) * 4u, ok);
                 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx_, off, 0, 0));
             }
             rx[j] = v;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void wgrad_f32(const float *__restrict__ x, co
             const int r = idx / (BCO / 4), c4 = idx - r * (BCO / 4);
             const long long m = k0 + r;
             const int co = co0 + c4 * 4;
-            const unsigned off = (m < mend && co < g.Cg) ? (unsigned)((int)m * g.Cg + co) * 4u : 0xFFFFFFFFu;
+            const unsigned off = acg_masked_off((unsigned)((int)m * g.Cg + co) * 4u, m < mend && co < g.Cg);
             rd[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd_, off, 0, 0));
         }
     };

@@ -224,3 +224,4 @@ int acg_igemm_x3_ws_launch(const float *in, const void *wp, const float *bias, f
     ACG_CHECK_LAUNCH("igemm_conv_x3_ws");
     return ACG_OK;
 }
+

@@ -31,6 +31,10 @@ CONV_CASES = [
     (4, 1, 1, "zero", 256, 256, 1, 6, 6),
     (3, 2, 1, "zero", 64, 128, 1, 12, 12),
     (3, 1, 1, "zero", 6, 40, 1, 20, 20),
+    # 3x3 stride-1 128-wide layers: the row-taps weight-gradient kernel (32-pixel row segments, partial tails)
+    (3, 1, 1, "zero", 128, 128, 2, 9, 37),
+    (3, 1, 1, "reflect", 64, 128, 1, 6, 40),
+    (3, 1, 0, "zero", 128, 256, 1, 10, 34),
 ]
 
 
