@@ -75,6 +75,20 @@ __global__ __launch_bounds__(256) void wgrad_f32(const float *__restrict__ x, co
         xy[j] = rr / g.Wg;
         xx[j] = rr - xy[j] * g.Wg;
     }
+    // thin layout: column quad c4 of tile tci = tap 8*tci + c4 (channels 0..3) — a per-lane tap, looked up ONCE here:
+    // inside the stage loop the table fetch is a vector load whose s_waitcnt vmcnt(0) would serialize the gathers
+    int tyj[XL], txj[XL];
+    bool tokj[XL];
+#pragma unroll
+    for (int j = 0; j < XL; ++j) {
+        tyj[j] = ty; txj[j] = tx; tokj[j] = true;
+        if (BCI == 32 && g.thin) {
+            const int t = tci * 8 + (tid + 256 * j) % (BCI / 4);
+            tokj[j] = t < taps.n;
+            tyj[j] = taps.dy[tokj[j] ? t : 0];
+            txj[j] = taps.dx[tokj[j] ? t : 0];
+        }
+    }
     auto load_stage = [&](long long k0) {
 #pragma unroll
         for (int j = 0; j < XL; ++j) {
@@ -84,15 +98,12 @@ __global__ __launch_bounds__(256) void wgrad_f32(const float *__restrict__ x, co
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             int ci = ci0 + c4 * 4;
             bool cok = ci < g.Cin;
-            if (BCI == 32 && g.thin) { // column quad c4 of tile tci = tap 8*tci + c4, channels 0..3
-                const int t = tci * 8 + c4;
-                cok = t < taps.n;
-                ty = taps.dy[cok ? t : 0];
-                tx = taps.dx[cok ? t : 0];
+            if (BCI == 32 && g.thin) {
+                cok = tokj[j];
                 ci = 0;
             }
             {
-                int iy = xy[j] * g.is + ty, ix = xx[j] * g.is + tx;
+                int iy = xy[j] * g.is + tyj[j], ix = xx[j] * g.is + txj[j];
                 bool ok = m < mend && cok;
                 if (g.reflect) {
                     iy = iy < 0 ? -iy : iy;
