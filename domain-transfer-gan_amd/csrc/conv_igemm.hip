@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void igemm_conv_f32(const float *__restrict__ 
                 ok = ok && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
                 pix = a_row[j] + ty * g.Win + tx;
             }
-            const unsigned off = ok ? (unsigned)(pix * g.Cin + coff) * 4u : 0xFFFFFFFFu;
+            const unsigned off = acg_masked_off((unsigned)(pix * g.Cin + coff) * 4u, ok);
             ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);
         }
         const unsigned soff = (unsigned)(((tw * g.bk8 + (c0 >> 3)) * g.ncols_pad) * 8) * 4u;

@@ -118,9 +118,9 @@ __global__ __launch_bounds__(512) void igemm_conv_x3_ws(const float *__restrict_
                     ok = ok && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
                     pix = a_row[j] + ty * g.Win + tx;
                 }
-                const unsigned off = ok ? (unsigned)(pix * g.Cin + c0 + 8 * u) * 4u : 0xFFFFFFFFu;
-                const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);
-                const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? off + 16u : 0xFFFFFFFFu, 0, 0);
+                const unsigned off = (unsigned)(pix * g.Cin + c0 + 8 * u) * 4u;
+                const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off, ok), 0, 0);
+                const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off + 16u, ok), 0, 0);
                 const f32x4 flo = __builtin_bit_cast(f32x4, lo), fhi = __builtin_bit_cast(f32x4, hi);
                 ra[j] = (f32x8){flo[0], flo[1], flo[2], flo[3], fhi[0], fhi[1], fhi[2], fhi[3]};
             }
