@@ -675,6 +675,28 @@ extern "C" int acg_conv2d_fwd(const acg_conv_desc *d, const float *x, const floa
     return acg_igemm_launch(x, wf, bias, y, g, t, st);
 }
 
+// Forward convolution that ALSO emits per-128-pixel-tile (mean, M2) of its output for the InstanceNorm behind it
+// (modules.py:24-31 computes those statistics from the conv output in a separate pass).  Only the wave-specialised
+// bf16x3 kernel implements it: 128-column tiles, Cin % 32 == 0, Ho*Wo % 128 == 0.  stats: [N][Ho*Wo/128][2][Co].
+extern "C" int acg_conv2d_fwd_stats_supported(const acg_conv_desc *d)
+{
+    if (d == nullptr || g_acg_precision != ACG_PREC_BF16X3 || g_acg_conv_impl != ACG_IMPL_MFMA) return 0;
+    if (thin_in(d) || thin_out(d) || d->Co < 128 || d->Ci % 32 != 0) return 0;
+    return ((long long)d->Ho * d->Wo) % 128 == 0 ? 1 : 0;
+}
+
+extern "C" int acg_conv2d_fwd_stats(const acg_conv_desc *d, const float *x, const float *wf, const float *bias, float *y,
+                                    float *stats, void *stream)
+{
+    int rc = check_desc(d, "acg_conv2d_fwd_stats");
+    if (rc) return rc;
+    ACG_REQUIRE(acg_conv2d_fwd_stats_supported(d) && stats != nullptr, "acg_conv2d_fwd_stats: unsupported shape or mode");
+    Geom g; Taps t;
+    fwd_geom(d, &g, &t, ACG_ACT_NONE);
+    const Taps tp = acg_taps_pack(t);
+    return acg_igemm_x3_ws_launch(x, wf, bias, y, g, tp, g.w_elems, (hipStream_t)stream, stats);
+}
+
 extern "C" size_t acg_conv2d_bwd_data_workspace_bytes(const acg_conv_desc *d)
 {
     if (d == nullptr || d->pad_mode != ACG_PAD_REFLECT || d->pad == 0) return 0;

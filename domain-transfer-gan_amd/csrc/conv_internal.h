@@ -60,7 +60,7 @@ void acg_wgrad_tiles(int Ci, int Co, int *bci, int *bco);
 
 extern int g_acg_precision;
 int acg_igemm_x3_ws_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g, const Taps &t,
-                           long long n_w_elems, hipStream_t st);
+                           long long n_w_elems, hipStream_t st, float *stats = nullptr);
 int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g, const Taps &t,
                           int bn, long long n_w_elems, hipStream_t st);
 int acg_wgrad_bf16_launch(const float *x, const float *dy, float *part, const WGeom &g, const Taps &t, int bci, int bco,

@@ -31,14 +31,18 @@ constexpr int BUF = 2 * A_IMG + 2 * B_IMG;            // A hi, A lo, B hi, B lo
 __device__ __forceinline__ int lds_at(int plane, int row, int pl) { return plane * pl + ((row ^ (2 * plane)) * 8); }
 }
 
-template <bool REFLECT>
-__global__ __launch_bounds__(512) void igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
+// 4 waves per SIMD = two 8-wave workgroups per CU: the register budget is 128 VGPRs.  The statistics epilogue (STATS)
+// would raise the allocation to 142 and halve the occupancy of the main loop; capped, it spills a few values around
+// the epilogue only (the loops are scratch-free), and the plain variant is untouched (124).
+template <bool REFLECT, bool STATS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
                                                         const float *__restrict__ bias, float *__restrict__ out,
                                                         Geom g, Taps taps, unsigned in_bytes, unsigned w_bytes,
-                                                        unsigned w_lo_bytes)
+                                                        unsigned w_lo_bytes, float *__restrict__ stats)
 {
     __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF];
     __shared__ long long out_off[BM];
+    __shared__ float red[2][2][64]; // [wn][wm][column]: cross-wave fold of the per-tile statistics
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -190,6 +194,61 @@ __global__ __launch_bounds__(512) void igemm_conv_x3_ws(const float *__restrict_
             }
     }
     __builtin_amdgcn_s_setprio(0);
+    if constexpr (STATS) {
+        // Per-tile (mean, M2) of the 128 output pixels of every channel, for the InstanceNorm that follows: the norm's
+        // statistics pass then merges 128-pixel partials (Chan) instead of re-reading the tensor.  Two passes over the
+        // accumulators (mean first, then squared deviations), lanes -> wave by shuffles, the two waves of a column by LDS.
+        // The launcher guarantees full tiles inside one image (GH*GW % 128 == 0) and act == NONE.
+        float bv[4], mu[4], q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int co = n0 + wn * TN + j * 16 + lr;
+            bv[j] = (bias != nullptr && co < g.Cout) ? bias[co] : 0.f;
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum += acc[i][j][r] + bv[j];
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            if (pl == 0) red[wn][wm][j * 16 + lr] = sum;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            mu[j] = (red[wn][0][j * 16 + lr] + red[wn][1][j * 16 + lr]) * (1.f / BM);
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dlt = acc[i][j][r] + bv[j] - mu[j];
+                    sq += dlt * dlt;
+                }
+            sq += __shfl_xor(sq, 16, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            q[j] = sq;
+        }
+        __syncthreads();
+        if (pl == 0)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[wn][wm][j * 16 + lr] = q[j];
+        __syncthreads();
+        if (wm == 0 && pl == 0) {
+            const int nchunks = GHW / BM;
+            const long long chunk = m0 / BM; // = image * nchunks + tile within the image
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = n0 + wn * TN + j * 16 + lr;
+                if (co < g.Cout) {
+                    float *o = stats + (chunk * 2) * g.Cout + co;
+                    o[0] = mu[j];
+                    o[g.Cout] = red[wn][0][j * 16 + lr] + red[wn][1][j * 16 + lr];
+                }
+            }
+            (void)nchunks;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int co = n0 + wn * TN + j * 16 + lr;
@@ -207,7 +266,7 @@ __global__ __launch_bounds__(512) void igemm_conv_x3_ws(const float *__restrict_
 
 // same contract as acg_igemm_bf16_launch for bn == 128, Cin % 32 == 0, ACG_PREC_BF16X3
 int acg_igemm_x3_ws_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g0, const Taps &t,
-                           long long n_w_elems, hipStream_t st)
+                           long long n_w_elems, hipStream_t st, float *stats)
 {
     Geom g = g0;
     g.thin = 0;
@@ -216,11 +275,13 @@ int acg_igemm_x3_ws_launch(const float *in, const void *wp, const float *bias, f
     const long long in_bytes = nimg * g.Hin * g.Win * g.Cin * 4;
     const long long w_bytes = n_w_elems * 2 * 2;
     ACG_REQUIRE(in_bytes < (1LL << 32) && w_bytes < (1LL << 32), "igemm_conv_x3_ws: operand exceeds the 4 GiB buffer-addressing limit");
+    ACG_REQUIRE(stats == nullptr || (((long long)g.GH * g.GW) % BM == 0 && g.act == ACG_ACT_NONE && g.os == 1),
+                "igemm_conv_x3_ws: per-tile statistics need whole 128-pixel tiles per image and no activation");
     const unsigned inb = (unsigned)in_bytes, wb = (unsigned)w_bytes, wlo = (unsigned)(n_w_elems * 2);
-    if (g.reflect)
-        hipLaunchKernelGGL((igemm_conv_x3_ws<true>), grid, dim3(512), 0, st, in, (const __bf16 *)wp, bias, out, g, t, inb, wb, wlo);
-    else
-        hipLaunchKernelGGL((igemm_conv_x3_ws<false>), grid, dim3(512), 0, st, in, (const __bf16 *)wp, bias, out, g, t, inb, wb, wlo);
+#define X3_WS(R, S) hipLaunchKernelGGL((igemm_conv_x3_ws<R, S>), grid, dim3(512), 0, st, in, (const __bf16 *)wp, bias, out, g, t, inb, wb, wlo, stats)
+    if (g.reflect) { if (stats) X3_WS(true, true); else X3_WS(true, false); }
+    else { if (stats) X3_WS(false, true); else X3_WS(false, false); }
+#undef X3_WS
     ACG_CHECK_LAUNCH("igemm_conv_x3_ws");
     return ACG_OK;
 }

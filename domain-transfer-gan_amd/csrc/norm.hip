@@ -8,7 +8,9 @@
 // All access is float4 over channels, consecutive lanes on consecutive channels (coalesced).
 #include "common.h"
 
-#define NORM_ROWS 1024 // pixels per block
+#define EW_UNROLL 4   // independent 16-byte loads per stream and thread in the element-wise passes
+#define NORM_ROWS 256 // pixels per block of the reduction passes: 32 images x 64 chunks = 2048 blocks at 128x128
+                      // (1024 gave 512 blocks = 2 per CU with one 16-byte load in flight per thread: ~2 TB/s)
 
 __device__ __forceinline__ void chan_merge(float &na, float &ma, float &sa, float nb, float mb, float sb)
 {
@@ -36,6 +38,7 @@ __global__ __launch_bounds__(256) void norm_stats_partial(const float *__restric
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     float cnt = 0.f;
     if (rl < rows_par)
+#pragma unroll 4
         for (long long r = r0 + rl; r < r1; r += rows_par) {
             const f32x4 v = *(const f32x4 *)(xg + r * C + c4 * 4);
             s1 += v;
@@ -68,20 +71,37 @@ __global__ __launch_bounds__(256) void norm_stats_partial(const float *__restric
     }
 }
 
-__global__ void norm_stats_final(const float *__restrict__ part, int G, long long P, int C, int nchunks, float eps,
-                                 int unbiased, float *__restrict__ mean, float *__restrict__ rstd,
-                                 float *__restrict__ run_mean, float *__restrict__ run_var, float momentum)
+// One workgroup per (group, 32 channels): 8 lanes share a channel and merge every 8th chunk each, then the 8 partial
+// (n, mean, M2) triples are merged in fixed order through LDS.  (One thread per channel walking all chunks serially
+// took 52 us per call once the chunks shrank to 128-256 pixels: 128 dependent round trips to L2.)
+#define FIN_CH 32
+#define FIN_KQ 8
+__global__ __launch_bounds__(256) void norm_stats_final(const float *__restrict__ part, int G, long long P, int C,
+                                                        int nchunks, float eps, int unbiased, float *__restrict__ mean,
+                                                        float *__restrict__ rstd, float *__restrict__ run_mean,
+                                                        float *__restrict__ run_var, float momentum, int rows_per_chunk)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G * C) return;
-    const int g = i / C, c = i - g * C;
+    __shared__ float sn[FIN_KQ][FIN_CH], sm[FIN_KQ][FIN_CH], ss[FIN_KQ][FIN_CH];
+    const int cc = threadIdx.x % FIN_CH, kq = threadIdx.x / FIN_CH;
+    const int cblocks = (C + FIN_CH - 1) / FIN_CH;
+    const int g = blockIdx.x / cblocks, c = (blockIdx.x % cblocks) * FIN_CH + cc;
     float n = 0.f, m = 0.f, s = 0.f;
-    for (int k = 0; k < nchunks; ++k) {
-        long long rows = P - (long long)k * NORM_ROWS;
-        if (rows > NORM_ROWS) rows = NORM_ROWS;
-        const float *p = part + ((long long)(g * nchunks + k) * 2) * C + c;
-        chan_merge(n, m, s, (float)rows, p[0], p[C]);
+    if (c < C) {
+#pragma unroll 4
+        for (int k = kq; k < nchunks; k += FIN_KQ) {
+            long long rows = P - (long long)k * rows_per_chunk;
+            if (rows > rows_per_chunk) rows = rows_per_chunk;
+            const float *p = part + ((long long)(g * nchunks + k) * 2) * C + c;
+            chan_merge(n, m, s, (float)rows, p[0], p[C]);
+        }
     }
+    sn[kq][cc] = n; sm[kq][cc] = m; ss[kq][cc] = s;
+    __syncthreads();
+    if (kq != 0 || c >= C) return;
+    n = 0.f; m = 0.f; s = 0.f;
+#pragma unroll
+    for (int q = 0; q < FIN_KQ; ++q) chan_merge(n, m, s, sn[q][cc], sm[q][cc], ss[q][cc]);
+    const int i = g * C + c;
     const float denom = unbiased ? (float)(P - 1) : (float)P;
     mean[i] = m;
     rstd[i] = rsqrtf(s / denom + eps);
@@ -91,30 +111,48 @@ __global__ void norm_stats_final(const float *__restrict__ part, int G, long lon
     }
 }
 
+// ACT / HAS_RES are template parameters: with run-time switches the body is a web of scalar branches with
+// s_waitcnt vmcnt(0) between them and the loads of a thread are issued one at a time (2.7-3.6 TB/s); specialised, all
+// loads of a thread go out back to back like a streaming copy.
+template <int ACT, bool HAS_RES>
 __global__ __launch_bounds__(256) void norm_apply_kernel(const float *__restrict__ x, const float *__restrict__ mean,
                                                          const float *__restrict__ rstd,
                                                          const float *__restrict__ gamma,
                                                          const float *__restrict__ beta, int gstride,
                                                          const float *__restrict__ res, float *__restrict__ y,
-                                                         long long P, int C, int act)
+                                                         long long P, int C)
 {
     const int C4 = C / 4;
     const int g = blockIdx.y;
     const long long total = P * C4;
     const long long base = (long long)g * P * C;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4) * 4;
-        const f32x4 v = *(const f32x4 *)(x + base + i * 4);
-        const f32x4 mu = *(const f32x4 *)(mean + g * C + c);
-        const f32x4 rs = *(const f32x4 *)(rstd + g * C + c);
-        const f32x4 ga = *(const f32x4 *)(gamma + g * gstride + c);
-        const f32x4 be = *(const f32x4 *)(beta + g * gstride + c);
-        f32x4 o = (v - mu) * rs * ga + be;
-        if (res != nullptr) o += *(const f32x4 *)(res + base + i * 4);
+    // one contiguous run of EW_UNROLL x 256 float4 per workgroup, a thread's elements 256 float4 apart
+    const long long i0 = (long long)blockIdx.x * (256 * EW_UNROLL) + threadIdx.x;
+    const bool inv = 256 % C4 == 0; // then the thread's channel quad is the same for all its elements
+    f32x4 v[EW_UNROLL], rv[EW_UNROLL];
+    bool ok[EW_UNROLL];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = acg_apply_act(o[k], act);
-        *(f32x4 *)(y + base + i * 4) = o;
+    for (int u = 0; u < EW_UNROLL; ++u) {
+        ok[u] = i0 + u * 256 < total;
+        const long long o = base + (ok[u] ? i0 + u * 256 : 0) * 4;
+        v[u] = *(const f32x4 *)(x + o);
+        if (HAS_RES) rv[u] = *(const f32x4 *)(res + o);
+    }
+    int c = (int)(i0 % C4) * 4;
+    f32x4 mu = *(const f32x4 *)(mean + g * C + c), rs = *(const f32x4 *)(rstd + g * C + c);
+    f32x4 ga = *(const f32x4 *)(gamma + g * gstride + c), be = *(const f32x4 *)(beta + g * gstride + c);
+#pragma unroll
+    for (int u = 0; u < EW_UNROLL; ++u) {
+        if (!inv && u > 0) {
+            c = (int)((i0 + u * 256) % C4) * 4;
+            mu = *(const f32x4 *)(mean + g * C + c); rs = *(const f32x4 *)(rstd + g * C + c);
+            ga = *(const f32x4 *)(gamma + g * gstride + c); be = *(const f32x4 *)(beta + g * gstride + c);
+        }
+        f32x4 o = (v[u] - mu) * rs * ga + be;
+        if (HAS_RES) o += rv[u];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = acg_apply_act(o[k], ACT);
+        if (ok[u]) *(f32x4 *)(y + base + (i0 + u * 256) * 4) = o;
     }
 }
 
@@ -147,6 +185,7 @@ __global__ __launch_bounds__(256) void norm_bwd_partial(const float *__restrict_
             ga = *(const f32x4 *)(gamma + g * gstride + c4 * 4);
             be = *(const f32x4 *)(beta + g * gstride + c4 * 4);
         }
+#pragma unroll 4
         for (long long r = r0 + rl; r < r1; r += rows_par) {
             const long long o = base + r * C + c4 * 4;
             f32x4 gy = *(const f32x4 *)(dy + o);
@@ -179,17 +218,28 @@ __global__ __launch_bounds__(256) void norm_bwd_partial(const float *__restrict_
 }
 
 // sums[(g*2 + {0,1})*C + c] = sum over chunks (fixed order)
-__global__ void norm_bwd_final(const float *__restrict__ part, int G, int C, int nchunks, float *__restrict__ sums)
+__global__ __launch_bounds__(256) void norm_bwd_final(const float *__restrict__ part, int G, int C, int nchunks,
+                                                      float *__restrict__ sums)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G * C) return;
-    const int g = i / C, c = i - g * C;
+    __shared__ float sa[FIN_KQ][FIN_CH], sb[FIN_KQ][FIN_CH];
+    const int cc = threadIdx.x % FIN_CH, kq = threadIdx.x / FIN_CH;
+    const int cblocks = (C + FIN_CH - 1) / FIN_CH;
+    const int g = blockIdx.x / cblocks, c = (blockIdx.x % cblocks) * FIN_CH + cc;
     float a = 0.f, b = 0.f;
-    for (int k = 0; k < nchunks; ++k) {
-        const float *p = part + ((long long)(g * nchunks + k) * 2) * C + c;
-        a += p[0];
-        b += p[C];
+    if (c < C) {
+#pragma unroll 4
+        for (int k = kq; k < nchunks; k += FIN_KQ) {
+            const float *p = part + ((long long)(g * nchunks + k) * 2) * C + c;
+            a += p[0];
+            b += p[C];
+        }
     }
+    sa[kq][cc] = a; sb[kq][cc] = b;
+    __syncthreads();
+    if (kq != 0 || c >= C) return;
+    a = 0.f; b = 0.f;
+#pragma unroll
+    for (int q = 0; q < FIN_KQ; ++q) { a += sa[q][cc]; b += sb[q][cc]; }
     sums[(g * 2) * C + c] = a;
     sums[(g * 2 + 1) * C + c] = b;
 }
@@ -214,41 +264,103 @@ __global__ void norm_bwd_params(const float *__restrict__ sums, int G, int C, in
 }
 
 // backward pass 2: dx = gamma*rstd*(gy - S1/P - xhat*S2/D) ; dres = gy
+template <int ACT, bool RECOMPUTE, bool HAS_DRES> // RECOMPUTE: activation mask from x (y == nullptr); see norm_apply_kernel
 __global__ __launch_bounds__(256) void norm_bwd_apply(const float *__restrict__ dy, const float *__restrict__ y,
                                                       const float *__restrict__ x, const float *__restrict__ mean,
                                                       const float *__restrict__ rstd,
                                                       const float *__restrict__ gamma,
                                                       const float *__restrict__ beta, int gstride,
                                                       const float *__restrict__ sums, float *__restrict__ dx,
-                                                      float *__restrict__ dres, long long P, int C, int act,
-                                                      float invP, float invD)
+                                                      float *__restrict__ dres, long long P, int C, float invP,
+                                                      float invD)
 {
     const int C4 = C / 4;
     const int g = blockIdx.y;
     const long long total = P * C4;
     const long long base = (long long)g * P * C;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4) * 4;
-        const long long o = base + i * 4;
-        f32x4 gy = *(const f32x4 *)(dy + o);
-        const f32x4 xv = *(const f32x4 *)(x + o);
-        const f32x4 mu = *(const f32x4 *)(mean + g * C + c);
-        const f32x4 rs = *(const f32x4 *)(rstd + g * C + c);
-        const f32x4 ga = *(const f32x4 *)(gamma + g * gstride + c);
-        if (act != ACG_ACT_NONE) {
-            f32x4 yy;
-            if (y == nullptr) yy = (xv - mu) * rs * ga + *(const f32x4 *)(beta + g * gstride + c);
-            else yy = *(const f32x4 *)(y + o);
+    const long long i0 = (long long)blockIdx.x * (256 * EW_UNROLL) + threadIdx.x;
+    const bool inv = 256 % C4 == 0;
+    f32x4 gv[EW_UNROLL], xv[EW_UNROLL], yv[EW_UNROLL];
+    bool ok[EW_UNROLL];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) gy[k] *= acg_act_grad_from_y(yy[k], act);
-        }
-        const f32x4 s1 = *(const f32x4 *)(sums + (g * 2) * C + c);
-        const f32x4 s2 = *(const f32x4 *)(sums + (g * 2 + 1) * C + c);
-        const f32x4 xh = (xv - mu) * rs;
-        *(f32x4 *)(dx + o) = ga * rs * (gy - s1 * invP - xh * (s2 * invD));
-        if (dres != nullptr) *(f32x4 *)(dres + o) = gy;
+    for (int u = 0; u < EW_UNROLL; ++u) {
+        ok[u] = i0 + u * 256 < total;
+        const long long o = base + (ok[u] ? i0 + u * 256 : 0) * 4;
+        gv[u] = *(const f32x4 *)(dy + o);
+        xv[u] = *(const f32x4 *)(x + o);
+        if (ACT != ACG_ACT_NONE && !RECOMPUTE) yv[u] = *(const f32x4 *)(y + o);
     }
+    int c = (int)(i0 % C4) * 4;
+    f32x4 mu, rs, ga, be = {0.f, 0.f, 0.f, 0.f}, s1, s2;
+    auto params = [&]() {
+        mu = *(const f32x4 *)(mean + g * C + c);
+        rs = *(const f32x4 *)(rstd + g * C + c);
+        ga = *(const f32x4 *)(gamma + g * gstride + c);
+        if (ACT != ACG_ACT_NONE && RECOMPUTE) be = *(const f32x4 *)(beta + g * gstride + c);
+        s1 = *(const f32x4 *)(sums + (g * 2) * C + c) * invP;
+        s2 = *(const f32x4 *)(sums + (g * 2 + 1) * C + c) * invD;
+    };
+    params();
+#pragma unroll
+    for (int u = 0; u < EW_UNROLL; ++u) {
+        if (!inv && u > 0) {
+            c = (int)((i0 + u * 256) % C4) * 4;
+            params();
+        }
+        f32x4 gy = gv[u];
+        const f32x4 xh = (xv[u] - mu) * rs;
+        if (ACT != ACG_ACT_NONE) {
+            const f32x4 yy = RECOMPUTE ? (xv[u] - mu) * rs * ga + be : yv[u]; // same expression as norm_apply_kernel
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gy[k] *= acg_act_grad_from_y(yy[k], ACT);
+        }
+        if (ok[u]) {
+            const long long o = base + (i0 + u * 256) * 4;
+            *(f32x4 *)(dx + o) = ga * rs * (gy - s1 - xh * s2);
+            if (HAS_DRES) *(f32x4 *)(dres + o) = gy;
+        }
+    }
+}
+
+// run-time (act, flags) -> template instance
+#define NORM_ACT_SWITCH(act, M)                                                  \
+    switch (act) {                                                               \
+    case ACG_ACT_RELU: M(ACG_ACT_RELU); break;                                   \
+    case ACG_ACT_LRELU: M(ACG_ACT_LRELU); break;                                 \
+    case ACG_ACT_TANH: M(ACG_ACT_TANH); break;                                   \
+    default: M(ACG_ACT_NONE); break;                                             \
+    }
+
+static void launch_norm_apply(dim3 grid, hipStream_t st, const float *x, const float *mean, const float *rstd,
+                              const float *gamma, const float *beta, int gstride, const float *res, float *y, long long P,
+                              int C, int act)
+{
+#define M(A)                                                                                                              \
+    do {                                                                                                                  \
+        if (res) hipLaunchKernelGGL((norm_apply_kernel<A, true>), grid, dim3(256), 0, st, x, mean, rstd, gamma, beta, gstride, res, y, P, C); \
+        else hipLaunchKernelGGL((norm_apply_kernel<A, false>), grid, dim3(256), 0, st, x, mean, rstd, gamma, beta, gstride, res, y, P, C);   \
+    } while (0)
+    NORM_ACT_SWITCH(act, M)
+#undef M
+}
+
+static void launch_norm_bwd_apply(dim3 grid, hipStream_t st, const float *dy, const float *y, const float *x,
+                                  const float *mean, const float *rstd, const float *gamma, const float *beta, int gstride,
+                                  const float *sums, float *dx, float *dres, long long P, int C, int act, float invP,
+                                  float invD)
+{
+#define L(A, R, D) hipLaunchKernelGGL((norm_bwd_apply<A, R, D>), grid, dim3(256), 0, st, dy, y, x, mean, rstd, gamma, beta, gstride, sums, dx, dres, P, C, invP, invD)
+#define M(A)                                                                         \
+    do {                                                                             \
+        const bool rc = y == nullptr;                                                \
+        if (rc && dres) L(A, true, true);                                            \
+        else if (rc) L(A, true, false);                                              \
+        else if (dres) L(A, false, true);                                            \
+        else L(A, false, false);                                                     \
+    } while (0)
+    NORM_ACT_SWITCH(act, M)
+#undef M
+#undef L
 }
 
 // BatchNorm eval mode: statistics come from the running buffers
@@ -299,16 +411,34 @@ extern "C" int acg_norm_stats(const float *x, int G, size_t P, int C, float eps,
     hipStream_t st = (hipStream_t)stream;
     const int nch = nchunks_of(P);
     hipLaunchKernelGGL(norm_stats_partial, dim3(nch, G), dim3(256), 0, st, x, (long long)P, C, nch, (float *)ws);
-    hipLaunchKernelGGL(norm_stats_final, dim3(acg_cdiv((long)G * C, 256)), dim3(256), 0, st, (const float *)ws, G,
-                       (long long)P, C, nch, eps, unbiased, mean, rstd, run_mean, run_var, momentum);
+    hipLaunchKernelGGL(norm_stats_final, dim3(G * acg_cdiv(C, FIN_CH)), dim3(256), 0, st, (const float *)ws, G,
+                       (long long)P, C, nch, eps, unbiased, mean, rstd, run_mean, run_var, momentum, NORM_ROWS);
     ACG_CHECK_LAUNCH("norm_stats");
+    return ACG_OK;
+}
+
+// Statistics from per-chunk (mean, M2) partials that a producer already holds — acg_conv2d_fwd_stats writes them from
+// its epilogue, one chunk per 128-pixel output tile — merged with the same Chan formula: the x tensor is not re-read.
+// part[((g*nchunks + chunk)*2 + {0:mean,1:M2})*C + c], nchunks = ceil(P / rows_per_chunk).
+extern "C" int acg_norm_stats_from_partials(const float *part, int G, size_t P, int C, int rows_per_chunk, float eps,
+                                            int unbiased, float *mean, float *rstd, void *stream)
+{
+    int rc = check_norm(G, P, C, "acg_norm_stats_from_partials");
+    if (rc) return rc;
+    ACG_REQUIRE(rows_per_chunk > 0 && part != nullptr, "acg_norm_stats_from_partials: bad partials");
+    ACG_REQUIRE(!(unbiased && P < 2), "acg_norm_stats_from_partials: unbiased variance needs P >= 2");
+    const int nch = (int)((P + rows_per_chunk - 1) / rows_per_chunk);
+    hipLaunchKernelGGL(norm_stats_final, dim3(G * acg_cdiv(C, FIN_CH)), dim3(256), 0, (hipStream_t)stream, part, G,
+                       (long long)P, C, nch, eps, unbiased, mean, rstd, (float *)nullptr, (float *)nullptr, 0.f, rows_per_chunk);
+    ACG_CHECK_LAUNCH("norm_stats_final");
     return ACG_OK;
 }
 
 static int ew_blocks(long long total)
 {
-    long long b = (total + 255) / 256;
-    return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+    // exactly one run of EW_UNROLL x 256 float4 per workgroup (the generic loops are grid-stride and take any grid)
+    const long long b = (total + 256 * EW_UNROLL - 1) / (256 * EW_UNROLL);
+    return (int)(b < 1 ? 1 : b);
 }
 
 extern "C" int acg_norm_apply(const float *x, const float *mean, const float *rstd, const float *gamma,
@@ -318,8 +448,8 @@ extern "C" int acg_norm_apply(const float *x, const float *mean, const float *rs
     int rc = check_norm(G, P, C, "acg_norm_apply");
     if (rc) return rc;
     ACG_REQUIRE(gstride == 0 || gstride == C, "acg_norm_apply: gstride must be 0 or C");
-    hipLaunchKernelGGL(norm_apply_kernel, dim3(ew_blocks((long long)P * (C / 4)), G), dim3(256), 0, (hipStream_t)stream,
-                       x, mean, rstd, gamma, beta, gstride, res, y, (long long)P, C, act);
+    launch_norm_apply(dim3(ew_blocks((long long)P * (C / 4)), G), (hipStream_t)stream, x, mean, rstd, gamma, beta, gstride, res,
+                      y, (long long)P, C, act);
     ACG_CHECK_LAUNCH("norm_apply_kernel");
     return ACG_OK;
 }
@@ -340,7 +470,7 @@ extern "C" int acg_norm_bwd_sums(const float *dy, const float *y, const float *x
     ACG_REQUIRE(act == ACG_ACT_NONE || y != nullptr, "acg_norm_bwd_sums: y required");
     hipLaunchKernelGGL(norm_bwd_partial, dim3(nch, G), dim3(256), 0, st, dy, y, x, mean, rstd, (const float *)nullptr,
                        (const float *)nullptr, 0, (long long)P, C, nch, act, (float *)ws);
-    hipLaunchKernelGGL(norm_bwd_final, dim3(acg_cdiv((long)G * C, 256)), dim3(256), 0, st, (const float *)ws, G, C, nch, sums);
+    hipLaunchKernelGGL(norm_bwd_final, dim3(G * acg_cdiv(C, FIN_CH)), dim3(256), 0, st, (const float *)ws, G, C, nch, sums);
     ACG_CHECK_LAUNCH("norm_bwd_sums");
     return ACG_OK;
 }
@@ -355,8 +485,8 @@ extern "C" int acg_norm_bwd_apply(const float *dy, const float *y, const float *
     const float invP = unbiased == 2 ? 0.f : 1.f / (float)Ptot;
     const float invD = unbiased == 2 ? 0.f : (unbiased ? 1.f / (float)(Ptot - 1) : invP);
     ACG_REQUIRE(act == ACG_ACT_NONE || y != nullptr, "acg_norm_bwd_apply: y required");
-    hipLaunchKernelGGL(norm_bwd_apply, dim3(ew_blocks((long long)P * (C / 4)), G), dim3(256), 0, (hipStream_t)stream, dy, y, x,
-                       mean, rstd, gamma, (const float *)nullptr, gstride, sums, dx, dres, (long long)P, C, act, invP, invD);
+    launch_norm_bwd_apply(dim3(ew_blocks((long long)P * (C / 4)), G), (hipStream_t)stream, dy, y, x, mean, rstd, gamma,
+                          (const float *)nullptr, gstride, sums, dx, dres, (long long)P, C, act, invP, invD);
     ACG_CHECK_LAUNCH("norm_bwd_apply");
     return ACG_OK;
 }
@@ -381,7 +511,7 @@ extern "C" int acg_norm_bwd(const float *dy, const float *y, const float *x, con
     ACG_REQUIRE(act == ACG_ACT_NONE || y != nullptr || beta != nullptr, "acg_norm_bwd: y or beta required for the activation mask");
     hipLaunchKernelGGL(norm_bwd_partial, dim3(nch, G), dim3(256), 0, st, dy, y, x, mean, rstd, gamma, beta, gstride,
                        (long long)P, C, nch, act, part);
-    hipLaunchKernelGGL(norm_bwd_final, dim3(acg_cdiv((long)G * C, 256)), dim3(256), 0, st, (const float *)part, G, C,
+    hipLaunchKernelGGL(norm_bwd_final, dim3(G * acg_cdiv(C, FIN_CH)), dim3(256), 0, st, (const float *)part, G, C,
                        nch, sums);
     if (dgamma != nullptr || dbeta != nullptr)
         hipLaunchKernelGGL(norm_bwd_params, dim3(acg_cdiv((long)G * C, 256)), dim3(256), 0, st, (const float *)sums, G, C,
@@ -389,8 +519,8 @@ extern "C" int acg_norm_bwd(const float *dy, const float *y, const float *x, con
     // unbiased == 2: statistics are constants (BatchNorm eval mode) -> dx = gamma * rstd * gy
     const float invP = unbiased == 2 ? 0.f : 1.f / (float)P;
     const float invD = unbiased == 2 ? 0.f : (unbiased ? 1.f / (float)(P - 1) : invP);
-    hipLaunchKernelGGL(norm_bwd_apply, dim3(ew_blocks((long long)P * (C / 4)), G), dim3(256), 0, st, dy, y, x, mean, rstd,
-                       gamma, beta, gstride, (const float *)sums, dx, dres, (long long)P, C, act, invP, invD);
+    launch_norm_bwd_apply(dim3(ew_blocks((long long)P * (C / 4)), G), st, dy, y, x, mean, rstd, gamma, beta, gstride,
+                          (const float *)sums, dx, dres, (long long)P, C, act, invP, invD);
     ACG_CHECK_LAUNCH("norm_bwd");
     return ACG_OK;
 }

@@ -63,12 +63,12 @@ class Conv2d(nn.Conv2d, _Cached):
     def packed(self):
         return self._cached(lambda: ops.PackedConv(self.weight, self.bias, cpad(self.in_channels), cpad(self.out_channels)))
 
-    def forward_nhwc(self, x, act=ACT_NONE, reflect_pad=0):
+    def forward_nhwc(self, x, act=ACT_NONE, reflect_pad=0, want_stats=False):
         if reflect_pad:
             pad, mode = reflect_pad, PAD_REFLECT
         else:
             pad, mode = self.padding[0], PAD_ZERO
-        return ops.Conv2dFn.apply(x, self.weight, self.bias, self.packed(), self.stride[0], pad, mode, act)
+        return ops.Conv2dFn.apply(x, self.weight, self.bias, self.packed(), self.stride[0], pad, mode, act, want_stats)
 
     def forward(self, input):
         return ops.ToNCHW.apply(self.forward_nhwc(ops.ToNHWC.apply(input)), self.out_channels)
@@ -299,8 +299,8 @@ def run_sequence(mods, x, C, z=None, res=None):
             if reflect:
                 raise NotImplementedError("reflection pad before ConvTranspose2d")
             x = conv.forward_nhwc(x, cact)
-        else:
-            x = conv.forward_nhwc(x, cact, reflect)
+        else:  # an (Cond)InstanceNorm right behind the conv can take its statistics from the conv epilogue
+            x = conv.forward_nhwc(x, cact, reflect, isinstance(norm, (InstanceNorm, CondInstanceNorm)))
         reflect = 0
         C = conv.out_channels
         if norm is not None:

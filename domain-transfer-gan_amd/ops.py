@@ -8,6 +8,7 @@ carried as torch tensors of shape (N, H, W, Cp) — or (N, Cp) for latent / MLP 
 There is no CPU path: tensors must live on a ROCm device and the library must load.
 """
 import ctypes
+import os
 
 import torch
 
@@ -205,11 +206,28 @@ def conv_desc(N, Hi, Wi, Ci, Co, K, stride, pad, pad_mode, Cir=0, Cor=0):
     return ConvDesc(N, Hi, Wi, Ci, Ho, Wo, Co, K, stride, pad, pad_mode, Cir, Cor)
 
 
+# Hand-off of the per-tile statistics a convolution epilogue produced (acg_conv2d_fwd_stats) to the InstanceNorm /
+# CondInstanceNorm that consumes its output next: (data_ptr of the conv output, partials tensor, rows per chunk).
+_CONV_STATS = None
+STATS_ROWS = 128
+CONV_STATS_ENABLED = os.environ.get("ACGAN_NO_CONV_STATS") is None  # A/B switch
+
+
+def take_conv_stats(x):
+    global _CONV_STATS
+    st, _CONV_STATS = _CONV_STATS, None
+    if st is not None and st[0] == x.data_ptr():
+        return st[1]
+    return None
+
+
 class Conv2dFn(torch.autograd.Function):
-    """nn.Conv2d (+ preceding ReflectionPad2d) + bias + fused activation."""
+    """nn.Conv2d (+ preceding ReflectionPad2d) + bias + fused activation.  want_stats: the caller runs an
+    (Cond)InstanceNorm on the output next — where the kernel supports it the epilogue emits that norm's per-tile
+    partial statistics, saving the norm one read of the tensor."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, packed, stride, pad, pad_mode, act):
+    def forward(ctx, x, weight, bias, packed, stride, pad, pad_mode, act, want_stats=False):
         x = x.contiguous()
         _check(x)
         N, Hi, Wi, Ci = x.shape
@@ -223,8 +241,16 @@ class Conv2dFn(torch.autograd.Function):
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        _lib.call("acg_conv2d_fwd", ctypes.byref(d), _ptr(x), _ptr(packed.wf), _ptr(packed.bias if bias is not None else None),
-                  _ptr(y), act, _stream())
+        global _CONV_STATS
+        _CONV_STATS = None
+        if want_stats and CONV_STATS_ENABLED and act == ACT_NONE and _lib.query("acg_conv2d_fwd_stats_supported", ctypes.byref(d)):
+            part = torch.empty((N, (d.Ho * d.Wo) // STATS_ROWS, 2, packed.Co), device=x.device, dtype=torch.float32)
+            _lib.call("acg_conv2d_fwd_stats", ctypes.byref(d), _ptr(x), _ptr(packed.wf),
+                      _ptr(packed.bias if bias is not None else None), _ptr(y), _ptr(part), _stream())
+            _CONV_STATS = (y.data_ptr(), part)
+        else:
+            _lib.call("acg_conv2d_fwd", ctypes.byref(d), _ptr(x), _ptr(packed.wf), _ptr(packed.bias if bias is not None else None),
+                      _ptr(y), act, _stream())
         if timed:
             e1.record()
             CONV_TIMER.events.append((e0, e1))
@@ -256,7 +282,7 @@ class Conv2dFn(torch.autograd.Function):
             ws = workspace(nb)
             _lib.call("acg_conv2d_bwd_weight", ctypes.byref(d), _ptr(x), _ptr(g), _ptr(dw), _ptr(db), pk.Or, pk.Ir, _ptr(ws),
                       nb, st)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 class ConvTranspose2dFn(torch.autograd.Function):
@@ -346,10 +372,15 @@ class NormAct(torch.autograd.Function):
         if kind == "bn_eval":  # running statistics (real length) -> padded mean / rstd
             _lib.call("acg_bn_eval_stats", _ptr(run_mean), _ptr(run_var), run_mean.numel(), C, eps, _ptr(mean), _ptr(rstd), st)
         else:
-            nb = _lib.query("acg_norm_workspace_bytes", G, P, C)
-            ws = workspace(nb)
-            _lib.call("acg_norm_stats", _ptr(x), G, P, C, eps, unbiased, _ptr(mean), _ptr(rstd), _ptr(run_mean),
-                      _ptr(run_var), momentum, _ptr(ws), nb, st)
+            part = take_conv_stats(x) if kind in ("in", "cin") else None
+            if part is not None:  # the producing convolution already reduced 128-pixel tiles: merge only
+                _lib.call("acg_norm_stats_from_partials", _ptr(part), G, P, C, STATS_ROWS, eps, unbiased, _ptr(mean),
+                          _ptr(rstd), st)
+            else:
+                nb = _lib.query("acg_norm_workspace_bytes", G, P, C)
+                ws = workspace(nb)
+                _lib.call("acg_norm_stats", _ptr(x), G, P, C, eps, unbiased, _ptr(mean), _ptr(rstd), _ptr(run_mean),
+                          _ptr(run_var), momentum, _ptr(ws), nb, st)
         y = torch.empty_like(x)
         if res is not None:
             res = res.contiguous()

@@ -90,6 +90,13 @@ int acg_pad_vector(const float *src, int n, float *dst, int np, void *stream); /
  *      365-382, 445-471; modules.py:162,180,211,227 (reflection pad folded into the loader). */
 int acg_conv2d_fwd(const acg_conv_desc *d, const float *x, const float *wf, const float *bias, float *y, int act,
                    void *stream);
+/* acg_conv2d_fwd with act = NONE that also writes, from its epilogue, the per-tile partial statistics of y that the
+ * InstanceNorm / CondInstanceNorm behind the convolution needs (modules.py:24-31, 46-55): stats[n][tile][{mean,M2}][Co]
+ * over tiles of 128 consecutive output pixels, to be merged by acg_norm_stats_from_partials(rows_per_chunk = 128).
+ * Supported (query first) for the bf16x3 128-column tile: Co >= 128, Ci % 32 == 0, Ho*Wo % 128 == 0. */
+int acg_conv2d_fwd_stats_supported(const acg_conv_desc *d);
+int acg_conv2d_fwd_stats(const acg_conv_desc *d, const float *x, const float *wf, const float *bias, float *y,
+                         float *stats, void *stream);
 /* data gradient of the above (autograd of nn.Conv2d / ReflectionPad2d): dy -> dx.
  * Reflect padding needs a workspace for the padded gradient image. */
 size_t acg_conv2d_bwd_data_workspace_bytes(const acg_conv_desc *d);
@@ -118,6 +125,10 @@ size_t acg_norm_workspace_bytes(int G, size_t P, int C);
  * (BatchNorm) they are updated with momentum (running_var takes the unbiased variance). */
 int acg_norm_stats(const float *x, int G, size_t P, int C, float eps, int unbiased, float *mean, float *rstd,
                    float *run_mean, float *run_var, float momentum, void *workspace, size_t ws_bytes, void *stream);
+/* the same statistics from per-chunk (mean, M2) partials a producer already holds (acg_conv2d_fwd_stats), merged with
+ * Chan's formula; x is not read.  part[((g*nchunks + chunk)*2 + {0,1})*C + c], nchunks = ceil(P / rows_per_chunk). */
+int acg_norm_stats_from_partials(const float *part, int G, size_t P, int C, int rows_per_chunk, float eps, int unbiased,
+                                 float *mean, float *rstd, void *stream);
 /* BatchNorm eval mode: mean/rstd (length Cp) from the running buffers (length C) */
 int acg_bn_eval_stats(const float *run_mean, const float *run_var, int C, int Cp, float eps, float *mean, float *rstd,
                       void *stream);

@@ -19,6 +19,10 @@ from test_hip_step import make_opt  # noqa: E402
 out, aug = sys.argv[1], int(sys.argv[2])
 rank, ws = D.init_from_env("gloo") if int(os.environ.get("WORLD_SIZE", "1")) > 1 else (0, 1)
 kw = dict(input_nc=3, output_nc=1, ngf=8, nef=8, ndf=8, nlatent=4, n_blocks=2)
+# what is tested here is the data-parallel exchange, not the conv arithmetic: exact-fp32 products keep the
+# "2 ranks == 1 rank" comparison down to summation order (the bf16x3 default adds 16-bit operand rounding on top)
+from dtgan_amd import ops  # noqa: E402
+ops.set_precision("f32")
 opt = make_opt(**kw)
 opt.sync_bn = aug == 2   # aug: 0 = StochCycleGAN, 1 = AugmentedCycleGAN (per-rank BatchNorm), 2 = AugmentedCycleGAN + SyncBN
 torch.manual_seed(1 + rank)

@@ -196,6 +196,44 @@ def test_batch_norm2d_train():
     assert rel(n(m.bias.grad), Bt.g) < 1e-4
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "f32"])
+def test_conv_epilogue_statistics_feed_instance_norm(prec):
+    """128-wide 3x3 reflect conv -> InstanceNorm -> ReLU (the resblock pattern at bench scale): in bf16x3 the conv
+    epilogue emits the norm's per-128-pixel-tile (mean, M2) and the norm only merges them — same result as the oracle,
+    and the fused entry point must really have been taken (strict f32 has no such kernel: separate statistics pass)."""
+    from hip_util import t, n, rel, precision
+    from dtgan_amd import modules as M, ops, _lib
+    N, C, H, W = 2, 128, 16, 24  # 384 pixels per image = 3 tiles
+    rs = np.random.RandomState(11)
+    x = rs.normal(0.3, 1.0, (N, C, H, W)); w = rs.normal(0, 0.05, (C, C, 3, 3)); b = rs.normal(0.5, 0.5, C)
+    sc = rs.normal(1, 0.3, C); sh = rs.normal(0, 0.3, C)
+    with precision(prec):
+        m = M.Sequential(nn.ReflectionPad2d(1), M.Conv2d(C, C, 3, padding=0, bias=True), M.InstanceNorm(C), nn.ReLU(True)).cuda()
+        with torch.no_grad():
+            m[1].weight.copy_(t(w)); m[1].bias.copy_(t(b)); m[2].scale.copy_(t(sc)); m[2].shift.copy_(t(sh))
+        calls = []
+        real = _lib.call
+        def spy(name, *a):
+            calls.append(name)
+            return real(name, *a)
+        _lib.call = spy
+        try:
+            xt = t(x, grad=True)
+            y = m(xt)
+        finally:
+            _lib.call = real
+        fused = "acg_conv2d_fwd_stats" in calls and "acg_norm_stats_from_partials" in calls
+        assert fused == (prec == "bf16x3"), calls
+        X, Wt, Bt, S, Sh = leaf(x), leaf(w), leaf(b), leaf(sc), leaf(sh)
+        yo = oops.relu(oops.instance_norm(oops.conv2d(X, Wt, Bt, stride=1, pad=1, pad_mode="reflect"), S, Sh))
+        assert rel(n(y), yo.v) < 5e-5
+        r = rs.normal(0, 1, yo.v.shape)
+        y.backward(t(r)); backward(yo, seed=r)
+        assert rel(n(xt.grad), X.g) < 2e-4
+        assert rel(n(m[1].weight.grad), Wt.g) < 2e-4
+        assert rel(n(m[2].scale.grad), S.g) < 2e-4
+
+
 def test_residual_norm_relu_fusion():
     """ResnetBlock tail: y = ReLU(x + IN(conv(...))) with the add + ReLU fused into the norm pass"""
     from hip_util import t, n, rel

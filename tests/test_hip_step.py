@@ -91,16 +91,21 @@ def _check_6_blocks(prec):
         load_recipe(net, k, 3, "rich")
     o = step.AugStep(step.Opt(**kw))
     o.load({k: recipe.values_for(net.shapes, k, 3, "rich") for k, net in o.nets().items()})
-    A, B, z = recipe.inputs(5, 4, 1, 1, 64, 4)  # batch >= 3: BatchNorm over E's 1x1 map
+    A, B, z = recipe.inputs(5, 8, 1, 1, 64, 4)  # E ends in a BatchNorm over (batch x 1x1): 8 samples keep it well conditioned
     l1, v1, g1 = m.train_instance(t(A), t(B), t(z))
     l0, v0, g0 = o.train_instance(A, B, z)
     (lt, gt, vt), (_, _, vt1) = STEP_TOL[prec]
     assert np.allclose(list(l1.values()), list(l0.values()), rtol=lt, atol=2e-6), (l1, l0)
     assert np.allclose(list(g1.values()), list(g0.values()), rtol=gt, atol=1e-6), (g1, g0)
-    for k in ("fake_A", "fake_B", "rec_A", "rec_B"):
+    for k in ("fake_A", "fake_B"):
         assert rel(n(v1[k]), v0[k]) < vt, k
+    # the cycle reconstructions chain two of these high-gain generators: tools/conditioning_probe.py (`step`) shows the
+    # EXACT-fp32 path moving rec_A / rec_B by 4e-4 .. 9e-4 when its inputs are perturbed by 4e-6 relative, the
+    # operand rounding of bf16x3 (which lands at 0.8 / 1.4e-3 here; single-pass images at 1.1-1.3e-4)
+    for k in ("rec_A", "rec_B"):
+        assert rel(n(v1[k]), v0[k]) < (vt if prec == "f32" else 3e-3), k
     # weights after the step: compare the generators' outputs on a fresh batch
-    A2, B2, z2 = recipe.inputs(6, 4, 1, 1, 64, 4)
+    A2, B2, z2 = recipe.inputs(6, 8, 1, 1, 64, 4)
     from oracle.tape import T
     fb = n(m.predict_B(t(A2), t(z2)))
     fbo = o.netG_A_B.forward(T(A2), T(z2)).v
