@@ -123,7 +123,7 @@ def main():
     # dense MFMA peaks (MI355X_MICROARCH.md): fp32 157.3, bf16 2500 TFLOP/s; bf16x3 issues 3 bf16 MFMAs per
     # algorithmic product, so its ceiling for ALGORITHMIC flops is 2500 / 3
     peak = {"f32": 157.3, "bf16x3": round(2500.0 / 3, 1), "bf16": 2500.0}[a.precision]
-    kname = {"f32": "igemm_conv_f32<128,128,2,2,32,REFLECT,!THIN>", "bf16x3": "igemm_conv_bf16<128,128,2,2,32,REFLECT,SPLIT>",
+    kname = {"f32": "igemm_conv_f32<128,128,2,2,32,REFLECT,!THIN>", "bf16x3": "igemm_conv_x3_ws<REFLECT,STATS> (wave-specialised, 16x16x32 bf16 MFMA x3)",
              "bf16": "igemm_conv_bf16<128,128,2,2,64,REFLECT,!SPLIT>"}[a.precision]
     dtype = {"f32": "f32", "bf16x3": "f32 tensors; conv products as 3 bf16 MFMAs on hi/lo-split fp32 operands (~2^-17 operand rounding), fp32 accumulate",
              "bf16": "bf16 (MFMA operands; fp32 accumulate and fp32 tensors)"}[a.precision]

@@ -1,7 +1,7 @@
 """GPU tests of the bf16 throughput mode (`ops.set_precision('bf16')`): conv operands are rounded to bf16 on their
 way into LDS, products accumulate in fp32 (v_mfma_f32_32x32x16_bf16); tensors in HBM stay fp32.
 
-This is NOT the parity path (that is fp32, tests/test_hip_ops.py ... test_hip_step.py, 1e-3 bar).  Tolerances here
+This is NOT a parity path (those are bf16x3 and f32: tests/test_hip_ops.py ... test_hip_step.py, 1e-3 bar).  Tolerances here
 follow the error model: two 2^-9 roundings per product, fp32 sums -> ~4e-3 of the output scale per conv; a dozen
 layers deep (whole generator) a few 1e-2."""
 import numpy as np
