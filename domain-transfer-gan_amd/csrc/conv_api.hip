@@ -341,6 +341,47 @@ __global__ void reflect_fold_kernel(const float *__restrict__ dxp, float *__rest
     }
 }
 
+// The same fold restricted to the FRAME: the input pixels the pad ring mirrors onto (rows / columns 1..p and
+// H-1-p..H-2).  Used when the data-gradient kernel already stored every other pixel straight into dx (Geom.fold_p):
+// 2p rows x W plus 2p columns x (H - 2p) pixels per image instead of all H x W.
+__global__ void reflect_fold_frame_kernel(const float *__restrict__ dxp, float *__restrict__ dx, int N, int H, int W, int C,
+                                          int p)
+{
+    const int C4 = C / 4;
+    const int nrow = 2 * p * W, ncol = 2 * p * (H - 2 * p); // frame pixels per image: dirty rows, then dirty columns
+    const long long total = (long long)N * (nrow + ncol) * C4;
+    const int Hp = H + 2 * p, Wp = W + 2 * p;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long r = i;
+        const int c4 = (int)(r % C4); r /= C4;
+        const int f = (int)(r % (nrow + ncol));
+        const int n = (int)(r / (nrow + ncol));
+        int y, x;
+        if (f < nrow) { // dirty row k: rows 1..p then H-1-p..H-2
+            const int k = f / W;
+            x = f - k * W;
+            y = k < p ? 1 + k : H - 1 - p + (k - p);
+        } else {        // dirty column k of a clean row
+            const int q = f - nrow, k = q / (H - 2 * p), yy = q - k * (H - 2 * p);
+            x = k < p ? 1 + k : W - 1 - p + (k - p);
+            y = yy == 0 ? 0 : (yy <= H - 2 - 2 * p ? p + yy : H - 1); // clean rows: 0, p+1..H-2-p, H-1
+        }
+        int ys[3], xs[3], ny = 0, nx = 0;
+        ys[ny++] = y + p;
+        if (y >= 1 && y <= p) ys[ny++] = p - y;
+        if (y >= H - 1 - p && y <= H - 2) ys[ny++] = 2 * (H - 1) - y + p;
+        xs[nx++] = x + p;
+        if (x >= 1 && x <= p) xs[nx++] = p - x;
+        if (x >= W - 1 - p && x <= W - 2) xs[nx++] = 2 * (W - 1) - x + p;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b)
+                acc += *(const f32x4 *)(dxp + (((long long)n * Hp + ys[a]) * Wp + xs[b]) * C + c4 * 4);
+        *(f32x4 *)(dx + (((long long)n * H + y) * W + x) * C + c4 * 4) = acc;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // column sums (bias gradient): dy[M][C] -> db[c] (first Cr columns), two deterministic stages
 // ------------------------------------------------------------------------------------------
@@ -616,9 +657,18 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
                 t.dy[t.n] = (short)(base - kh); t.dx[t.n] = (short)(base - kw); t.w[t.n] = (short)(kh * K + kw);
                 t.n++;
             }
+        // the wave-specialised kernel stores the pixels nothing is mirrored onto straight into dst: only the frame is folded
+        const bool frame = refl && !thin_in_valu_dgrad(d) && acg_igemm_uses_ws(g) && d->Hi > 4 * p + 1 && d->Wi > 4 * p + 1;
+        if (frame) { g.fold_p = p; g.fold_H = d->Hi; g.fold_W = d->Wi; g.out2 = dst; }
         int rc = thin_in_valu_dgrad(d) ? thin_out_launch(src, wb, bias, out, g, t, st) : acg_igemm_launch(src, wb, bias, out, g, t, st);
         if (rc != ACG_OK) return rc;
-        if (refl) {
+        if (frame) {
+            const long long total = (long long)d->N * (2 * p * d->Wi + 2 * p * (d->Hi - 2 * p)) * (d->Ci / 4);
+            const int blocks = acg_cdiv(total, 256) > 4096 ? 4096 : acg_cdiv(total, 256);
+            hipLaunchKernelGGL(reflect_fold_frame_kernel, dim3(blocks), dim3(256), 0, st, (const float *)ws, dst, d->N, d->Hi,
+                               d->Wi, d->Ci, p);
+            ACG_CHECK_LAUNCH("reflect_fold_frame_kernel");
+        } else if (refl) {
             const long long total = (long long)d->N * d->Hi * d->Wi * (d->Ci / 4);
             const int blocks = acg_cdiv(total, 256) > 4096 ? 4096 : acg_cdiv(total, 256);
             hipLaunchKernelGGL(reflect_fold_kernel, dim3(blocks), dim3(256), 0, st, (const float *)ws, dst, d->N, d->Hi,

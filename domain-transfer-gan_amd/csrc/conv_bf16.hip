@@ -228,6 +228,14 @@ static void launch_bf16_kc(int bn, dim3 grid, hipStream_t st, const float *in, c
         hipLaunchKernelGGL((igemm_conv_bf16<128, 32, 4, 1, KC, REFLECT, SPLIT>), grid, block, 0, st, in, wp, bias, out, g, t, inb, wb, wlo);
 }
 
+// does this launch go to the wave-specialised bf16x3 kernel (conv_x3.hip)?  128-column tiles, 32-channel stages
+bool acg_igemm_uses_ws(const Geom &g)
+{
+    static const bool no_ws = getenv("ACG_NO_WS") != nullptr; // A/B switch
+    return !no_ws && g_acg_precision == ACG_PREC_BF16X3 && g_acg_conv_impl == ACG_IMPL_MFMA && !g.thin && g.Cout >= 128 &&
+           g.Cin % 32 == 0;
+}
+
 // n_w_elems: element count of the packed weight array (hi part); the lo part of BF16X3 sits right behind it
 int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g0, const Taps &t,
                           int bn, long long n_w_elems, hipStream_t st)
@@ -247,8 +255,8 @@ int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, fl
         if (g.reflect) launch_bf16_kc<KCV, true, SP>(bn, grid, st, in, w, bias, out, g, t, inb, wb, wlo);   \
         else launch_bf16_kc<KCV, false, SP>(bn, grid, st, in, w, bias, out, g, t, inb, wb, wlo);            \
     } while (0)
-    static const bool no_ws = getenv("ACG_NO_WS") != nullptr; // A/B switch for the wave-specialised kernel
-    if (split && bn == 128 && g.Cin % 32 == 0 && !no_ws) return acg_igemm_x3_ws_launch(in, wp, bias, out, g0, t, n_w_elems, st);
+    if (acg_igemm_uses_ws(g0)) return acg_igemm_x3_ws_launch(in, wp, bias, out, g0, t, n_w_elems, st);
+    ACG_REQUIRE(g0.fold_p == 0, "igemm_conv_bf16: the fold bypass is implemented by the wave-specialised kernel only");
     if (split) { // hi+lo images double the LDS: 32-channel stages keep 3-4 blocks per CU
         if (g.Cin % 32 == 0) BF16_DISPATCH(32, true);
         else BF16_DISPATCH(16, true);

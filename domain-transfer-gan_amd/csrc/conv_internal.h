@@ -33,6 +33,12 @@ struct Geom {
     int act;
     int ncols_pad;        // packed-weight column count (multiple of the N tile)
     long long w_elems;    // element count of the packed weight array (bf16 modes: where the lo part starts)
+    // Data gradient of a reflection-padded convolution, computed on the padded grid (Hout x Wout = fold_H+2p x fold_W+2p).
+    // fold_p > 0 (wave-specialised kernel only): padded-grid pixels whose input pixel receives no mirrored contribution
+    // are stored straight into out2 (N, fold_H, fold_W, Cout); only the frame (pad ring + the rows/columns it mirrors
+    // onto) goes to `out`, and reflect_fold_frame_kernel sums that 3 % of the pixels afterwards.
+    int fold_p = 0, fold_H = 0, fold_W = 0;
+    float *out2 = nullptr;
     int thin;             // 1: K flattened over (tap, 4 channels): stage s = taps 8s..8s+7, channels 0..3 of each
     int bk8;              // 8-float k-chunks per packed weight slab (Cin/8; thin: 4*ceil(ntaps/8), single slab)
     long long Mtot;       // N*GH*GW
@@ -59,8 +65,10 @@ int acg_wgrad_launch(const float *x, const float *dy, float *part, const WGeom &
 void acg_wgrad_tiles(int Ci, int Co, int *bci, int *bco);
 
 extern int g_acg_precision;
+extern int g_acg_conv_impl;
 int acg_igemm_x3_ws_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g, const Taps &t,
                            long long n_w_elems, hipStream_t st, float *stats = nullptr);
+bool acg_igemm_uses_ws(const Geom &g);
 int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g, const Taps &t,
                           int bn, long long n_w_elems, hipStream_t st);
 int acg_wgrad_bf16_launch(const float *x, const float *dy, float *part, const WGeom &g, const Taps &t, int bci, int bco,

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                         unsigned w_lo_bytes, float *__restrict__ stats)
 {
     __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF];
-    __shared__ long long out_off[BM];
+    __shared__ float *out_ptr[BM]; // output row of every tile pixel (nullptr past the end)
     __shared__ float red[2][2][64]; // [wn][wm][column]: cross-wave fold of the per-tile statistics
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -57,14 +57,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
     if (tid < BM) {
         const long long m = m0 + tid;
-        long long off = -1;
+        float *ptr = nullptr;
         if (m < g.Mtot) {
             const int n = (int)(m / GHW);
             const int r = (int)(m - (long long)n * GHW);
             const int gy = r / g.GW, gx = r - gy * g.GW;
-            off = (((long long)n * g.Hout + (gy * g.os + g.oy0)) * g.Wout + (gx * g.os + g.ox0)) * g.Cout;
+            const int oy = gy * g.os + g.oy0, ox = gx * g.os + g.ox0;
+            ptr = out + (((long long)n * g.Hout + oy) * g.Wout + ox) * g.Cout;
+            if (g.fold_p > 0) { // reflect data gradient: pixels nothing is mirrored onto bypass the fold
+                const int p = g.fold_p, iy = oy - p, ix = ox - p;
+                const bool cy = iy >= 0 && iy < g.fold_H && !(iy >= 1 && iy <= p) && !(iy >= g.fold_H - 1 - p && iy <= g.fold_H - 2);
+                const bool cx = ix >= 0 && ix < g.fold_W && !(ix >= 1 && ix <= p) && !(ix >= g.fold_W - 1 - p && ix <= g.fold_W - 2);
+                if (cy && cx) ptr = g.out2 + (((long long)n * g.fold_H + iy) * g.fold_W + ix) * g.Cout;
+            }
         }
-        out_off[tid] = off;
+        out_ptr[tid] = ptr;
     }
 
     if (wave >= 4) {
@@ -258,8 +265,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const long long off = out_off[wm * TM + i * 16 + 4 * pl + r];
-                if (cok && off >= 0) out[off + co] = acg_apply_act(acc[i][j][r] + bv, g.act);
+                float *dst = out_ptr[wm * TM + i * 16 + 4 * pl + r];
+                if (cok && dst != nullptr) dst[co] = acg_apply_act(acc[i][j][r] + bv, g.act);
             }
     }
 }
