@@ -786,7 +786,11 @@ static void wgrad_plan(const acg_conv_desc *d, int Cx, int Cg, long long Mtot, i
     }
     const int KP = 256; // multiple of every kernel variant's pixels-per-stage (fp32: 32/128, bf16: 64/256)
     const long long base = (wgrad_thin(d) ? 1LL : (long long)d->K * d->K) * (*CiP / bci) * (*CoP / bco);
-    long long ns = 1536 / base;
+    // workgroups per launch: a whole number of residency waves.  The bf16 128x128 kernel holds 2 workgroups per CU:
+    // 512 = exactly one wave (vs 1536: -6..-10 %, and a third of the partial-sum traffic); 768 = 1.5 waves is the worst
+    // choice (+15 %).  The smaller tiles hold 3-4 per CU and keep more, shorter workgroups.
+    const long long target = (g_acg_precision != ACG_PREC_F32 && g_acg_conv_impl == ACG_IMPL_MFMA && bci == 128 && bco == 128 && !wgrad_thin(d)) ? 512 : 1024;
+    long long ns = target / base;
     const long long cap = Mtot / (KP * 4);
     if (ns > cap) ns = cap;
     if (ns > 512) ns = 512;
