@@ -2,7 +2,7 @@
 //
 // The single-role kernel (conv_bf16.hip) runs its phases one after the other inside every wave — split the fp32
 // operands (VALU), store them to LDS, barrier, read fragments, issue MFMAs — and rocprofv3 counters show the three
-// pipes each busy about a third of the time (profiles/r01_d_*).  Here a workgroup of 8 waves divides the work:
+// pipes each busy about a third of the time.  Here a workgroup of 8 waves divides the work:
 //   waves 0-3  consumers: ds_read fragments + v_mfma_f32_16x16x32_bf16 only (2x2 waves x 64x64 outputs; this shape
 //              ran 3-4 % faster than 32x32x16 at equal cycles: the chip holds a higher clock on it);
 //   waves 4-7  producers: buffer loads, hi/lo split, LDS stores for the NEXT stage into the other LDS buffer.
@@ -31,11 +31,11 @@ constexpr int BUF = 2 * A_IMG + 2 * B_IMG;            // A hi, A lo, B hi, B lo
 __device__ __forceinline__ int lds_at(int plane, int row, int pl) { return plane * pl + ((row ^ (2 * plane)) * 8); }
 }
 
-// 4 waves per SIMD = two 8-wave workgroups per CU: the register budget is 128 VGPRs.  The statistics epilogue (STATS)
-// would raise the allocation to 142 and halve the occupancy of the main loop; capped, it spills a few values around
-// the epilogue only (the loops are scratch-free), and the plain variant is untouched (124).
+// 4 waves per SIMD = two 8-wave workgroups per CU: the register budget is 128 VGPRs (all four instances allocate 122,
+// no scratch).  STATS: also emit the per-tile (mean, M2) for an InstanceNorm behind the convolution (see the epilogue).
 template <bool REFLECT, bool STATS>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void
+igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
                                                         const float *__restrict__ bias, float *__restrict__ out,
                                                         Geom g, Taps taps, unsigned in_bytes, unsigned w_bytes,
                                                         unsigned w_lo_bytes, float *__restrict__ stats)
