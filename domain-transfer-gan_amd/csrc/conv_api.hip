@@ -345,7 +345,7 @@ __global__ void reflect_fold_kernel(const float *__restrict__ dxp, float *__rest
 // H-1-p..H-2).  Used when the data-gradient kernel already stored every other pixel straight into dx (Geom.fold_p):
 // 2p rows x W plus 2p columns x (H - 2p) pixels per image instead of all H x W.
 __global__ void reflect_fold_frame_kernel(const float *__restrict__ dxp, float *__restrict__ dx, int N, int H, int W, int C,
-                                          int p)
+                                          int p, const float *__restrict__ addend)
 {
     const int C4 = C / 4;
     const int nrow = 2 * p * W, ncol = 2 * p * (H - 2 * p); // frame pixels per image: dirty rows, then dirty columns
@@ -378,7 +378,9 @@ __global__ void reflect_fold_frame_kernel(const float *__restrict__ dxp, float *
         for (int a = 0; a < ny; ++a)
             for (int b = 0; b < nx; ++b)
                 acc += *(const f32x4 *)(dxp + (((long long)n * Hp + ys[a]) * Wp + xs[b]) * C + c4 * 4);
-        *(f32x4 *)(dx + (((long long)n * H + y) * W + x) * C + c4 * 4) = acc;
+        const long long o = (((long long)n * H + y) * W + x) * C + c4 * 4;
+        if (addend != nullptr) acc += *(const f32x4 *)(addend + o);
+        *(f32x4 *)(dx + o) = acc;
     }
 }
 
@@ -624,8 +626,16 @@ static void fwd_geom(const acg_conv_desc *d, Geom *g, Taps *t, int act)
 
 // data gradient (and ConvTranspose forward): gathers from the conv-OUTPUT side tensor `src`
 // (N,Ho,Wo,Co) with packed wb, writes the conv-INPUT side tensor `dst` (N,Hi,Wi,Ci).
+// addend (optional): tensor of dst's shape added to the result; only the frame path below implements it
+static bool dgrad_frame_ok(const acg_conv_desc *d, const Geom &g)
+{
+    const int p = d->pad;
+    return d->stride == 1 && d->pad_mode == ACG_PAD_REFLECT && p > 0 && !thin_in_valu_dgrad(d) && acg_igemm_uses_ws(g) &&
+           d->Hi > 4 * p + 1 && d->Wi > 4 * p + 1;
+}
+
 static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb, const float *bias, float *dst,
-                       int act, void *ws, size_t ws_bytes, hipStream_t st)
+                       int act, void *ws, size_t ws_bytes, hipStream_t st, const float *addend = nullptr)
 {
     Geom g; Taps t;
     g.Hin = d->Ho; g.Win = d->Wo; g.Cin = d->Co;
@@ -658,15 +668,16 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
                 t.n++;
             }
         // the wave-specialised kernel stores the pixels nothing is mirrored onto straight into dst: only the frame is folded
-        const bool frame = refl && !thin_in_valu_dgrad(d) && acg_igemm_uses_ws(g) && d->Hi > 4 * p + 1 && d->Wi > 4 * p + 1;
-        if (frame) { g.fold_p = p; g.fold_H = d->Hi; g.fold_W = d->Wi; g.out2 = dst; }
+        const bool frame = refl && dgrad_frame_ok(d, g);
+        ACG_REQUIRE(addend == nullptr || frame, "dgrad: the fused addend needs the frame path (query acg_conv2d_bwd_data_add_supported)");
+        if (frame) { g.fold_p = p; g.fold_H = d->Hi; g.fold_W = d->Wi; g.out2 = dst; g.addend = addend; }
         int rc = thin_in_valu_dgrad(d) ? thin_out_launch(src, wb, bias, out, g, t, st) : acg_igemm_launch(src, wb, bias, out, g, t, st);
         if (rc != ACG_OK) return rc;
         if (frame) {
             const long long total = (long long)d->N * (2 * p * d->Wi + 2 * p * (d->Hi - 2 * p)) * (d->Ci / 4);
             const int blocks = acg_cdiv(total, 256) > 4096 ? 4096 : acg_cdiv(total, 256);
             hipLaunchKernelGGL(reflect_fold_frame_kernel, dim3(blocks), dim3(256), 0, st, (const float *)ws, dst, d->N, d->Hi,
-                               d->Wi, d->Ci, p);
+                               d->Wi, d->Ci, p, addend);
             ACG_CHECK_LAUNCH("reflect_fold_frame_kernel");
         } else if (refl) {
             const long long total = (long long)d->N * d->Hi * d->Wi * (d->Ci / 4);
@@ -767,6 +778,26 @@ extern "C" int acg_conv2d_bwd_data(const acg_conv_desc *d, const float *dy, cons
         return ACG_OK;
     }
     return dgrad_igemm(d, dy, wb, nullptr, dx, ACG_ACT_NONE, ws, ws_bytes, st);
+}
+
+// dx = data gradient + addend (a tensor of dx's shape): the residual-path gradient of a ResnetBlock joins the gradient
+// of the block's first convolution (modules.py:185-188, 232-235: out = x + conv_block(x)) inside the convolution's
+// epilogue instead of in a separate element-wise pass.  Implemented by the frame path of the reflect data gradient.
+extern "C" int acg_conv2d_bwd_data_add_supported(const acg_conv_desc *d)
+{
+    if (d == nullptr || g_acg_conv_impl != ACG_IMPL_MFMA) return 0;
+    Geom g;
+    g.Cin = d->Co; g.Cout = d->Ci; g.thin = (d->stride == 1 && thin_out(d)) ? 1 : 0;
+    return dgrad_frame_ok(d, g) ? 1 : 0;
+}
+
+extern "C" int acg_conv2d_bwd_data_add(const acg_conv_desc *d, const float *dy, const float *wb, const float *addend,
+                                       float *dx, void *ws, size_t ws_bytes, void *stream)
+{
+    int rc = check_desc(d, "acg_conv2d_bwd_data_add");
+    if (rc) return rc;
+    ACG_REQUIRE(addend != nullptr && acg_conv2d_bwd_data_add_supported(d), "acg_conv2d_bwd_data_add: unsupported shape or mode");
+    return dgrad_igemm(d, dy, wb, nullptr, dx, ACG_ACT_NONE, ws, ws_bytes, (hipStream_t)stream, addend);
 }
 
 // split-K plan shared by the workspace query and the launch

@@ -39,6 +39,7 @@ struct Geom {
     // onto) goes to `out`, and reflect_fold_frame_kernel sums that 3 % of the pixels afterwards.
     int fold_p = 0, fold_H = 0, fold_W = 0;
     float *out2 = nullptr;
+    const float *addend = nullptr; // fold_p > 0 only: tensor of out2's shape added to the result (residual-path gradient)
     int thin;             // 1: K flattened over (tap, 4 channels): stage s = taps 8s..8s+7, channels 0..3 of each
     int bk8;              // 8-float k-chunks per packed weight slab (Cin/8; thin: 4*ceil(ntaps/8), single slab)
     long long Mtot;       // N*GH*GW

@@ -42,6 +42,7 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
 {
     __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF];
     __shared__ float *out_ptr[BM]; // output row of every tile pixel (nullptr past the end)
+    __shared__ const float *add_ptr[BM]; // row of Geom.addend to add on the way out (nullptr: none)
     __shared__ float red[2][2][64]; // [wn][wm][column]: cross-wave fold of the per-tile statistics
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -58,6 +59,7 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
     if (tid < BM) {
         const long long m = m0 + tid;
         float *ptr = nullptr;
+        const float *aptr = nullptr;
         if (m < g.Mtot) {
             const int n = (int)(m / GHW);
             const int r = (int)(m - (long long)n * GHW);
@@ -68,10 +70,15 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
                 const int p = g.fold_p, iy = oy - p, ix = ox - p;
                 const bool cy = iy >= 0 && iy < g.fold_H && !(iy >= 1 && iy <= p) && !(iy >= g.fold_H - 1 - p && iy <= g.fold_H - 2);
                 const bool cx = ix >= 0 && ix < g.fold_W && !(ix >= 1 && ix <= p) && !(ix >= g.fold_W - 1 - p && ix <= g.fold_W - 2);
-                if (cy && cx) ptr = g.out2 + (((long long)n * g.fold_H + iy) * g.fold_W + ix) * g.Cout;
+                if (cy && cx) {
+                    const long long o2 = (((long long)n * g.fold_H + iy) * g.fold_W + ix) * g.Cout;
+                    ptr = g.out2 + o2;
+                    if (g.addend != nullptr) aptr = g.addend + o2;
+                }
             }
         }
         out_ptr[tid] = ptr;
+        add_ptr[tid] = aptr;
     }
 
     if (wave >= 4) {
@@ -252,7 +259,12 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
     for (int k = 0; k < BM * (BN / 4) / 256; ++k) { // 16 float4 per thread, consecutive lanes on consecutive channels
         const int idx = tid + 256 * k, row = idx / (BN / 4), c4 = idx - row * (BN / 4);
         float *dst = out_ptr[row];
-        if (dst != nullptr && n0 + c4 * 4 < g.Cout) *(f32x4 *)(dst + n0 + c4 * 4) = *(const f32x4 *)&tile[row * TS + c4 * 4];
+        if (dst != nullptr && n0 + c4 * 4 < g.Cout) {
+            f32x4 v = *(const f32x4 *)&tile[row * TS + c4 * 4];
+            const float *ap = add_ptr[row];
+            if (ap != nullptr) v += *(const f32x4 *)(ap + n0 + c4 * 4);
+            *(f32x4 *)(dst + n0 + c4 * 4) = v;
+        }
     }
 }
 

@@ -63,12 +63,13 @@ class Conv2d(nn.Conv2d, _Cached):
     def packed(self):
         return self._cached(lambda: ops.PackedConv(self.weight, self.bias, cpad(self.in_channels), cpad(self.out_channels)))
 
-    def forward_nhwc(self, x, act=ACT_NONE, reflect_pad=0, want_stats=False):
+    def forward_nhwc(self, x, act=ACT_NONE, reflect_pad=0, want_stats=False, want_identity=False):
         if reflect_pad:
             pad, mode = reflect_pad, PAD_REFLECT
         else:
             pad, mode = self.padding[0], PAD_ZERO
-        return ops.Conv2dFn.apply(x, self.weight, self.bias, self.packed(), self.stride[0], pad, mode, act, want_stats)
+        return ops.Conv2dFn.apply(x, self.weight, self.bias, self.packed(), self.stride[0], pad, mode, act, want_stats,
+                                  want_identity)
 
     def forward(self, input):
         return ops.ToNCHW.apply(self.forward_nhwc(ops.ToNHWC.apply(input)), self.out_channels)
@@ -261,6 +262,7 @@ def run_sequence(mods, x, C, z=None, res=None):
     last_norm = max([k for k, m in enumerate(mods) if isinstance(m, (InstanceNorm, CondInstanceNorm, BatchNorm2d))
                      or (isinstance(m, MergeModule))] + [-1]) if res is not None else -1
     reflect = 0
+    skip_routed = False
     while i < n:
         m = mods[i]
         if isinstance(m, nn.ReflectionPad2d):
@@ -300,7 +302,11 @@ def run_sequence(mods, x, C, z=None, res=None):
                 raise NotImplementedError("reflection pad before ConvTranspose2d")
             x = conv.forward_nhwc(x, cact)
         else:  # an (Cond)InstanceNorm right behind the conv can take its statistics from the conv epilogue
-            x = conv.forward_nhwc(x, cact, reflect, isinstance(norm, (InstanceNorm, CondInstanceNorm)))
+            skip_here = res is not None and not skip_routed and x is res  # the block's FIRST convolution
+            x = conv.forward_nhwc(x, cact, reflect, isinstance(norm, (InstanceNorm, CondInstanceNorm)), skip_here)
+            if skip_here:  # the skip connection continues from the conv's identity output: its gradient is added
+                x, res = x  # inside that conv's data-gradient epilogue
+                skip_routed = True
         reflect = 0
         C = conv.out_channels
         if norm is not None:

@@ -224,10 +224,12 @@ def take_conv_stats(x):
 class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d (+ preceding ReflectionPad2d) + bias + fused activation.  want_stats: the caller runs an
     (Cond)InstanceNorm on the output next — where the kernel supports it the epilogue emits that norm's per-tile
-    partial statistics, saving the norm one read of the tensor."""
+    partial statistics, saving the norm one read of the tensor.  want_identity: also return x itself as a second
+    output; a ResnetBlock feeds that alias to its skip connection, so the skip gradient arrives HERE and is added
+    inside the data-gradient epilogue (acg_conv2d_bwd_data_add) instead of by a separate autograd accumulation."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, packed, stride, pad, pad_mode, act, want_stats=False):
+    def forward(ctx, x, weight, bias, packed, stride, pad, pad_mode, act, want_stats=False, want_identity=False):
         x = x.contiguous()
         _check(x)
         N, Hi, Wi, Ci = x.shape
@@ -256,10 +258,12 @@ class Conv2dFn(torch.autograd.Function):
             CONV_TIMER.events.append((e0, e1))
         ctx.d, ctx.packed, ctx.act, ctx.has_bias = d, packed, act, bias is not None
         ctx.save_for_backward(x, y if act != ACT_NONE else None)
+        if want_identity:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, y = ctx.saved_tensors
         d, pk = ctx.d, ctx.packed
         dy = dy.contiguous()
@@ -274,7 +278,13 @@ class Conv2dFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             nb = _lib.query("acg_conv2d_bwd_data_workspace_bytes", ctypes.byref(d))
             ws = workspace(nb) if nb else None
-            _lib.call("acg_conv2d_bwd_data", ctypes.byref(d), _ptr(g), _ptr(pk.wb), _ptr(dx), _ptr(ws), nb, st)
+            if dskip is not None and _lib.query("acg_conv2d_bwd_data_add_supported", ctypes.byref(d)):
+                _lib.call("acg_conv2d_bwd_data_add", ctypes.byref(d), _ptr(g), _ptr(pk.wb), _ptr(dskip.contiguous()), _ptr(dx),
+                          _ptr(ws), nb, st)
+            else:
+                _lib.call("acg_conv2d_bwd_data", ctypes.byref(d), _ptr(g), _ptr(pk.wb), _ptr(dx), _ptr(ws), nb, st)
+                if dskip is not None:
+                    dx = dx + dskip
         if ctx.needs_input_grad[1]:
             dw = torch.empty((pk.Or, pk.Ir, pk.K, pk.K), device=x.device, dtype=torch.float32)
             db = torch.empty(pk.Or, device=x.device, dtype=torch.float32) if ctx.has_bias else None
@@ -282,7 +292,7 @@ class Conv2dFn(torch.autograd.Function):
             ws = workspace(nb)
             _lib.call("acg_conv2d_bwd_weight", ctypes.byref(d), _ptr(x), _ptr(g), _ptr(dw), _ptr(db), pk.Or, pk.Ir, _ptr(ws),
                       nb, st)
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 class ConvTranspose2dFn(torch.autograd.Function):

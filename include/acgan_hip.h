@@ -102,6 +102,12 @@ int acg_conv2d_fwd_stats(const acg_conv_desc *d, const float *x, const float *wf
 size_t acg_conv2d_bwd_data_workspace_bytes(const acg_conv_desc *d);
 int acg_conv2d_bwd_data(const acg_conv_desc *d, const float *dy, const float *wb, float *dx, void *workspace,
                         size_t ws_bytes, void *stream);
+/* dx = data gradient + addend (same shape as dx), fused into the convolution epilogue: the gradient arriving over a
+ * ResnetBlock's skip connection (modules.py:185-188, 232-235) joins the gradient of the block's first convolution without
+ * a separate element-wise pass.  Supported (query first) where the reflect data gradient takes its frame path. */
+int acg_conv2d_bwd_data_add_supported(const acg_conv_desc *d);
+int acg_conv2d_bwd_data_add(const acg_conv_desc *d, const float *dy, const float *wb, const float *addend, float *dx,
+                            void *ws, size_t ws_bytes, void *stream);
 /* weight (+bias) gradient: x, dy -> dw in torch OIHW layout (Or x Ir real channels), db[Or] (may be NULL).
  * Deterministic split-K over pixels with a second-stage reduction (no atomics). */
 size_t acg_conv2d_bwd_weight_workspace_bytes(const acg_conv_desc *d);

@@ -234,6 +234,51 @@ def test_conv_epilogue_statistics_feed_instance_norm(prec):
         assert rel(n(m[2].scale.grad), S.g) < 2e-4
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "f32"])
+def test_resnet_block_128_fused_paths(prec):
+    """A 128-wide ResnetBlock (the bench-scale block) against the oracle.  In bf16x3 its backward must take the fused
+    routes: the skip gradient is added inside the first convolution's data-gradient epilogue
+    (acg_conv2d_bwd_data_add: frame path of the reflect fold) and the second convolution feeds the InstanceNorm's
+    statistics from its epilogue; strict f32 takes the separate passes.  Same numbers either way."""
+    from hip_util import t, n, rel, precision
+    from dtgan_amd import modules as M, _lib
+    N, C, H, W = 2, 128, 16, 24
+    rs = np.random.RandomState(5)
+    x = rs.normal(0.1, 1.0, (N, C, H, W))
+    w1 = rs.normal(0, 0.04, (C, C, 3, 3)); b1 = rs.normal(0, 0.3, C)
+    w2 = rs.normal(0, 0.04, (C, C, 3, 3)); b2 = rs.normal(0, 0.3, C)
+    sc = rs.normal(1, 0.3, C); sh = rs.normal(0, 0.3, C)
+    with precision(prec):
+        blk = M.ResnetBlock(C, "reflect", M.InstanceNorm, False, True).cuda()
+        cb = blk.conv_block
+        with torch.no_grad():
+            cb[1].weight.copy_(t(w1)); cb[1].bias.copy_(t(b1)); cb[4].weight.copy_(t(w2)); cb[4].bias.copy_(t(b2))
+            cb[5].scale.copy_(t(sc)); cb[5].shift.copy_(t(sh))
+        calls = []
+        real = _lib.call
+        def spy(name, *a):
+            calls.append(name)
+            return real(name, *a)
+        _lib.call = spy
+        try:
+            xt = t(x, grad=True)
+            y = blk(xt * 1.0)  # a non-leaf input, as inside a generator
+            r = rs.normal(0, 1, y.shape)
+            y.backward(t(r))
+        finally:
+            _lib.call = real
+        fused = "acg_conv2d_bwd_data_add" in calls and "acg_conv2d_fwd_stats" in calls
+        assert fused == (prec == "bf16x3"), sorted(set(calls))
+        X, W1, B1, W2, B2, S, Sh = (leaf(a) for a in (x, w1, b1, w2, b2, sc, sh))
+        h = oops.relu(oops.conv2d(X, W1, B1, stride=1, pad=1, pad_mode="reflect"))
+        yo = oops.relu(oops.add(X, oops.instance_norm(oops.conv2d(h, W2, B2, stride=1, pad=1, pad_mode="reflect"), S, Sh)))
+        assert rel(n(y), yo.v) < 5e-5
+        backward(yo, seed=r)
+        assert rel(n(xt.grad), X.g) < 2e-4
+        assert rel(n(cb[1].weight.grad), W1.g) < 2e-4
+        assert rel(n(cb[4].weight.grad), W2.g) < 2e-4
+
+
 def test_residual_norm_relu_fusion():
     """ResnetBlock tail: y = ReLU(x + IN(conv(...))) with the add + ReLU fused into the norm pass"""
     from hip_util import t, n, rel
