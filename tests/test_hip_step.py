@@ -110,3 +110,39 @@ def _check_6_blocks(prec):
     fb = n(m.predict_B(t(A2), t(z2)))
     fbo = o.netG_A_B.forward(T(A2), T(z2)).v
     assert rel(fb, fbo) < vt1
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_stoch_enc_branch_against_oracle(prec, monkeypatch):
+    """--stoch_enc (model.py:414-419, 501-502, 519-522): post_z is a clamped reparametrised sample, the KLD term joins
+    loss_G and the latent GAN terms drop out.  The reference draws its N(0,1) noise internally, so this branch is pinned
+    by the oracle only: the same eps is injected into both sides."""
+    from hip_util import t, n, rel, load_recipe, precision
+    from dtgan_amd import model as M
+    from oracle import recipe, step
+    kw = dict(input_nc=3, output_nc=3, ngf=8, nef=8, ndf=8, nlatent=4, n_blocks=3, stoch_enc=True)
+    N = 8
+    A, B, z = recipe.inputs(21, N, 3, 3, 64, 4)
+    eps = np.random.RandomState(77).normal(0, 1, (N, 1, 4)).astype(np.float32)
+
+    def fixed_reparametrize(mu, logvar, n_sample=1):  # model.py:15-22 with the draw replaced by `eps`
+        assert n_sample == 1
+        zz = t(eps).mul(logvar.mul(0.5).exp()[:, None, :]).add(mu[:, None, :]).clamp(-4.0, 4.0)
+        return zz.view(zz.size(0) * zz.size(1), zz.size(2), 1, 1)
+
+    monkeypatch.setattr(M, "gauss_reparametrize", fixed_reparametrize)
+    with precision(prec):
+        m = M.AugmentedCycleGAN(make_opt(**kw), testing=True)
+        for k, net in m._net_dict().items():
+            load_recipe(net, k, 9, "init")
+        o = step.AugStep(step.Opt(**kw))
+        o.load({k: recipe.values_for(net.shapes, k, 9, "init") for k, net in o.nets().items()})
+        l1, v1, g1 = m.train_instance(t(A), t(B), t(z))
+        l0, v0, g0 = o.train_instance(A, B, z, eps=eps)
+        (lt, gt, vt), _ = STEP_TOL[prec]
+        assert list(l1.keys()) == list(l0.keys())
+        assert np.allclose(list(l1.values()), list(l0.values()), rtol=lt, atol=2e-6), (l1, l0)
+        assert np.allclose(list(g1.values()), list(g0.values()), rtol=gt, atol=1e-6), (g1, g0)
+        for k in ("fake_A", "fake_B", "rec_A", "rec_B"):
+            assert rel(n(v1[k]), v0[k]) < vt, k
+        assert l1["KLD_z_B"] != 0.0
