@@ -960,7 +960,9 @@ extern "C" int acg_conv2d_bwd_weight(const acg_conv_desc *d, const float *x, con
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     ACG_REQUIRE(ws != nullptr && ws_bytes >= acg_conv2d_bwd_weight_workspace_bytes(d), "acg_conv2d_bwd_weight: workspace too small");
-    const bool tout = thin_out(d) && d->stride == 1;
+    // the mirrored thin formulation walks the UNPADDED input pixels: right for zero padding only (a reflected border
+    // pairs x[refl(q)] with dy of pixels outside that walk); reflect-padded thin-output layers take the general path
+    const bool tout = thin_out(d) && d->stride == 1 && !(d->pad_mode == ACG_PAD_REFLECT && d->pad > 0);
     const bool fused = dw != nullptr && db != nullptr && g_acg_conv_impl == ACG_IMPL_MFMA && !tout;
     if (dw != nullptr) {
         rc = tout ? wgrad_thin_out(d, x, dy, dw, Or, Ir, ws, ws_bytes, st)

@@ -256,6 +256,8 @@ int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, fl
         else launch_bf16_kc<KCV, false, SP>(bn, grid, st, in, w, bias, out, g, t, inb, wb, wlo);            \
     } while (0)
     if (acg_igemm_uses_ws(g0)) return acg_igemm_x3_ws_launch(in, wp, bias, out, g0, t, n_w_elems, st);
+    static const bool no_patch = getenv("ACG_NO_PATCH") != nullptr; // A/B switch
+    if (!no_patch && acg_conv_patch16_ok(g0, t)) return acg_conv_patch16_launch(in, wp, bias, out, g0, t, n_w_elems, st);
     ACG_REQUIRE(g0.fold_p == 0, "igemm_conv_bf16: the fold bypass is implemented by the wave-specialised kernel only");
     if (split) { // hi+lo images double the LDS: 32-channel stages keep 3-4 blocks per CU
         if (g.Cin % 32 == 0) BF16_DISPATCH(32, true);

@@ -70,6 +70,9 @@ extern int g_acg_conv_impl;
 int acg_igemm_x3_ws_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g, const Taps &t,
                            long long n_w_elems, hipStream_t st, float *stats = nullptr);
 bool acg_igemm_uses_ws(const Geom &g);
+bool acg_conv_patch16_ok(const Geom &g, const Taps &t);
+int acg_conv_patch16_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g, const Taps &t,
+                            long long n_w_elems, hipStream_t st);
 int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g, const Taps &t,
                           int bn, long long n_w_elems, hipStream_t st);
 int acg_wgrad_bf16_launch(const float *x, const float *dy, float *part, const WGeom &g, const Taps &t, int bci, int bco,

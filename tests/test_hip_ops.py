@@ -35,6 +35,12 @@ CONV_CASES = [
     (3, 1, 1, "zero", 128, 128, 2, 9, 37),
     (3, 1, 1, "reflect", 64, 128, 1, 6, 40),
     (3, 1, 0, "zero", 128, 256, 1, 10, 34),
+    # 32 <-> 3 channel layers: the patch kernel (8x16 output tiles, partial tiles, reflect / zero halo), forward and
+    # as the data gradient of the 3 -> 32 stem
+    (7, 1, 3, "reflect", 32, 3, 2, 20, 37),
+    (7, 1, 3, "zero", 32, 3, 1, 9, 18),
+    (7, 1, 3, "reflect", 3, 32, 2, 18, 21),
+    (3, 1, 1, "zero", 32, 3, 1, 10, 10),
 ]
 
 
