@@ -23,8 +23,10 @@ static bool thin_out(const acg_conv_desc *d) { return thin_ok(d->Cor, d->K) && !
 // widest gathered tensor the VALU thin-output kernel takes.  It beats the padded 32-column MFMA tile only against the
 // fp32 matrix pipe (1.7 vs 2.9 ms on the 7x7 32->3 head); on the bf16 pipe the MFMA tile wins 2x (0.87 ms in bf16x3).
 static int thin_valu_max() { return g_acg_precision == ACG_PREC_F32 || g_acg_conv_impl != ACG_IMPL_MFMA ? 64 : 0; }
-static bool thin_out_valu_fwd(const acg_conv_desc *d) { return thin_out(d) && d->Ci <= thin_valu_max(); }
-static bool thin_in_valu_dgrad(const acg_conv_desc *d) { return thin_in(d) && d->Co <= thin_valu_max(); }
+// ... and it needs C/4 lanes per pixel to divide a wave: 16, 32 or 64 stored channels (others take the MFMA tile)
+static bool thin_valu_c(int C) { return C <= thin_valu_max() && (C == 16 || C == 32 || C == 64); }
+static bool thin_out_valu_fwd(const acg_conv_desc *d) { return thin_out(d) && thin_valu_c(d->Ci); }
+static bool thin_in_valu_dgrad(const acg_conv_desc *d) { return thin_in(d) && thin_valu_c(d->Co); }
 extern "C" int acg_set_conv_impl(int impl)
 {
     ACG_REQUIRE(impl == ACG_IMPL_MFMA || impl == ACG_IMPL_DIRECT, "acg_set_conv_impl: unknown impl %d", impl);
@@ -275,10 +277,10 @@ extern "C" int acg_pack_conv_weight(const float *w, int Or, int Ir, int K, int C
         };
         if (thin_i) {
             if (wf) hipLaunchKernelGGL(pack_weight_thin_kernel, dim3(64), dim3(256), 0, st, w, Or, Ir, K * K, acg_ncols_pad(Co), 0, wf);
-            if (wb && Co <= thin_valu_max()) hipLaunchKernelGGL(pack_weight_thinN_kernel, dim3(64), dim3(256), 0, st, w, Or, Ir, K * K, Co, 1, wb);
+            if (wb && thin_valu_c(Co)) hipLaunchKernelGGL(pack_weight_thinN_kernel, dim3(64), dim3(256), 0, st, w, Or, Ir, K * K, Co, 1, wb);
             else if (wb) regular(nullptr, wb);
         } else {
-            if (wf && Ci <= thin_valu_max()) hipLaunchKernelGGL(pack_weight_thinN_kernel, dim3(64), dim3(256), 0, st, w, Or, Ir, K * K, Ci, 0, wf);
+            if (wf && thin_valu_c(Ci)) hipLaunchKernelGGL(pack_weight_thinN_kernel, dim3(64), dim3(256), 0, st, w, Or, Ir, K * K, Ci, 0, wf);
             else if (wf) regular(wf, nullptr);
             if (wb) hipLaunchKernelGGL(pack_weight_thin_kernel, dim3(64), dim3(256), 0, st, w, Or, Ir, K * K, acg_ncols_pad(Ci), 1, wb);
         }

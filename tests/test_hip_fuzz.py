@@ -1,0 +1,75 @@
+"""Randomised convolution geometries: the MFMA path (whatever tile / kernel the dispatcher picks: wave-specialised, generic,
+patch, thin, frame fold ...) against the naive `direct` kernels, which take their geometry straight from the descriptor and
+share no tiling code with it.  Forward, data gradient, weight gradient and bias gradient, both parity arithmetics.
+Seeded: the same 160 cases every run."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    rs = np.random.RandomState(20260)
+    out = []
+    chans = [1, 3, 8, 16, 32, 48, 64, 128, 160, 256]
+    while len(out) < 160:
+        K = int(rs.choice([1, 3, 4, 7]))
+        stride = int(rs.choice([1, 1, 1, 2]))
+        mode = str(rs.choice(["zero", "reflect"]))
+        if stride == 2:
+            if K not in (3, 4):
+                continue
+            mode = "zero"
+        pad = int(rs.choice([0, K // 2, min(1, K - 1)]))  # the ABI requires pad < K
+        if mode == "reflect" and pad == 0:
+            mode = "zero"
+        Ci, Co = int(rs.choice(chans)), int(rs.choice(chans))
+        if Ci <= 4 and Co <= 4:
+            continue
+        if stride == 2 and Co <= 4:
+            continue  # not in the reference; dgrad raises (documented)
+        N = int(rs.choice([1, 2, 3]))
+        H, W = int(rs.randint(max(K, 2 * pad + 2, 5), 41)), int(rs.randint(max(K, 2 * pad + 2, 5), 41))
+        if Ci * Co >= 128 * 128:
+            H, W = min(H, 20), min(W, 24)
+        out.append((K, stride, pad, mode, Ci, Co, N, H, W))
+    return out
+
+
+def _run(case, impl):
+    from hip_util import t, n
+    from dtgan_amd import modules as M, ops
+    K, stride, pad, mode, Ci, Co, N, H, W = case
+    rs = np.random.RandomState(abs(hash(case)) % (2 ** 31))
+    x = rs.normal(0, 1, (N, Ci, H, W)); w = rs.normal(0, 0.2, (Co, Ci, K, K)); b = rs.normal(0, 0.5, (Co,))
+    ops.set_conv_impl(impl)
+    try:
+        if mode == "reflect":
+            m = M.Sequential(nn.ReflectionPad2d(pad), M.Conv2d(Ci, Co, K, stride=stride, padding=0, bias=True)).cuda()
+        else:
+            m = M.Sequential(M.Conv2d(Ci, Co, K, stride=stride, padding=pad, bias=True)).cuda()
+        conv = [c for c in m.modules() if c.__class__.__name__ == "Conv2d"][0]
+        with torch.no_grad():
+            conv.weight.copy_(t(w)); conv.bias.copy_(t(b))
+        xt = t(x, grad=True)
+        y = m(xt)
+        r = np.random.RandomState(7).normal(0, 1, tuple(y.shape))
+        y.backward(t(r))
+        return n(y), n(xt.grad), n(conv.weight.grad), n(conv.bias.grad)
+    finally:
+        ops.set_conv_impl("mfma")
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "f32"])
+@pytest.mark.parametrize("case", _cases(), ids=lambda c: "k%ds%dp%d%s_%dto%d_%dx%dx%d" % c)
+def test_conv_mfma_equals_direct(case, prec):
+    from hip_util import rel, precision
+    with precision(prec):
+        a = _run(case, "mfma")
+        d = _run(case, "direct")
+    tol = 3e-5 if prec == "bf16x3" else 1e-5
+    for got, ref, name in zip(a, d, ("fwd", "dgrad", "wgrad", "bias")):
+        assert got.shape == ref.shape, name
+        assert rel(got, ref) < (tol * 4 if name == "wgrad" else tol), name
