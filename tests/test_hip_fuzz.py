@@ -73,3 +73,43 @@ def test_conv_mfma_equals_direct(case, prec):
     for got, ref, name in zip(a, d, ("fwd", "dgrad", "wgrad", "bias")):
         assert got.shape == ref.shape, name
         assert rel(got, ref) < (tol * 4 if name == "wgrad" else tol), name
+
+
+def _norm_cases():
+    rs = np.random.RandomState(777)
+    out = []
+    for _ in range(24):
+        C = int(rs.choice([3, 8, 16, 24, 48, 64, 128, 130, 256]))
+        N = int(rs.choice([1, 2, 5]))
+        H, W = int(rs.randint(2, 50)), int(rs.randint(2, 50))
+        out.append((N, C, H, W))
+    return out
+
+
+@pytest.mark.parametrize("shape", _norm_cases(), ids=lambda s: "%dx%dx%dx%d" % s)
+def test_instance_norm_random_shapes(shape):
+    """InstanceNorm (modules.py:64-97: biased variance, eps 1e-5, affine) forward / backward on random shapes — channel
+    counts that are not multiples of 16, pixel counts around the 256-pixel reduction chunks — against the same formula in
+    fp64 torch on the device."""
+    from hip_util import t, n, rel
+    from dtgan_amd import modules as M
+    N, C, H, W = shape
+    rs = np.random.RandomState(N * 1000 + C + H * 7 + W)
+    x = rs.normal(0.3, 1.2, shape); sc = rs.normal(1, 0.3, C); sh = rs.normal(0, 0.3, C); r = rs.normal(0, 1, shape)
+    m = M.InstanceNorm(C).cuda()
+    with torch.no_grad():
+        m.scale.copy_(t(sc)); m.shift.copy_(t(sh))
+    xt = t(x, grad=True)
+    y = m(xt)
+    y.backward(t(r))
+    xd = torch.tensor(x, dtype=torch.float64, device="cuda", requires_grad=True)
+    scd = torch.tensor(sc, dtype=torch.float64, device="cuda", requires_grad=True)
+    shd = torch.tensor(sh, dtype=torch.float64, device="cuda", requires_grad=True)
+    mu = xd.mean(dim=(2, 3), keepdim=True)
+    var = ((xd - mu) ** 2).mean(dim=(2, 3), keepdim=True)
+    yd = (xd - mu) / torch.sqrt(var + 1e-5) * scd.view(1, C, 1, 1) + shd.view(1, C, 1, 1)
+    yd.backward(torch.tensor(r, dtype=torch.float64, device="cuda"))
+    assert rel(n(y), yd.detach().cpu().numpy()) < 2e-5
+    assert rel(n(xt.grad), xd.grad.cpu().numpy()) < 2e-4
+    assert rel(n(m.scale.grad), scd.grad.cpu().numpy()) < 2e-4
+    assert rel(n(m.shift.grad), shd.grad.cpu().numpy()) < 2e-4
