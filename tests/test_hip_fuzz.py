@@ -113,3 +113,42 @@ def test_instance_norm_random_shapes(shape):
     assert rel(n(xt.grad), xd.grad.cpu().numpy()) < 2e-4
     assert rel(n(m.scale.grad), scd.grad.cpu().numpy()) < 2e-4
     assert rel(n(m.shift.grad), shd.grad.cpu().numpy()) < 2e-4
+
+
+def _ct_cases():
+    rs = np.random.RandomState(4242)
+    out = []
+    for _ in range(20):
+        Ci, Co = int(rs.choice([8, 16, 32, 48, 64, 128, 256])), int(rs.choice([8, 16, 32, 64, 128]))
+        N, H, W = int(rs.choice([1, 2, 3])), int(rs.randint(2, 24)), int(rs.randint(2, 24))
+        out.append((Ci, Co, N, H, W))
+    return out
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "f32"])
+@pytest.mark.parametrize("dims", _ct_cases(), ids=lambda c: "%dto%d_%dx%dx%d" % c)
+def test_conv_transpose_mfma_equals_direct(dims, prec):
+    """nn.ConvTranspose2d(k3, s2, p1, op1) (networks.py:176-181, 228-233): sub-pixel-phase MFMA path vs the naive kernels"""
+    from hip_util import t, n, rel, precision
+    from dtgan_amd import modules as M, ops
+    Ci, Co, N, H, W = dims
+    rs = np.random.RandomState(Ci * 31 + Co + H)
+    x = rs.normal(0, 1, (N, Ci, H, W)); w = rs.normal(0, 0.3, (Ci, Co, 3, 3)); b = rs.normal(0, 0.5, (Co,))
+    r = rs.normal(0, 1, (N, Co, 2 * H, 2 * W))
+    res = {}
+    with precision(prec):
+        for impl in ("mfma", "direct"):
+            ops.set_conv_impl(impl)
+            try:
+                m = M.ConvTranspose2d(Ci, Co, 3, stride=2, padding=1, output_padding=1, bias=True).cuda()
+                with torch.no_grad():
+                    m.weight.copy_(t(w)); m.bias.copy_(t(b))
+                xt = t(x, grad=True)
+                y = m(xt)
+                y.backward(t(r))
+                res[impl] = (n(y), n(xt.grad), n(m.weight.grad), n(m.bias.grad))
+            finally:
+                ops.set_conv_impl("mfma")
+    tol = 3e-5 if prec == "bf16x3" else 1e-5
+    for got, ref, name in zip(res["mfma"], res["direct"], ("fwd", "dgrad", "wgrad", "bias")):
+        assert rel(got, ref) < (tol * 4 if name == "wgrad" else tol), name
