@@ -11,6 +11,7 @@
 // and per resident workgroup; two workgroups per CU).
 #include "common.h"
 #include "conv_internal.h"
+#include <cstdlib>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
@@ -27,20 +28,40 @@ constexpr int BM = 128, BN = 128, KC = 32, NK8 = KC / 8;
 // SQ_LDS_BANK_CONFLICT = 0 (a [row][16 k] image with 32-B rows is 2-way conflicted: 42 % of the LDS cycles).
 constexpr int APL = BM * 8, BPL = BN * 8;             // plane strides (bf16 elements)
 constexpr int A_IMG = NK8 * APL, B_IMG = NK8 * BPL;   // one hi (or lo) image
-constexpr int BUF = 2 * A_IMG + 2 * B_IMG;            // A hi, A lo, B hi, B lo
 __device__ __forceinline__ int lds_at(int plane, int row, int pl) { return plane * pl + ((row ^ (2 * plane)) * 8); }
+
+// ROWP ("row patch") variant, stride-1 K x K convolutions on output grids whose width divides 128: the 128-pixel tile
+// is R = 128/GW whole output rows, and the K taps of one kernel row read the SAME input rows shifted by one pixel.  The A
+// image then holds R segments of GW+K-1 gathered pixels (halo included) and is refreshed once per kernel ROW instead of
+// once per tap — a third of the A loads, splits and LDS stores for a 3x3 — while a tap's fragment is 16 consecutive
+// image rows starting kx rows further.  Any shift must stay conflict-free, so the planes are not XOR-permuted here:
+// planes 2q and 2q+1 (the pair a ds_read_b128 lane group spans) sit a multiple of 256 B apart (16 consecutive rows ->
+// 16 distinct slots in both), and the pairs are offset by 64 B so that the 8-lane store groups (2 pixels x 4 planes) land
+// 2-way (16 array cycles against the 13-cycle store).
+constexpr int RP_ROWS = 160;                          // row capacity per plane: R*(GW+K-1) <= 128 + 8*3
+constexpr int RP_PL = RP_ROWS * 8;                    // plane size (bf16 elements)
+constexpr int RP_IMG = NK8 * RP_PL + 64;              // one hi (or lo) image incl. the pair offset
+__device__ __forceinline__ int rp_at(int plane, int row) { return plane * RP_PL + (plane >> 1) * 32 + row * 8; }
+template <bool ROWP> struct WsLds {
+    static constexpr int AIMG = ROWP ? RP_IMG : A_IMG;
+    static constexpr int TOTAL = 4 * AIMG + 4 * B_IMG;            // [A buf 0/1][hi|lo] then [B buf 0/1][hi|lo]
+    static __device__ __forceinline__ int a_off(int buf) { return buf * 2 * AIMG; }
+    static __device__ __forceinline__ int b_off(int buf) { return 4 * AIMG + buf * 2 * B_IMG; }
+};
 }
 
 // 4 waves per SIMD = two 8-wave workgroups per CU: the register budget is 128 VGPRs (all four instances allocate 122,
 // no scratch).  STATS: also emit the per-tile (mean, M2) for an InstanceNorm behind the convolution (see the epilogue).
-template <bool REFLECT, bool STATS>
+template <bool REFLECT, bool STATS, bool ROWP>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
                                                         const float *__restrict__ bias, float *__restrict__ out,
                                                         Geom g, Taps taps, unsigned in_bytes, unsigned w_bytes,
-                                                        unsigned w_lo_bytes, float *__restrict__ stats)
+                                                        unsigned w_lo_bytes, float *__restrict__ stats, int kdim)
 {
-    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF];
+    typedef WsLds<ROWP> L;
+    constexpr int AIMG = L::AIMG;
+    __shared__ __attribute__((aligned(16))) __bf16 lds[L::TOTAL];
     __shared__ float *out_ptr[BM]; // output row of every tile pixel (nullptr past the end)
     __shared__ const float *add_ptr[BM]; // row of Geom.addend to add on the way out (nullptr: none)
     __shared__ float red[2][2][64]; // [wn][wm][column]: cross-wave fold of the per-tile statistics
@@ -112,36 +133,12 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
             b_voff[i] = (unsigned)((((plane >> 1) * g.ncols_pad + n0 + col) * 16 + (plane & 1) * 8) * 2);
             b_lds[i] = lds_at(plane, col, BPL);
         }
-        f32x8 ra[AL];
+        f32x8 ra[ROWP ? 3 : AL]; // ROWP: up to 3 of the R*(GW+K-1)*4 <= 640 patch units per thread
         u32x4 rb[BL], rbl[BL];
-        auto load_stage = [&](int s) {
-            const int cc = s / taps.n;
-            const int t = s - cc * taps.n;
-            const int c0 = cc * KC;
-            const int pk = taps.pk[t];
-            const int ty = (pk << 24) >> 24, tx = (pk << 16) >> 24, tw = pk >> 16;
-#pragma unroll
-            for (int j = 0; j < AL; ++j) {
-                int pix;
-                bool ok = a_ok[j];
-                if (REFLECT) {
-                    int iy = a_by[j] + ty, ix = a_bx[j] + tx;
-                    iy = iy < 0 ? -iy : iy;
-                    iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
-                    ix = ix < 0 ? -ix : ix;
-                    ix = ix >= g.Win ? 2 * (g.Win - 1) - ix : ix;
-                    pix = (a_row[j] + iy) * g.Win + ix;
-                } else {
-                    const int iy = a_by[j] + ty, ix = a_bx[j] + tx;
-                    ok = ok && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
-                    pix = a_row[j] + ty * g.Win + tx;
-                }
-                const unsigned off = (unsigned)(pix * g.Cin + c0 + 8 * u) * 4u;
-                const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off, ok), 0, 0);
-                const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off + 16u, ok), 0, 0);
-                const f32x4 flo = __builtin_bit_cast(f32x4, lo), fhi = __builtin_bit_cast(f32x4, hi);
-                ra[j] = (f32x8){flo[0], flo[1], flo[2], flo[3], fhi[0], fhi[1], fhi[2], fhi[3]};
-            }
+        // ROWP geometry: the tile is rows gy0 .. gy0+R-1 of image n_img; patch pixel pp = r*RW + px
+        const int RW = g.GW + kdim - 1, npu = ROWP ? (BM / g.GW) * RW * 4 : 0;
+        const int n_img = (int)(m0 / GHW), gy0 = (int)(m0 - (long long)n_img * GHW) / g.GW;
+        auto load_b = [&](int tw, int c0) {
             const unsigned soff = (unsigned)(((tw * (g.Cin >> 4) + (c0 >> 4)) * g.ncols_pad) * 16) * 2u;
 #pragma unroll
             for (int i = 0; i < BL; ++i) {
@@ -149,17 +146,92 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
                 rbl[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[i], soff + w_lo_bytes, 0);
             }
         };
+        auto load_stage = [&](int s) {
+            const int cc = s / taps.n;
+            const int t = s - cc * taps.n;
+            const int c0 = cc * KC;
+            const int pk = taps.pk[t];
+            const int ty = (pk << 24) >> 24, tx = (pk << 16) >> 24, tw = pk >> 16;
+            if constexpr (ROWP) {
+                if (t % kdim == 0) { // first tap of a kernel row: gather the R x (GW+K-1) patch of this row (tx = its dx)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int q = pt + 256 * j;
+                        const int pp = q >> 2, uu = q & 3;
+                        const int r = pp / RW, px = pp - r * RW;
+                        int iy = gy0 + r + ty, ix = px + tx;
+                        bool ok = q < npu;
+                        if (REFLECT) {
+                            iy = iy < 0 ? -iy : iy;
+                            iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
+                            ix = ix < 0 ? -ix : ix;
+                            ix = ix >= g.Win ? 2 * (g.Win - 1) - ix : ix;
+                        } else {
+                            ok = ok && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+                        }
+                        const unsigned off = (unsigned)(((n_img * g.Hin + iy) * g.Win + ix) * g.Cin + c0 + 8 * uu) * 4u;
+                        const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off, ok), 0, 0);
+                        const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off + 16u, ok), 0, 0);
+                        const f32x4 flo = __builtin_bit_cast(f32x4, lo), fhi = __builtin_bit_cast(f32x4, hi);
+                        ra[j] = (f32x8){flo[0], flo[1], flo[2], flo[3], fhi[0], fhi[1], fhi[2], fhi[3]};
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < AL; ++j) {
+                    int pix;
+                    bool ok = a_ok[j];
+                    if (REFLECT) {
+                        int iy = a_by[j] + ty, ix = a_bx[j] + tx;
+                        iy = iy < 0 ? -iy : iy;
+                        iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
+                        ix = ix < 0 ? -ix : ix;
+                        ix = ix >= g.Win ? 2 * (g.Win - 1) - ix : ix;
+                        pix = (a_row[j] + iy) * g.Win + ix;
+                    } else {
+                        const int iy = a_by[j] + ty, ix = a_bx[j] + tx;
+                        ok = ok && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+                        pix = a_row[j] + ty * g.Win + tx;
+                    }
+                    const unsigned off = (unsigned)(pix * g.Cin + c0 + 8 * u) * 4u;
+                    const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off, ok), 0, 0);
+                    const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off + 16u, ok), 0, 0);
+                    const f32x4 flo = __builtin_bit_cast(f32x4, lo), fhi = __builtin_bit_cast(f32x4, hi);
+                    ra[j] = (f32x8){flo[0], flo[1], flo[2], flo[3], fhi[0], fhi[1], fhi[2], fhi[3]};
+                }
+            }
+            load_b(tw, c0);
+        };
         load_stage(0);
         for (int s = 0; s < S; ++s) {
-            __bf16 *As = lds + (s & 1) * BUF, *Bs = As + 2 * A_IMG;
+            // A buffer: per kernel row in ROWP (s / kdim), per stage otherwise; B buffer: per stage
+            const bool a_new = !ROWP || (s % taps.n) % kdim == 0;
+            __bf16 *As = lds + L::a_off(ROWP ? (s / kdim) & 1 : s & 1), *Bs = lds + L::b_off(s & 1);
+            if (a_new) {
+                if constexpr (ROWP) {
 #pragma unroll
-            for (int j = 0; j < AL; ++j) {
-                const int a_at = lds_at(u, rrow + RPP * j, APL);
-                const float v[8] = {ra[j][0], ra[j][1], ra[j][2], ra[j][3], ra[j][4], ra[j][5], ra[j][6], ra[j][7]};
-                acg_u32x4 hi, lo;
-                acg_split8(v, hi, lo);
-                *(acg_u32x4 *)&As[a_at] = hi;
-                *(acg_u32x4 *)&As[A_IMG + a_at] = lo;
+                    for (int j = 0; j < 3; ++j) {
+                        const int q = pt + 256 * j;
+                        if (q < npu) {
+                            const int a_at = rp_at(q & 3, q >> 2);
+                            const float v[8] = {ra[j][0], ra[j][1], ra[j][2], ra[j][3], ra[j][4], ra[j][5], ra[j][6], ra[j][7]};
+                            acg_u32x4 hi, lo;
+                            acg_split8(v, hi, lo);
+                            *(acg_u32x4 *)&As[a_at] = hi;
+                            *(acg_u32x4 *)&As[AIMG + a_at] = lo;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < AL; ++j) {
+                        const int a_at = lds_at(u, rrow + RPP * j, APL);
+                        const float v[8] = {ra[j][0], ra[j][1], ra[j][2], ra[j][3], ra[j][4], ra[j][5], ra[j][6], ra[j][7]};
+                        acg_u32x4 hi, lo;
+                        acg_split8(v, hi, lo);
+                        *(acg_u32x4 *)&As[a_at] = hi;
+                        *(acg_u32x4 *)&As[AIMG + a_at] = lo;
+                    }
+                }
             }
 #pragma unroll
             for (int i = 0; i < BL; ++i) {
@@ -167,7 +239,7 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
                 *(u32x4 *)&Bs[B_IMG + b_lds[i]] = rbl[i];
             }
             if (s + 1 < S) load_stage(s + 1);
-            __syncthreads(); // buffer s&1 is full; the consumers have drained buffer (s+1)&1
+            __syncthreads(); // B buffer s&1 (and the A buffer of its kernel row) is full; the consumers have drained the other
         }
         return;
     }
@@ -182,15 +254,25 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int pl = lane >> 4, lr = lane & 15;
+    int arow[4]; // ROWP: image row of this lane's pixel in row-tile i for the first tap of a kernel row
+    if constexpr (ROWP) {
+        const int RWc = g.GW + kdim - 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tp = wm * TM + i * 16 + lr, r = tp / g.GW;
+            arow[i] = r * RWc + (tp - r * g.GW);
+        }
+    }
     for (int s = 0; s < S; ++s) {
         __syncthreads();
-        const __bf16 *As = lds + (s & 1) * BUF, *Bs = As + 2 * A_IMG;
+        const __bf16 *As = lds + L::a_off(ROWP ? (s / kdim) & 1 : s & 1), *Bs = lds + L::b_off(s & 1);
+        const int kx = ROWP ? (s % taps.n) % kdim : 0;
         bf16x8 a[4], al[4], b[4], bl[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int at = lds_at(pl, wm * TM + i * 16 + lr, APL);
+            const int at = ROWP ? rp_at(pl, arow[i] + kx) : lds_at(pl, wm * TM + i * 16 + lr, APL);
             a[i] = *(const bf16x8 *)&As[at];
-            al[i] = *(const bf16x8 *)&As[A_IMG + at];
+            al[i] = *(const bf16x8 *)&As[AIMG + at];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -212,7 +294,7 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
     // and leaves in coalesced 512-byte rows — 37 us per launch faster than storing the 16-column MFMA fragments
     // directly (64-byte segments), and the accumulators die early.
     constexpr int TS = BN; // row stride (floats)
-    static_assert(BM * TS * 4 <= 2 * BUF * 2, "the staged tile must fit the two LDS buffers");
+    static_assert(BM * TS * 4 <= L::TOTAL * 2, "the staged tile must fit the LDS buffers");
     float *tile = (float *)lds;
     __syncthreads(); // every consumer wave is done with the last LDS buffer (the producers have exited)
 #pragma unroll
@@ -282,9 +364,24 @@ int acg_igemm_x3_ws_launch(const float *in, const void *wp, const float *bias, f
     ACG_REQUIRE(stats == nullptr || (((long long)g.GH * g.GW) % BM == 0 && g.act == ACG_ACT_NONE && g.os == 1),
                 "igemm_conv_x3_ws: per-tile statistics need whole 128-pixel tiles per image and no activation");
     const unsigned inb = (unsigned)in_bytes, wb = (unsigned)w_bytes, wlo = (unsigned)(n_w_elems * 2);
-#define X3_WS(R, S) hipLaunchKernelGGL((igemm_conv_x3_ws<R, S>), grid, dim3(512), 0, st, in, (const __bf16 *)wp, bias, out, g, t, inb, wb, wlo, stats)
-    if (g.reflect) { if (stats) X3_WS(true, true); else X3_WS(true, false); }
-    else { if (stats) X3_WS(false, true); else X3_WS(false, false); }
+    // row-patch variant: forward-style tap lists (K x K, row-major, dx ascending by 1 within a kernel row) on grids whose
+    // width divides the 128-pixel tile
+    int kdim = 0;
+    static const bool no_rowp = getenv("ACG_NO_ROWP") != nullptr; // A/B switch
+    if (!no_rowp && g.is == 1 && g.os == 1 && g.oy0 == 0 && g.ox0 == 0 && g.fold_p == 0) {
+        int k = 1;
+        while (k * k < t.n) ++k;
+        bool ok = k * k == t.n && k >= 2 && g.GW % 16 == 0 && BM % g.GW == 0 && ((long long)g.GH * g.GW) % BM == 0 &&
+                  (BM / g.GW) * (g.GW + k - 1) <= RP_ROWS && g.Hout == g.GH && g.Wout == g.GW;
+        for (int i = 0; ok && i < t.n; ++i)
+            ok = t.dy[i] == t.dy[(i / k) * k] && t.dx[i] == t.dx[(i / k) * k] + i % k;
+        if (ok) kdim = k;
+    }
+#define X3_WS(R, S, P) hipLaunchKernelGGL((igemm_conv_x3_ws<R, S, P>), grid, dim3(512), 0, st, in, (const __bf16 *)wp, bias, out, g, t, inb, wb, wlo, stats, kdim)
+#define X3_WS2(R, S) do { if (kdim) X3_WS(R, S, true); else X3_WS(R, S, false); } while (0)
+    if (g.reflect) { if (stats) X3_WS2(true, true); else X3_WS2(true, false); }
+    else { if (stats) X3_WS2(false, true); else X3_WS2(false, false); }
+#undef X3_WS2
 #undef X3_WS
     ACG_CHECK_LAUNCH("igemm_conv_x3_ws");
     return ACG_OK;

@@ -41,6 +41,12 @@ CONV_CASES = [
     (7, 1, 3, "zero", 32, 3, 1, 9, 18),
     (7, 1, 3, "reflect", 3, 32, 2, 18, 21),
     (3, 1, 1, "zero", 32, 3, 1, 10, 10),
+    # row-patch variant of the wave-specialised kernel: output width 16 / 32 / 64 / 128 (R = 8 / 4 / 2 / 1 rows per tile)
+    (3, 1, 1, "reflect", 128, 128, 1, 16, 16),
+    (3, 1, 1, "zero", 128, 128, 2, 8, 32),
+    (3, 1, 1, "reflect", 64, 128, 1, 4, 64),
+    (4, 1, 1, "zero", 128, 128, 1, 17, 17),
+    (3, 1, 1, "reflect", 128, 256, 1, 2, 128),
 ]
 
 
