@@ -57,7 +57,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
                                                         const float *__restrict__ bias, float *__restrict__ out,
                                                         Geom g, Taps taps, unsigned in_bytes, unsigned w_bytes,
-                                                        unsigned w_lo_bytes, float *__restrict__ stats, int kdim)
+                                                        unsigned w_lo_bytes, float *__restrict__ stats, int kdim, int dxmin)
 {
     typedef WsLds<ROWP> L;
     constexpr int AIMG = L::AIMG;
@@ -153,13 +153,13 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
             const int pk = taps.pk[t];
             const int ty = (pk << 24) >> 24, tx = (pk << 16) >> 24, tw = pk >> 16;
             if constexpr (ROWP) {
-                if (t % kdim == 0) { // first tap of a kernel row: gather the R x (GW+K-1) patch of this row (tx = its dx)
+                if (t % kdim == 0) { // first tap of a kernel row: gather the R x (GW+K-1) patch of this row, from dx = dxmin
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
                         const int q = pt + 256 * j;
                         const int pp = q >> 2, uu = q & 3;
                         const int r = pp / RW, px = pp - r * RW;
-                        int iy = gy0 + r + ty, ix = px + tx;
+                        int iy = gy0 + r + ty, ix = px + dxmin;
                         bool ok = q < npu;
                         if (REFLECT) {
                             iy = iy < 0 ? -iy : iy;
@@ -266,7 +266,7 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
     for (int s = 0; s < S; ++s) {
         __syncthreads();
         const __bf16 *As = lds + L::a_off(ROWP ? (s / kdim) & 1 : s & 1), *Bs = lds + L::b_off(s & 1);
-        const int kx = ROWP ? (s % taps.n) % kdim : 0;
+        const int kx = ROWP ? ((taps.pk[s % taps.n] << 16) >> 24) - dxmin : 0; // this tap's column offset in the patch
         bf16x8 a[4], al[4], b[4], bl[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -364,20 +364,22 @@ int acg_igemm_x3_ws_launch(const float *in, const void *wp, const float *bias, f
     ACG_REQUIRE(stats == nullptr || (((long long)g.GH * g.GW) % BM == 0 && g.act == ACG_ACT_NONE && g.os == 1),
                 "igemm_conv_x3_ws: per-tile statistics need whole 128-pixel tiles per image and no activation");
     const unsigned inb = (unsigned)in_bytes, wb = (unsigned)w_bytes, wlo = (unsigned)(n_w_elems * 2);
-    // row-patch variant: forward-style tap lists (K x K, row-major, dx ascending by 1 within a kernel row) on grids whose
-    // width divides the 128-pixel tile
-    int kdim = 0;
+    // row-patch variant: K x K tap lists in kernel-row order (forward: dx ascending, stride-1 data gradient: descending) on
+    // grids whose width divides the 128-pixel tile
+    int kdim = 0, dxmin = 0;
     static const bool no_rowp = getenv("ACG_NO_ROWP") != nullptr; // A/B switch
     if (!no_rowp && g.is == 1 && g.os == 1 && g.oy0 == 0 && g.ox0 == 0 && g.fold_p == 0) {
         int k = 1;
         while (k * k < t.n) ++k;
         bool ok = k * k == t.n && k >= 2 && g.GW % 16 == 0 && BM % g.GW == 0 && ((long long)g.GH * g.GW) % BM == 0 &&
                   (BM / g.GW) * (g.GW + k - 1) <= RP_ROWS && g.Hout == g.GH && g.Wout == g.GW;
-        for (int i = 0; ok && i < t.n; ++i)
-            ok = t.dy[i] == t.dy[(i / k) * k] && t.dx[i] == t.dx[(i / k) * k] + i % k;
-        if (ok) kdim = k;
+        int mn = t.dx[0];
+        for (int i = 1; i < t.n; ++i) mn = t.dx[i] < mn ? t.dx[i] : mn;
+        for (int i = 0; ok && i < t.n; ++i) // one dy per kernel row, its dx within [mn, mn + k) (ascending: forward, descending: data gradient)
+            ok = t.dy[i] == t.dy[(i / k) * k] && t.dx[i] >= mn && t.dx[i] < mn + k;
+        if (ok) { kdim = k; dxmin = mn; }
     }
-#define X3_WS(R, S, P) hipLaunchKernelGGL((igemm_conv_x3_ws<R, S, P>), grid, dim3(512), 0, st, in, (const __bf16 *)wp, bias, out, g, t, inb, wb, wlo, stats, kdim)
+#define X3_WS(R, S, P) hipLaunchKernelGGL((igemm_conv_x3_ws<R, S, P>), grid, dim3(512), 0, st, in, (const __bf16 *)wp, bias, out, g, t, inb, wb, wlo, stats, kdim, dxmin)
 #define X3_WS2(R, S) do { if (kdim) X3_WS(R, S, true); else X3_WS(R, S, false); } while (0)
     if (g.reflect) { if (stats) X3_WS2(true, true); else X3_WS2(true, false); }
     else { if (stats) X3_WS2(false, true); else X3_WS2(false, false); }

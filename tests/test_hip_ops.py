@@ -47,6 +47,7 @@ CONV_CASES = [
     (3, 1, 1, "reflect", 64, 128, 1, 4, 64),
     (4, 1, 1, "zero", 128, 128, 1, 17, 17),
     (3, 1, 1, "reflect", 128, 256, 1, 2, 128),
+    (4, 1, 1, "zero", 128, 128, 2, 16, 32),   # its DATA gradient (grid = the 16x32 input, taps with descending dx)
 ]
 
 
