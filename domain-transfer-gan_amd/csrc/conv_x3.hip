@@ -30,15 +30,15 @@ constexpr int APL = BM * 8, BPL = BN * 8;             // plane strides (bf16 ele
 constexpr int A_IMG = NK8 * APL, B_IMG = NK8 * BPL;   // one hi (or lo) image
 __device__ __forceinline__ int lds_at(int plane, int row, int pl) { return plane * pl + ((row ^ (2 * plane)) * 8); }
 
-// ROWP ("row patch") variant, stride-1 K x K convolutions on output grids whose width divides 128: the 128-pixel tile
-// is R = 128/GW whole output rows, and the K taps of one kernel row read the SAME input rows shifted by one pixel.  The A
-// image then holds R segments of GW+K-1 gathered pixels (halo included) and is refreshed once per kernel ROW instead of
-// once per tap — a third of the A loads, splits and LDS stores for a 3x3 — while a tap's fragment is 16 consecutive
-// image rows starting kx rows further.  Any shift must stay conflict-free, so the planes are not XOR-permuted here:
+// ROWP ("row patch") variant, stride-1 K x K convolutions: the 128 consecutive output pixels of a tile are a few
+// SEGMENTS of grid rows, and the K taps of one kernel row read the SAME input rows shifted by one pixel.  The A image then
+// holds the segments with their K-1 halo pixels and is refreshed once per kernel ROW instead of once per tap — a third of
+// the A loads, splits and LDS stores for a 3x3 — while a tap's fragment is the 16 image rows of its pixels, kx further
+// (consecutive except where a 16-pixel group crosses a segment end: those few lanes are 2-way).  Any shift must stay conflict-free, so the planes are not XOR-permuted here:
 // planes 2q and 2q+1 (the pair a ds_read_b128 lane group spans) sit a multiple of 256 B apart (16 consecutive rows ->
 // 16 distinct slots in both), and the pairs are offset by 64 B so that the 8-lane store groups (2 pixels x 4 planes) land
 // 2-way (16 array cycles against the 13-cycle store).
-constexpr int RP_ROWS = 160;                          // row capacity per plane: R*(GW+K-1) <= 128 + 8*3
+constexpr int RP_ROWS = 160;                          // row capacity per plane: 128 + segments * (K-1)
 constexpr int RP_PL = RP_ROWS * 8;                    // plane size (bf16 elements)
 constexpr int RP_IMG = NK8 * RP_PL + 64;              // one hi (or lo) image incl. the pair offset
 __device__ __forceinline__ int rp_at(int plane, int row) { return plane * RP_PL + (plane >> 1) * 32 + row * 8; }
@@ -133,11 +133,17 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
             b_voff[i] = (unsigned)((((plane >> 1) * g.ncols_pad + n0 + col) * 16 + (plane & 1) * 8) * 2);
             b_lds[i] = lds_at(plane, col, BPL);
         }
-        f32x8 ra[ROWP ? 3 : AL]; // ROWP: up to 3 of the R*(GW+K-1)*4 <= 640 patch units per thread
+        f32x8 ra[ROWP ? 3 : AL]; // ROWP: up to 3 of the <= 160*4 patch units per thread
         u32x4 rb[BL], rbl[BL];
-        // ROWP geometry: the tile is rows gy0 .. gy0+R-1 of image n_img; patch pixel pp = r*RW + px
-        const int RW = g.GW + kdim - 1, npu = ROWP ? (BM / g.GW) * RW * 4 : 0;
-        const int n_img = (int)(m0 / GHW), gy0 = (int)(m0 - (long long)n_img * GHW) / g.GW;
+        // ROWP geometry: the tile's 128 consecutive output pixels form SEGMENTS, one per grid row it touches (the first
+        // starts at column x0, the others at 0); segment s occupies image rows [row0(s), row0(s) + len(s) + K-1)
+        const long long grow0 = m0 / g.GW;                     // global grid row (image * GH + gy) of the first pixel
+        const int x0 = (int)(m0 - grow0 * g.GW);
+        const int first = g.GW - x0 < BM ? g.GW - x0 : BM;     // pixels in segment 0
+        const int RW = g.GW + kdim - 1;
+        const int nseg = first >= BM ? 1 : 1 + (BM - first + g.GW - 1) / g.GW;
+        const int npu = ROWP ? (BM + nseg * (kdim - 1)) * 4 : 0;
+        const long long grows = g.Mtot / g.GW;                 // grid rows in the whole tensor
         auto load_b = [&](int tw, int c0) {
             const unsigned soff = (unsigned)(((tw * (g.Cin >> 4) + (c0 >> 4)) * g.ncols_pad) * 16) * 2u;
 #pragma unroll
@@ -158,9 +164,16 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
                     for (int j = 0; j < 3; ++j) {
                         const int q = pt + 256 * j;
                         const int pp = q >> 2, uu = q & 3;
-                        const int r = pp / RW, px = pp - r * RW;
-                        int iy = gy0 + r + ty, ix = px + dxmin;
-                        bool ok = q < npu;
+                        int seg = 0, px = pp;
+                        if (pp >= first + kdim - 1) {
+                            const int qq = pp - (first + kdim - 1);
+                            seg = 1 + qq / RW;
+                            px = qq - (seg - 1) * RW;
+                        }
+                        const long long grow = grow0 + seg;
+                        const int n_img = (int)(grow / g.GH);
+                        int iy = (int)(grow - (long long)n_img * g.GH) + ty, ix = (seg == 0 ? x0 : 0) + px + dxmin;
+                        bool ok = q < npu && grow < grows;
                         if (REFLECT) {
                             iy = iy < 0 ? -iy : iy;
                             iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
@@ -254,13 +267,18 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int pl = lane >> 4, lr = lane & 15;
-    int arow[4]; // ROWP: image row of this lane's pixel in row-tile i for the first tap of a kernel row
+    int arow[4]; // ROWP: image row of this lane's pixel in row-tile i at column offset 0 of its segment's patch
     if constexpr (ROWP) {
-        const int RWc = g.GW + kdim - 1;
+        const int x0c = (int)(m0 % g.GW), firstc = g.GW - x0c < BM ? g.GW - x0c : BM, RWc = g.GW + kdim - 1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int tp = wm * TM + i * 16 + lr, r = tp / g.GW;
-            arow[i] = r * RWc + (tp - r * g.GW);
+            const int tp = wm * TM + i * 16 + lr;
+            if (tp < firstc) {
+                arow[i] = tp;
+            } else {
+                const int sg = 1 + (tp - firstc) / g.GW;
+                arow[i] = (firstc + kdim - 1) + (sg - 1) * RWc + (tp - firstc - (sg - 1) * g.GW);
+            }
         }
     }
     for (int s = 0; s < S; ++s) {
@@ -368,11 +386,10 @@ int acg_igemm_x3_ws_launch(const float *in, const void *wp, const float *bias, f
     // grids whose width divides the 128-pixel tile
     int kdim = 0, dxmin = 0;
     static const bool no_rowp = getenv("ACG_NO_ROWP") != nullptr; // A/B switch
-    if (!no_rowp && g.is == 1 && g.os == 1 && g.oy0 == 0 && g.ox0 == 0 && g.fold_p == 0) {
+    if (!no_rowp && g.is == 1 && g.os == 1 && g.oy0 == 0 && g.ox0 == 0) {
         int k = 1;
         while (k * k < t.n) ++k;
-        bool ok = k * k == t.n && k >= 2 && g.GW % 16 == 0 && BM % g.GW == 0 && ((long long)g.GH * g.GW) % BM == 0 &&
-                  (BM / g.GW) * (g.GW + k - 1) <= RP_ROWS && g.Hout == g.GH && g.Wout == g.GW;
+        bool ok = k * k == t.n && k >= 2 && BM + (2 + BM / g.GW) * (k - 1) <= RP_ROWS && g.Hout == g.GH && g.Wout == g.GW;
         int mn = t.dx[0];
         for (int i = 1; i < t.n; ++i) mn = t.dx[i] < mn ? t.dx[i] : mn;
         for (int i = 0; ok && i < t.n; ++i) // one dy per kernel row, its dx within [mn, mn + k) (ascending: forward, descending: data gradient)
