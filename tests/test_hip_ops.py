@@ -48,6 +48,8 @@ CONV_CASES = [
     (4, 1, 1, "zero", 128, 128, 1, 17, 17),
     (3, 1, 1, "reflect", 128, 256, 1, 2, 128),
     (4, 1, 1, "zero", 128, 128, 2, 16, 32),   # its DATA gradient (grid = the 16x32 input, taps with descending dx)
+    (3, 1, 1, "zero", 128, 128, 3, 9, 13),    # 13-wide rows: ~11 segments per tile, tiles straddling images
+    (3, 1, 1, "reflect", 160, 128, 2, 11, 130),  # 130-wide rows (the padded data-gradient width), Cin = 5 x 32
 ]
 
 
