@@ -57,7 +57,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
                                                         const float *__restrict__ bias, float *__restrict__ out,
                                                         Geom g, Taps taps, unsigned in_bytes, unsigned w_bytes,
-                                                        unsigned w_lo_bytes, float *__restrict__ stats, int kdim, int dxmin)
+                                                        unsigned w_lo_bytes, float *__restrict__ stats, int kdim, int dxmin, int kstep)
 {
     typedef WsLds<ROWP> L;
     constexpr int AIMG = L::AIMG;
@@ -152,37 +152,57 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
                 rbl[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[i], soff + w_lo_bytes, 0);
             }
         };
-        auto load_stage = [&](int s) {
-            const int cc = s / taps.n;
-            const int t = s - cc * taps.n;
-            const int c0 = cc * KC;
-            const int pk = taps.pk[t];
+        // ROWP: the patch unit (pixel pp, 8-channel group uu) a thread gathers does not depend on the kernel row except
+        // through iy = gy + dy: segment, image, reflected column and validity are fixed per thread, so only the row term is
+        // left inside the loop (the 64-bit divisions of the segment arithmetic used to run once per kernel row and unit)
+        int rp_gy[3], rp_nb[3], rp_ix[3];
+        bool rp_ok[3];
+        if constexpr (ROWP) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int q = pt + 256 * j;
+                const int pp = q >> 2;
+                int seg = 0, px = pp;
+                if (pp >= first + kdim - 1) {
+                    const int qq = pp - (first + kdim - 1);
+                    seg = 1 + qq / RW;
+                    px = qq - (seg - 1) * RW;
+                }
+                const long long grow = grow0 + seg;
+                const int n_img = (int)(grow / g.GH);
+                int ix = (seg == 0 ? x0 : 0) + px + dxmin;
+                bool ok = q < npu && grow < grows;
+                if (REFLECT) {
+                    ix = ix < 0 ? -ix : ix;
+                    ix = ix >= g.Win ? 2 * (g.Win - 1) - ix : ix;
+                } else {
+                    ok = ok && (unsigned)ix < (unsigned)g.Win;
+                }
+                rp_gy[j] = (int)(grow - (long long)n_img * g.GH);
+                rp_nb[j] = n_img * g.Hin;
+                rp_ix[j] = ix;
+                rp_ok[j] = ok;
+            }
+        }
+        int st_t = 0, st_c0 = 0, st_k = 0; // tap, first input channel and position in the kernel row of the NEXT stage to load
+        auto load_stage = [&]() {
+            const int c0 = st_c0;
+            const int pk = taps.pk[st_t];
             const int ty = (pk << 24) >> 24, tx = (pk << 16) >> 24, tw = pk >> 16;
             if constexpr (ROWP) {
-                if (t % kdim == 0) { // first tap of a kernel row: gather the R x (GW+K-1) patch of this row, from dx = dxmin
+                if (st_k == 0) { // first tap of a kernel row: gather the R x (GW+K-1) patch of this row, from dx = dxmin
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
-                        const int q = pt + 256 * j;
-                        const int pp = q >> 2, uu = q & 3;
-                        int seg = 0, px = pp;
-                        if (pp >= first + kdim - 1) {
-                            const int qq = pp - (first + kdim - 1);
-                            seg = 1 + qq / RW;
-                            px = qq - (seg - 1) * RW;
-                        }
-                        const long long grow = grow0 + seg;
-                        const int n_img = (int)(grow / g.GH);
-                        int iy = (int)(grow - (long long)n_img * g.GH) + ty, ix = (seg == 0 ? x0 : 0) + px + dxmin;
-                        bool ok = q < npu && grow < grows;
+                        const int uu = (pt + 256 * j) & 3;
+                        int iy = rp_gy[j] + ty;
+                        bool ok = rp_ok[j];
                         if (REFLECT) {
                             iy = iy < 0 ? -iy : iy;
                             iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
-                            ix = ix < 0 ? -ix : ix;
-                            ix = ix >= g.Win ? 2 * (g.Win - 1) - ix : ix;
                         } else {
-                            ok = ok && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+                            ok = ok && (unsigned)iy < (unsigned)g.Hin;
                         }
-                        const unsigned off = (unsigned)(((n_img * g.Hin + iy) * g.Win + ix) * g.Cin + c0 + 8 * uu) * 4u;
+                        const unsigned off = (unsigned)(((rp_nb[j] + iy) * g.Win + rp_ix[j]) * g.Cin + c0 + 8 * uu) * 4u;
                         const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off, ok), 0, 0);
                         const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off + 16u, ok), 0, 0);
                         const f32x4 flo = __builtin_bit_cast(f32x4, lo), fhi = __builtin_bit_cast(f32x4, hi);
@@ -214,12 +234,15 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
                 }
             }
             load_b(tw, c0);
+            if (++st_t == taps.n) { st_t = 0; st_c0 += KC; }
+            if (ROWP && ++st_k == kdim) st_k = 0;
         };
-        load_stage(0);
+        load_stage();
+        int pk_k = 0, pk_buf = 0; // ROWP: position of stage s in its kernel row, and that row's A buffer
         for (int s = 0; s < S; ++s) {
-            // A buffer: per kernel row in ROWP (s / kdim), per stage otherwise; B buffer: per stage
-            const bool a_new = !ROWP || (s % taps.n) % kdim == 0;
-            __bf16 *As = lds + L::a_off(ROWP ? (s / kdim) & 1 : s & 1), *Bs = lds + L::b_off(s & 1);
+            // A buffer: per kernel row in ROWP, per stage otherwise; B buffer: per stage
+            const bool a_new = !ROWP || pk_k == 0;
+            __bf16 *As = lds + L::a_off(ROWP ? pk_buf : s & 1), *Bs = lds + L::b_off(s & 1);
             if (a_new) {
                 if constexpr (ROWP) {
 #pragma unroll
@@ -251,7 +274,8 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
                 *(u32x4 *)&Bs[b_lds[i]] = rb[i];
                 *(u32x4 *)&Bs[B_IMG + b_lds[i]] = rbl[i];
             }
-            if (s + 1 < S) load_stage(s + 1);
+            if (s + 1 < S) load_stage();
+            if (ROWP && ++pk_k == kdim) { pk_k = 0; pk_buf ^= 1; }
             __syncthreads(); // B buffer s&1 (and the A buffer of its kernel row) is full; the consumers have drained the other
         }
         return;
@@ -281,10 +305,12 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
             }
         }
     }
+    // ROWP: the taps of a kernel row step through the patch columns by kstep (+1 forward, -1 data gradient); kept in
+    // scalar counters (a per-stage scalar load of the tap behind the barrier stalled the wave on its latency)
+    int kk = 0, abuf = 0, kx = ROWP ? (kstep > 0 ? 0 : kdim - 1) : 0;
     for (int s = 0; s < S; ++s) {
         __syncthreads();
-        const __bf16 *As = lds + L::a_off(ROWP ? (s / kdim) & 1 : s & 1), *Bs = lds + L::b_off(s & 1);
-        const int kx = ROWP ? ((taps.pk[s % taps.n] << 16) >> 24) - dxmin : 0; // this tap's column offset in the patch
+        const __bf16 *As = lds + L::a_off(ROWP ? abuf : s & 1), *Bs = lds + L::b_off(s & 1);
         bf16x8 a[4], al[4], b[4], bl[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -306,6 +332,10 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             }
+        if constexpr (ROWP) {
+            kx += kstep;
+            if (++kk == kdim) { kk = 0; abuf ^= 1; kx = kstep > 0 ? 0 : kdim - 1; }
+        }
     }
     __builtin_amdgcn_s_setprio(0);
     // Epilogue through LDS: the tile (accumulator + bias, activation) is staged in the LDS the main loop no longer needs
@@ -384,7 +414,7 @@ int acg_igemm_x3_ws_launch(const float *in, const void *wp, const float *bias, f
     const unsigned inb = (unsigned)in_bytes, wb = (unsigned)w_bytes, wlo = (unsigned)(n_w_elems * 2);
     // row-patch variant: K x K tap lists in kernel-row order (forward: dx ascending, stride-1 data gradient: descending) on
     // grids whose width divides the 128-pixel tile
-    int kdim = 0, dxmin = 0;
+    int kdim = 0, dxmin = 0, kstep = 1;
     static const bool no_rowp = getenv("ACG_NO_ROWP") != nullptr; // A/B switch
     if (!no_rowp && g.is == 1 && g.os == 1 && g.oy0 == 0 && g.ox0 == 0) {
         int k = 1;
@@ -394,9 +424,12 @@ int acg_igemm_x3_ws_launch(const float *in, const void *wp, const float *bias, f
         for (int i = 1; i < t.n; ++i) mn = t.dx[i] < mn ? t.dx[i] : mn;
         for (int i = 0; ok && i < t.n; ++i) // one dy per kernel row, its dx within [mn, mn + k) (ascending: forward, descending: data gradient)
             ok = t.dy[i] == t.dy[(i / k) * k] && t.dx[i] >= mn && t.dx[i] < mn + k;
+        kstep = t.dx[0] == mn ? 1 : -1;
+        for (int i = 0; ok && i < t.n; ++i) // and the dx of every row run mn .. mn+k-1 in steps of kstep
+            ok = t.dx[i] == (kstep > 0 ? mn + i % k : mn + k - 1 - i % k);
         if (ok) { kdim = k; dxmin = mn; }
     }
-#define X3_WS(R, S, P) hipLaunchKernelGGL((igemm_conv_x3_ws<R, S, P>), grid, dim3(512), 0, st, in, (const __bf16 *)wp, bias, out, g, t, inb, wb, wlo, stats, kdim, dxmin)
+#define X3_WS(R, S, P) hipLaunchKernelGGL((igemm_conv_x3_ws<R, S, P>), grid, dim3(512), 0, st, in, (const __bf16 *)wp, bias, out, g, t, inb, wb, wlo, stats, kdim, dxmin, kstep)
 #define X3_WS2(R, S) do { if (kdim) X3_WS(R, S, true); else X3_WS(R, S, false); } while (0)
     if (g.reflect) { if (stats) X3_WS2(true, true); else X3_WS2(true, false); }
     else { if (stats) X3_WS2(false, true); else X3_WS2(false, false); }
