@@ -359,7 +359,25 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
             // the 8 pixels of a unit are consecutive output positions: when no lane's unit crosses a row end (always
             // so for W % 8 == 0), the row part of the address is formed once and each pixel costs a few VALU ops
             const bool in_row = gx + 8 <= g.Wg && m + 8 <= mend;
-            if (__builtin_amdgcn_ballot_w64(uok && !in_row) == 0) {
+            const int ixf = gx * g.is + tx; // first input column of the run; its last is ixf + 7 * is
+            const bool interior = in_row && ixf >= 0 && ixf + 7 * g.is < g.Win;
+            if (__builtin_amdgcn_ballot_w64(uok && !interior) == 0) {
+                // no lane's run touches a row end or the padding columns (15 of 16 runs of a 128-wide map): one masked
+                // VGPR offset per unit, the pixel step rides in the scalar offset — no per-pixel VALU work at all
+                int iy = gy * g.is + ty;
+                bool oky = uok;
+                if (g.reflect) {
+                    iy = iy < 0 ? -iy : iy;
+                    iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
+                } else {
+                    oky = oky && (unsigned)iy < (unsigned)g.Hin;
+                }
+                const unsigned off = acg_masked_off((unsigned)(((n * g.Hin + iy) * g.Win + ixf) * g.Cin + ci) * 4u, oky);
+                const unsigned xstep = (unsigned)(g.is * g.Cin) * 4u;
+#pragma unroll
+                for (int p = 0; p < 8; ++p)
+                    rx[l][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx_, off, p * xstep, 0));
+            } else if (__builtin_amdgcn_ballot_w64(uok && !in_row) == 0) {
                 int iy = gy * g.is + ty;
                 bool oky = uok && in_row;
                 if (g.reflect) {
@@ -413,10 +431,17 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
             const bool uok = unit < DU && co < g.Cg;
             const bool full = m + 8 <= mend;
             const unsigned base = (unsigned)((int)m * g.Cg + co) * 4u, step = (unsigned)g.Cg * 4u;
+            if (__builtin_amdgcn_ballot_w64(uok && !full) == 0) { // whole units: one masked offset, scalar pixel step
+                const unsigned off = acg_masked_off(base, uok);
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const unsigned off = acg_masked_off(base + p * step, uok && (full || m + p < mend));
-                rd[l][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd_, off, 0, 0));
+                for (int p = 0; p < 8; ++p)
+                    rd[l][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd_, off, p * step, 0));
+            } else {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const unsigned off = acg_masked_off(base + p * step, uok && (full || m + p < mend));
+                    rd[l][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd_, off, 0, 0));
+                }
             }
         }
     };
