@@ -14,8 +14,18 @@ import torch
 import torch.distributed as td
 
 
+# test hook: ACGAN_DIST_FORCE=1 runs every collective in a ONE-rank group too, so that the RCCL path (init, all-reduce of
+# the flat gradient buffers, the float64 scalar reductions) can be exercised on a single-GPU box
+_FORCE = os.environ.get("ACGAN_DIST_FORCE") == "1"
+
+
 def is_on():
     return td.is_available() and td.is_initialized()
+
+
+def exchange_on():
+    """True when the step has to exchange gradients/statistics (more than one rank, or the one-rank test hook)."""
+    return is_on() and (td.get_world_size() > 1 or _FORCE)
 
 
 def world_size():
@@ -29,7 +39,7 @@ def rank():
 def init_from_env(backend=None):
     """torchrun-style init (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT / LOCAL_RANK)."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
-    if ws <= 1 or is_on():
+    if (ws <= 1 and not _FORCE) or is_on():
         return rank(), world_size()
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -42,7 +52,7 @@ def init_from_env(backend=None):
 def allreduce_mean_(bufs):
     """In-place average of each flat buffer across ranks (async launches, one wait at the end)."""
     ws = world_size()
-    if ws <= 1:
+    if not exchange_on():
         return
     if td.get_backend() == "gloo" and bufs[0].is_cuda:
         # test-only path (2 ranks sharing one GPU under gloo): stage through the host
@@ -60,7 +70,7 @@ def allreduce_mean_(bufs):
 
 def broadcast_params_(nets):
     """Rank 0's initial parameters/buffers to every rank (replicas must start identical)."""
-    if world_size() <= 1:
+    if not exchange_on():
         return
     stage = td.get_backend() == "gloo"
     for n in nets:
@@ -77,7 +87,7 @@ def average_scalars(vals, sq_keys=(), min_keys=(), max_keys=()):
     """Reported scalars: rank-mean of the losses; gradient norms are already global (the gradients
     were averaged before the norm); min/max monitors reduce accordingly.  `vals`: OrderedDict of floats."""
     ws = world_size()
-    if ws <= 1:
+    if not exchange_on():
         return vals
     keys = list(vals.keys())
     dev = "cuda" if td.get_backend() == "nccl" else "cpu"

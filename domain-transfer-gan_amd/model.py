@@ -188,7 +188,7 @@ class _Base(object):
         return ops.ToNCHW.apply(x, C).detach()
 
     def _allreduce(self, flats):
-        if acg_dist.world_size() > 1:
+        if acg_dist.exchange_on():
             acg_dist.allreduce_mean_([f.g for f in flats])
 
     # ---- north-star aliases -----------------------------------------------------

@@ -20,8 +20,8 @@ SYNC_BN = False         # set by model.py from opt.sync_bn: BatchNorm statistics
 
 
 def ops_dist_on():
-    import torch.distributed as td
-    return td.is_available() and td.is_initialized() and td.get_world_size() > 1
+    from . import dist
+    return dist.exchange_on()
 
 
 def mark_dirty(net):

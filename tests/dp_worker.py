@@ -17,7 +17,8 @@ from oracle import recipe  # noqa: E402
 from test_hip_step import make_opt  # noqa: E402
 
 out, aug = sys.argv[1], int(sys.argv[2])
-rank, ws = D.init_from_env("gloo") if int(os.environ.get("WORLD_SIZE", "1")) > 1 else (0, 1)
+backend = os.environ.get("ACGAN_DP_BACKEND", "gloo")   # "nccl": the one-rank RCCL smoke (ACGAN_DIST_FORCE=1)
+rank, ws = D.init_from_env(backend) if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or D._FORCE) else (0, 1)
 kw = dict(input_nc=3, output_nc=1, ngf=8, nef=8, ndf=8, nlatent=4, n_blocks=2)
 # what is tested here is the data-parallel exchange, not the conv arithmetic: exact-fp32 products keep the
 # "2 ranks == 1 rank" comparison down to summation order (the bf16x3 default adds 16-bit operand rounding on top)

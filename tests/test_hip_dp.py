@@ -16,9 +16,10 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(tmp_path, ws, aug, port):
-    out = str(tmp_path / ("dp_ws%d_aug%d.npz" % (ws, aug)))
+def _run(tmp_path, ws, aug, port, **extra_env):
+    out = str(tmp_path / ("dp_ws%d_aug%d%s.npz" % (ws, aug, "_x" if extra_env else "")))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(ws), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env)
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), out, str(aug)],
                               env=dict(env, RANK=str(r), LOCAL_RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                               text=True) for r in range(ws)]
@@ -60,3 +61,18 @@ def test_two_ranks_equal_one_rank_aug_with_syncbn(tmp_path):
     assert np.allclose(two["s1/losses"], one["s1/losses"], rtol=1e-2, atol=1e-5)
     for k in ("probe_fake_B", "probe_fake_A"):
         assert np.max(np.abs(two[k] - one[k])) < 1e-2 * np.max(np.abs(one[k])), k
+
+
+def test_rccl_backend_one_rank_group(tmp_path):
+    """The exchange over the backend bench.py uses (torch.distributed "nccl" = RCCL).  RCCL wants one GPU per rank, so on
+    this one-GPU box the group has ONE rank and ACGAN_DIST_FORCE=1 makes the step run every collective anyway (parameter
+    broadcast, both gradient all-reduces on the flat buffers, SyncBN statistics, the float64 SUM/MIN/MAX of the
+    reported scalars): the results must equal the step without a process group."""
+    plain = _run(tmp_path, 1, 2, 29547)
+    rccl = _run(tmp_path, 1, 2, 29548, ACGAN_DIST_FORCE="1", ACGAN_DP_BACKEND="nccl", RANK="0")
+    for k in ("s0/losses", "s0/gnorms"):   # SyncBN forms its statistics from all-reduced sums: rounding-level differences
+        assert np.allclose(rccl[k], plain[k], rtol=1e-5, atol=1e-7), k
+    for k in ("s1/losses", "s1/gnorms"):   # after one Adam update (amplifies them, see test_hip_step.py)
+        assert np.allclose(rccl[k], plain[k], rtol=3e-3, atol=1e-6), k
+    for k in ("probe_fake_B", "probe_fake_A"):
+        assert np.max(np.abs(rccl[k] - plain[k])) < 1e-2 * np.max(np.abs(plain[k])), k
