@@ -822,8 +822,17 @@ static void wgrad_plan(const acg_conv_desc *d, int Cx, int Cg, long long Mtot, i
     // workgroups per launch: a whole number of residency waves.  The bf16 128x128 kernel holds 2 workgroups per CU:
     // 512 = exactly one wave (vs 1536: -6..-10 %, and a third of the partial-sum traffic); 768 = 1.5 waves is the worst
     // choice (+15 %).  The smaller tiles hold 3-4 per CU and keep more, shorter workgroups.
-    const long long target = (g_acg_precision != ACG_PREC_F32 && g_acg_conv_impl == ACG_IMPL_MFMA && bci == 128 && bco == 128 && !wgrad_thin(d)) ? 512 : 1024;
-    long long ns = target / base;
+    long long target = (g_acg_precision != ACG_PREC_F32 && g_acg_conv_impl == ACG_IMPL_MFMA && bci == 128 && bco == 128 && !wgrad_thin(d)) ? 512 : 1024;
+    long long nblk = base;
+    // kernel-row weight gradient (conv_wgrad_tr.hip, same conditions as acg_wgrad_krow_ok): three taps per workgroup, one
+    // 512-thread workgroup per CU -> one residency wave of 256
+    static const bool no_krow = getenv("ACG_NO_KROW") != nullptr;
+    if (!no_krow && g_acg_precision == ACG_PREC_BF16X3 && g_acg_conv_impl == ACG_IMPL_MFMA && !wgrad_thin(d) && d->K == 3 &&
+        d->stride == 1 && d->pad == 1 && d->Hi == d->Ho && d->Wi == d->Wo && d->Wo % 32 == 0 && Cx % 128 == 0 && Cg % 128 == 0) {
+        nblk = 3LL * (*CiP / 128) * (*CoP / 128);
+        target = 256;
+    }
+    long long ns = target / nblk;
     const long long cap = Mtot / (KP * 4);
     if (ns > cap) ns = cap;
     if (ns > 512) ns = 512;

@@ -50,6 +50,11 @@ CONV_CASES = [
     (4, 1, 1, "zero", 128, 128, 2, 16, 32),   # its DATA gradient (grid = the 16x32 input, taps with descending dx)
     (3, 1, 1, "zero", 128, 128, 3, 9, 13),    # 13-wide rows: ~11 segments per tile, tiles straddling images
     (3, 1, 1, "reflect", 160, 128, 2, 11, 130),  # 130-wide rows (the padded data-gradient width), Cin = 5 x 32
+    # kernel-row weight gradient (conv_wgrad_tr.hip): 128-multiple channels, width a multiple of the 32-pixel run
+    (3, 1, 1, "reflect", 128, 128, 2, 6, 32),
+    (3, 1, 1, "zero", 128, 256, 1, 5, 64),
+    (3, 1, 1, "zero", 256, 128, 3, 4, 32),
+    (3, 1, 1, "reflect", 128, 128, 1, 40, 96),   # several splits, runs that cross image rows within a split
 ]
 
 
