@@ -824,6 +824,7 @@ static void wgrad_plan(const acg_conv_desc *d, int Cx, int Cg, long long Mtot, i
     // choice (+15 %).  The smaller tiles hold 3-4 per CU and keep more, shorter workgroups.
     long long target = (g_acg_precision != ACG_PREC_F32 && g_acg_conv_impl == ACG_IMPL_MFMA && bci == 128 && bco == 128 && !wgrad_thin(d)) ? 512 : 1024;
     long long nblk = base;
+    int gran = KP;
     // kernel-row weight gradient (conv_wgrad_tr.hip, same conditions as acg_wgrad_krow_ok): three taps per workgroup, one
     // 512-thread workgroup per CU -> one residency wave of 256
     static const bool no_krow = getenv("ACG_NO_KROW") != nullptr;
@@ -831,6 +832,7 @@ static void wgrad_plan(const acg_conv_desc *d, int Cx, int Cg, long long Mtot, i
         d->stride == 1 && d->pad == 1 && d->Hi == d->Ho && d->Wi == d->Wo && d->Wo % 32 == 0 && Cx % 128 == 0 && Cg % 128 == 0) {
         nblk = 3LL * (*CiP / 128) * (*CoP / 128);
         target = 256;
+        gran = 32; // its stage is a 32-pixel run: splits this fine fill 255 of the 256 CUs at batch 32 (256-pixel splits: 246)
     }
     long long ns = target / nblk;
     const long long cap = Mtot / (KP * 4);
@@ -838,7 +840,7 @@ static void wgrad_plan(const acg_conv_desc *d, int Cx, int Cg, long long Mtot, i
     if (ns > 512) ns = 512;
     if (ns < 1) ns = 1;
     long long per = (Mtot + ns - 1) / ns;
-    per = (per + KP - 1) / KP * KP;
+    per = (per + gran - 1) / gran * gran;
     ns = (Mtot + per - 1) / per;
     *nsplit = (int)ns;
     *mps = per;

@@ -53,7 +53,12 @@ __global__ __launch_bounds__(512) void wgrad_x3_krow(const float *__restrict__ x
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const int tiles_ci = g.CiP / BC, tiles_co = g.CoP / BC;
-    int b = blockIdx.x;
+    // XCD-aware order (bijective, any grid size): workgroups are dealt to the 8 XCDs round-robin, so the three kernel rows
+    // of one pixel range — which stream the same dy rows and overlapping x rows — are made neighbours on ONE XCD and share
+    // its L2 (dealt across three XCDs each of them pulled its own copy from HBM: 1.6 GB per launch)
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+    int b = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const int tco = b % tiles_co; b /= tiles_co;
     const int tci = b % tiles_ci; b /= tiles_ci;
     const int ky = b % 3;
@@ -117,9 +122,11 @@ __global__ __launch_bounds__(512) void wgrad_x3_krow(const float *__restrict__ x
         const unsigned o0 = xoff(pj);
         rxa[0] = __builtin_amdgcn_raw_buffer_load_b128(rx_, o0, 0, 0);
         rxa[1] = __builtin_amdgcn_raw_buffer_load_b128(rx_, o0, 16, 0);
-        const unsigned o1 = acg_masked_off(xoff(KP + pj), extra);
-        rxb[0] = __builtin_amdgcn_raw_buffer_load_b128(rx_, o1, 0, 0);
-        rxb[1] = __builtin_amdgcn_raw_buffer_load_b128(rx_, o1, 16, 0);
+        if (wave == 0) { // the two halo pixels past the run: 32 units, the first half of wave 0 (the other lanes masked)
+            const unsigned o1 = acg_masked_off(xoff(KP + pj), extra);
+            rxb[0] = __builtin_amdgcn_raw_buffer_load_b128(rx_, o1, 0, 0);
+            rxb[1] = __builtin_amdgcn_raw_buffer_load_b128(rx_, o1, 16, 0);
+        }
         const unsigned od = (unsigned)(((int)lm + pj) * g.Cg + co0 + 8 * c8) * 4u;
         rda[0] = __builtin_amdgcn_raw_buffer_load_b128(rd_, od, 0, 0);
         rda[1] = __builtin_amdgcn_raw_buffer_load_b128(rd_, od, 16, 0);
@@ -161,9 +168,15 @@ __global__ __launch_bounds__(512) void wgrad_x3_krow(const float *__restrict__ x
         if (nst > 1) load_stage();
     }
     __syncthreads();
+#ifndef ACG_KROW_LATE
+#define ACG_KROW_LATE 1
+#endif
+    // waves 4-7 (the second wave of every SIMD) convert and store the next stage AFTER their MFMAs, waves 0-3 before: one
+    // wave of a SIMD is in its VALU/LDS-store phase while its partner feeds the matrix pipe
+    const bool late = ACG_KROW_LATE && wave >= 4;
     for (int s = 0; s < nst; ++s) {
         const int cur = s & 1;
-        if (s + 1 < nst) {
+        if (!late && s + 1 < nst) {
             store_stage(cur ^ 1);
             if (s + 2 < nst) load_stage();
         }
@@ -182,13 +195,18 @@ __global__ __launch_bounds__(512) void wgrad_x3_krow(const float *__restrict__ x
                 const bf16x8 ah = tr_frag(xb + (ks * 16 + t) * PITCH);
                 const bf16x8 al = tr_frag(xb + XIMG + (ks * 16 + t) * PITCH);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[t][j], 0, 0, 0);
-                    acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[t][j], 0, 0, 0);
-                    acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[t][j], 0, 0, 0);
-                }
+                for (int j = 0; j < 2; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[t][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[t][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[t][j], 0, 0, 0);
             }
         }
+        if (late && s + 1 < nst) {
+            store_stage(cur ^ 1);
+            if (s + 2 < nst) load_stage();
+        }
+
         __syncthreads();
     }
 
