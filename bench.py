@@ -130,7 +130,7 @@ def main():
     traffic = None
     # measured by tools/profile_traffic.sh + tools/summarize_traffic.py (separate --pmc passes), committed per kernel
     tj = os.path.join(ROOT, "profiles", {"f32": "r01_c_resblock_conv_traffic_f32.json",
-                                         "bf16x3": "r01_e_resblock_conv_traffic_bf16x3.json"}.get(a.precision, "-"))
+                                         "bf16x3": "r01_f_resblock_conv_traffic_bf16x3.json"}.get(a.precision, "-"))
     if os.path.exists(tj) and (N, S) == (32, 256):
         traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
     out = {
