@@ -165,6 +165,7 @@ __global__ void linear_bwd_kernel(const float *__restrict__ dy, const float *__r
         if (t >= N * I) return;
         const int n = t / I, i = t - n * I;
         float acc = 0.f;
+#pragma unroll 8 // independent loads in flight: the rolled loop paid one L2 latency per output channel (19 us for 128)
         for (int o = 0; o < O; ++o) {
             const float g = dy[(long long)n * Op + o] * acg_act_grad_from_y(y[(long long)n * Op + o], act);
             acc += g * w[(long long)o * I + i];
@@ -174,6 +175,7 @@ __global__ void linear_bwd_kernel(const float *__restrict__ dy, const float *__r
         if (t >= O * I) return;
         const int o = t / I, i = t - o * I;
         float acc = 0.f, bs = 0.f;
+#pragma unroll 8
         for (int n = 0; n < N; ++n) {
             const float g = dy[(long long)n * Op + o] * acg_act_grad_from_y(y[(long long)n * Op + o], act);
             acc += g * x[(long long)n * ldx + i];
@@ -183,12 +185,42 @@ __global__ void linear_bwd_kernel(const float *__restrict__ dy, const float *__r
         if (db && i == 0) db[o] = bs;
     }
 }
+// dx[n][i] = sum_o g[n][o] * w[o][i] with the sum over o split across the workgroup: one workgroup per row n, thread
+// (chunk, i) adds its chunk of output channels, the chunks meet in LDS in fixed order (deterministic).  The one-thread-per-
+// output loop above needs O dependent-latency steps (19 us for O = 128 at 4 workgroups); this one O / chunks.
+__global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+                                                            const float *__restrict__ w, float *__restrict__ dx, int I, int ldx,
+                                                            int O, int Op, int act)
+{
+    __shared__ float red[256];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int CH = 256 / I, OC = (O + CH - 1) / CH; // launcher guarantees I <= 256
+    const int i = tid % I, ch = tid / I;
+    float acc = 0.f;
+    if (ch < CH) {
+        const int o1 = (ch + 1) * OC < O ? (ch + 1) * OC : O;
+#pragma unroll 4
+        for (int o = ch * OC; o < o1; ++o) {
+            const float g = dy[(long long)n * Op + o] * acg_act_grad_from_y(y[(long long)n * Op + o], act);
+            acc += g * w[(long long)o * I + i];
+        }
+    }
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < I) {
+        float s = 0.f;
+        for (int c = 0; c < CH; ++c) s += red[c * I + tid];
+        dx[(long long)n * ldx + tid] = s;
+    }
+}
 extern "C" int acg_linear_bwd(const float *dy, const float *y, const float *x, const float *w, float *dx, float *dw,
                               float *db, int N, int I, int ldx, int O, int Op, int act, void *stream)
 {
     ACG_REQUIRE(N > 0 && I > 0 && O > 0 && Op >= O && ldx >= I, "acg_linear_bwd: bad dims");
     hipStream_t st = (hipStream_t)stream;
-    if (dx != nullptr)
+    if (dx != nullptr && I <= 256 && O >= 32)
+        hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(N), dim3(256), 0, st, dy, y, w, dx, I, ldx, O, Op, act);
+    else if (dx != nullptr)
         hipLaunchKernelGGL(linear_bwd_kernel, dim3(acg_cdiv((long)N * I, 128)), dim3(128), 0, st, dy, y, x, w, dx, dw, db, N,
                            I, ldx, O, Op, act, 0);
     if (dw != nullptr || db != nullptr)

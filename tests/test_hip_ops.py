@@ -385,6 +385,20 @@ def test_linear_and_spatial_mean():
     g = r * np.where(pre > 0, 1, 0.2)
     gx = np.zeros_like(x); gx[:, :6] = g @ w
     assert rel(n(xt.grad), gx) < 1e-5 and rel(n(wt.grad), g.T @ x[:, :6]) < 1e-5 and rel(n(bt.grad), g.sum(0)) < 1e-5
+    # wide layers (CondInstanceNorm's latent -> 128 channels, the latent MLP): the workgroup-parallel dx kernel
+    for N_, I_, ld_, O_, act in ((32, 16, 16, 128, ops.ACT_RELU), (7, 64, 64, 64, ops.ACT_LRELU), (3, 5, 16, 200, ops.ACT_NONE)):
+        x = rs.normal(0, 1, (N_, ld_)); w = rs.normal(0, 0.5, (O_, I_)); b = rs.normal(0, 0.5, O_)
+        xt, wt, bt = t(x, True), t(w, True), t(b, True)
+        y = ops.LinearFn.apply(xt, wt, bt, act, O_)
+        pre = x[:, :I_] @ w.T + b
+        slope = {ops.ACT_RELU: 0.0, ops.ACT_LRELU: 0.2, ops.ACT_NONE: 1.0}[act]
+        ref = np.where(pre > 0, pre, slope * pre)
+        assert rel(n(y)[:, :O_], ref) < 1e-5
+        r = rs.normal(0, 1, n(y).shape); r[:, O_:] = 0
+        y.backward(t(r))
+        g = r[:, :O_] * np.where(pre > 0, 1, slope)
+        gx = np.zeros_like(x); gx[:, :I_] = g @ w
+        assert rel(n(xt.grad), gx) < 1e-5 and rel(n(wt.grad), g.T @ x[:, :I_]) < 1e-5 and rel(n(bt.grad), g.sum(0)) < 1e-5
     a = rs.normal(0, 1, (2, 5, 3, 16))
     at = t(a, True)
     sm = ops.SpatialMean.apply(at)
