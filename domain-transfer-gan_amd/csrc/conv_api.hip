@@ -460,6 +460,7 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ part, int nsplit, 
     const float *p = thin == 2 ? part + ((long long)(tap * 4 + o)) * CoP + ci   // rows (tap, co), columns ci
                    : thin == 1 ? part + ((long long)(tap * 4 + ci)) * CoP + o  // rows (tap, ci), columns co
                                : part + ((long long)tap * CiP + ci) * CoP + o;
+#pragma unroll 8 // same summation order, eight loads in flight (the rolled loop paid one memory latency per split)
     for (int k = 0; k < nsplit; ++k) s += p[k * stride];
     dw[((long long)o * Ir + ci) * KK + tap] = s;
 }
