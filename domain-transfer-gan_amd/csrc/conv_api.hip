@@ -834,6 +834,12 @@ static void wgrad_plan(const acg_conv_desc *d, int Cx, int Cg, long long Mtot, i
         nblk = 3LL * (*CiP / 128) * (*CoP / 128);
         target = 256;
         gran = 32; // its stage is a 32-pixel run: splits this fine fill 255 of the 256 CUs at batch 32 (256-pixel splits: 246)
+    } else if (!no_krow && g_acg_precision == ACG_PREC_BF16X3 && g_acg_conv_impl == ACG_IMPL_MFMA && !wgrad_thin(d) && d->K == 3 &&
+               d->stride == 1 && d->pad == 1 && d->Hi == d->Ho && d->Wi == d->Wo && d->Wo % 128 == 0 &&
+               ((Cx == 32 && Cg == 64) || (Cx == 64 && Cg == 32))) {
+        nblk = 3; // the 32 <-> 64 channel variant (acg_wgrad_krow_s_ok): 256 threads, two workgroups per CU
+        target = 512;
+        gran = 128;
     }
     long long ns = target / nblk;
     const long long cap = Mtot / (KP * 4);

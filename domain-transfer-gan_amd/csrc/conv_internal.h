@@ -80,6 +80,8 @@ int acg_wgrad_bf16_launch(const float *x, const float *dy, float *part, const WG
 // conv_wgrad_tr.hip: one kernel row per workgroup (stride-1 3x3, 128-multiple channels, bf16x3)
 bool acg_wgrad_krow_ok(const WGeom &g, const Taps &t);
 int acg_wgrad_krow_launch(const float *x, const float *dy, float *part, const WGeom &g, hipStream_t st);
+bool acg_wgrad_krow_s_ok(const WGeom &g, const Taps &t);   // its 32 <-> 64 channel, 128-pixel-run variant
+int acg_wgrad_krow_s_launch(const float *x, const float *dy, float *part, const WGeom &g, hipStream_t st);
 
 #ifdef __HIPCC__
 // bf16x3 operand split of 8 fp32 values: hi = RNE bf16(x), lo = RNE bf16(x - hi), each returned as 8 packed bf16

@@ -233,6 +233,7 @@ int acg_wgrad_launch(const float *x, const float *dy, float *part, const WGeom &
     int bci, bco;
     acg_wgrad_tiles(g.Cin, g.Cg, &bci, &bco);
     if (acg_wgrad_krow_ok(g, t)) return acg_wgrad_krow_launch(x, dy, part, g, st);
+    if (acg_wgrad_krow_s_ok(g, t)) return acg_wgrad_krow_s_launch(x, dy, part, g, st);
     if (g_acg_precision != ACG_PREC_F32 && !g.thin) return acg_wgrad_bf16_launch(x, dy, part, g, t, bci, bco, st);
     const int blocks = g.nsplit * (g.thin ? 1 : t.n) * (g.CiP / bci) * (g.CoP / bco);
     dim3 grid(blocks), block(256);

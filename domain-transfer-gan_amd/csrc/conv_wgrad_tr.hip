@@ -236,6 +236,258 @@ __global__ __launch_bounds__(512) void wgrad_x3_krow(const float *__restrict__ x
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same scheme for the full-resolution 32 <-> 64 channel layers (networks.py:164, 183: 3x3 at 256 x 256).  Their whole
+// (Cin x Cout) tile is one or two 32x32 MFMA tiles, so the waves of a workgroup cannot divide channels: they divide the
+// PIXELS of a 128-pixel run instead (wave w: pixels 32w .. 32w+31, all three taps of the kernel row, the whole channel
+// tile) and add their accumulators through LDS once at the end.  These layers are HBM-bound (805 MB of x and dy per
+// launch against 77 GFLOP): the per-tap kernel pulled both tensors through L2 nine times (0.8 ms); here the three kernel
+// rows of a pixel range share an XCD and each reads them once.  One stage buffer, two barriers per stage, next stage's
+// loads in flight under the MFMAs; 66 KB of LDS: two workgroups per CU.
+namespace {
+constexpr int SKP = 128;                                      // pixels per stage
+constexpr int SXW = SKP + 2;
+constexpr int spitch(int C) { return C * 2 + ((C * 2) % 128 == 0 ? 64 : 0); } // 32 ch: 64 B, 64 ch: 192 B (4 rows -> 4 segments)
+}
+
+template <int BCI, int BCO>
+__global__ __launch_bounds__(256) void wgrad_x3_krow_s(const float *__restrict__ x, const float *__restrict__ dy,
+                                                       float *__restrict__ part, WGeom g, unsigned x_bytes, unsigned d_bytes)
+{
+    constexpr int PX = spitch(BCI), PD = spitch(BCO);
+    constexpr int XI = SXW * PX, DI = SKP * PD;                 // one hi (or lo) image
+    constexpr int UX = BCI / 8, UD = BCO / 8;                   // 8-channel units per pixel
+    constexpr int XS = SKP * UX / 256, DS = SKP * UD / 256;     // unit slots per thread (run pixels; the 2 halo pixels go extra)
+    constexpr int TI = BCI / 32, TJ = BCO / 32;
+    static_assert(TI * TJ == 2 && XS >= 1 && DS >= 1, "tile config");
+    constexpr int LDSB = 2 * XI + 2 * DI;
+    constexpr int REDB = 3 * TI * TJ * 16 * 64 * 4;             // one tap's accumulators of three waves
+    __shared__ __attribute__((aligned(16))) char lds[LDSB > REDB ? LDSB : REDB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+    const int b = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int ky = b % 3, split = b / 3;
+    const long long mbeg = (long long)split * g.m_per_split;
+    long long mend = mbeg + g.m_per_split;
+    if (mend > g.Mtot) mend = g.Mtot;
+    const int nst = mbeg < mend ? (int)((mend - mbeg) / SKP) : 0;
+    const int H = g.Hg, W = g.Wg;
+
+    f32x16 acc[3][TI][TJ];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+
+    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd_ = __builtin_amdgcn_make_buffer_rsrc((void *)dy, 0, d_bytes, 0x00020000);
+
+    int ln, loy, lox;
+    {
+        const long long mm = mbeg < g.Mtot ? mbeg : 0;
+        ln = (int)(mm / ((long long)H * W));
+        const int rr = (int)(mm - (long long)ln * H * W);
+        loy = rr / W;
+        lox = rr - loy * W;
+    }
+    long long lm = mbeg;
+    u32x4 rx[XS][2], rh[2], rd[DS][2];
+    const bool halo = tid < 2 * UX;                              // unit (pixel -1 or SKP, channel group tid % UX)
+    const bool do_bias = g.bias_from == 1 && ky == 0;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    auto load_stage = [&]() {
+        int iy = loy + ky - 1;
+        bool rowok = true;
+        if (g.reflect) {
+            iy = iy < 0 ? -iy : iy;
+            iy = iy >= H ? 2 * (H - 1) - iy : iy;
+        } else {
+            rowok = (unsigned)iy < (unsigned)H;
+        }
+        const int rowbase = (ln * H + iy) * W;
+#pragma unroll
+        for (int k = 0; k < XS; ++k) { // run pixels lox .. lox+127: always inside the row
+            const int u = tid + 256 * k;
+            const unsigned off = acg_masked_off((unsigned)((rowbase + lox + u / UX) * g.Cin + 8 * (u % UX)) * 4u, rowok);
+            rx[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rx_, off, 0, 0);
+            rx[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rx_, off, 16, 0);
+        }
+        if (wave == 0) { // the two halo pixels
+            int ix = tid < UX ? lox - 1 : lox + SKP;
+            bool ok = rowok && halo;
+            if (g.reflect) {
+                ix = ix < 0 ? -ix : ix;
+                ix = ix >= W ? 2 * (W - 1) - ix : ix;
+            } else {
+                ok = ok && (unsigned)ix < (unsigned)W;
+            }
+            const unsigned off = acg_masked_off((unsigned)((rowbase + ix) * g.Cin + 8 * (tid % UX)) * 4u, ok);
+            rh[0] = __builtin_amdgcn_raw_buffer_load_b128(rx_, off, 0, 0);
+            rh[1] = __builtin_amdgcn_raw_buffer_load_b128(rx_, off, 16, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < DS; ++k) {
+            const int u = tid + 256 * k;
+            const unsigned off = (unsigned)(((int)lm + u / UD) * g.Cg + 8 * (u % UD)) * 4u;
+            rd[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rd_, off, 0, 0);
+            rd[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rd_, off, 16, 0);
+        }
+        lm += SKP;
+        lox += SKP;
+        if (lox == W) { lox = 0; if (++loy == H) { loy = 0; ++ln; } }
+    };
+    auto put = [&](char *img_hi, char *img_lo, int byte_off, const u32x4 (&r)[2]) {
+        const f32x4 a = __builtin_bit_cast(f32x4, r[0]), c = __builtin_bit_cast(f32x4, r[1]);
+        const float v[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+        acg_u32x4 hi, lo;
+        acg_split8(v, hi, lo);
+        *(acg_u32x4 *)(img_hi + byte_off) = hi;
+        *(acg_u32x4 *)(img_lo + byte_off) = lo;
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int k = 0; k < XS; ++k) {
+            const int u = tid + 256 * k;
+            put(lds, lds + XI, (1 + u / UX) * PX + (u % UX) * 16, rx[k]);
+        }
+        if (halo) put(lds, lds + XI, (tid < UX ? 0 : SKP + 1) * PX + (tid % UX) * 16, rh);
+#pragma unroll
+        for (int k = 0; k < DS; ++k) {
+            const int u = tid + 256 * k;
+            put(lds + 2 * XI, lds + 2 * XI + DI, (u / UD) * PD + (u % UD) * 16, rd[k]);
+            if (do_bias) {
+                const f32x4 a = __builtin_bit_cast(f32x4, rd[k][0]), c = __builtin_bit_cast(f32x4, rd[k][1]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bsum[e] += a[e]; bsum[4 + e] += c[e]; }
+            }
+        }
+    };
+
+    const int gq = lane >> 4, li = lane & 15;
+    const int frag_row = 32 * wave + 8 * (gq >> 1) + (li >> 2), frag_col = 16 * (gq & 1) + 4 * (li & 3);
+    const lds_char *xb = (const lds_char *)lds + frag_row * PX + frag_col * 2;
+    const lds_char *db = (const lds_char *)lds + 2 * XI + frag_row * PD + frag_col * 2;
+    auto frag = [&](const lds_char *p, int pitch) {
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p);
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p + 4 * pitch));
+        return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    if (nst > 0) load_stage();
+    for (int s = 0; s < nst; ++s) {
+        __syncthreads(); // every wave has read the previous stage
+        store_stage();
+        __syncthreads();
+        if (s + 1 < nst) load_stage(); // in flight under the MFMAs
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 bh[TJ], bl[TJ];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                bh[j] = frag(db + ks * 16 * PD + j * 64, PD);
+                bl[j] = frag(db + DI + ks * 16 * PD + j * 64, PD);
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    const bf16x8 ah = frag(xb + (ks * 16 + t) * PX + i * 64, PX);
+                    const bf16x8 al = frag(xb + XI + (ks * 16 + t) * PX + i * 64, PX);
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[t][i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[t][i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[t][i][j], 0, 0, 0);
+                }
+        }
+    }
+    __syncthreads();
+
+    if (do_bias) { // threads with the same channel group (tid % UD) fold their column sums in fixed order
+        float *red = (float *)lds;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[tid * 8 + e] = bsum[e];
+        __syncthreads();
+        if (tid < BCO) {
+            float sum = 0.f;
+            for (int r = 0; r < 256 / UD; ++r) sum += red[(r * UD + (tid >> 3)) * 8 + (tid & 7)];
+            g.bias_part[(long long)split * g.CoP + tid] = sum;
+        }
+        __syncthreads();
+    }
+
+    // the four waves hold partial sums over their pixel slices: waves 1-3 park one tap at a time in LDS, wave 0 adds them
+    // in wave order and writes the tap out
+    float *red = (float *)lds;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        if (wave > 0) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[(((wave - 1) * TI * TJ + i * TJ + j) * 16 + r) * 64 + lane] = acc[t][i][j][r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float *o = part + ((long long)split * 9 + ky * 3 + t) * g.CiP * g.CoP;
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[t][i][j][r];
+#pragma unroll
+                        for (int w = 0; w < 3; ++w) v += red[((w * TI * TJ + i * TJ + j) * 16 + r) * 64 + lane];
+                        const int ci = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        const int co = j * 32 + (lane & 31);
+                        o[(long long)ci * g.CoP + co] = v;
+                    }
+        }
+        __syncthreads();
+    }
+}
+
+static bool krow_taps_ok(const WGeom &g, const Taps &t)
+{
+    if (g_acg_precision != ACG_PREC_BF16X3 || g_acg_conv_impl != ACG_IMPL_MFMA || g.thin) return false;
+    if (t.n != 9 || g.is != 1 || g.Hin != g.Hg || g.Win != g.Wg || g.bias_from == 2) return false;
+    for (int i = 0; i < 9; ++i)
+        if (t.dy[i] != i / 3 - 1 || t.dx[i] != i % 3 - 1) return false;
+    return true;
+}
+
+// the 32 <-> 64 channel variant: whole-tensor channel tiles, width a multiple of the 128-pixel run
+bool acg_wgrad_krow_s_ok(const WGeom &g, const Taps &t)
+{
+    static const bool off = getenv("ACG_NO_KROW") != nullptr || getenv("ACG_NO_KROW_S") != nullptr; // A/B switches
+    if (off || !krow_taps_ok(g, t) || g.Wg % SKP != 0 || g.m_per_split % SKP != 0) return false;
+    const bool c = (g.Cin == 32 && g.Cg == 64) || (g.Cin == 64 && g.Cg == 32);
+    return c && g.CiP == g.Cin && g.CoP == g.Cg;
+}
+
+int acg_wgrad_krow_s_launch(const float *x, const float *dy, float *part, const WGeom &g, hipStream_t st)
+{
+    const int blocks = g.nsplit * 3;
+    const long long nimg = g.Mtot / ((long long)g.Hg * g.Wg);
+    const long long xbytes = nimg * g.Hin * g.Win * g.Cin * 4, dbytes = g.Mtot * g.Cg * 4;
+    ACG_REQUIRE(xbytes < (1LL << 32) && dbytes < (1LL << 32), "wgrad_x3_krow_s: operand exceeds the 4 GiB buffer-addressing limit");
+    if (g.Cin == 32) hipLaunchKernelGGL((wgrad_x3_krow_s<32, 64>), dim3(blocks), dim3(256), 0, st, x, dy, part, g, (unsigned)xbytes, (unsigned)dbytes);
+    else hipLaunchKernelGGL((wgrad_x3_krow_s<64, 32>), dim3(blocks), dim3(256), 0, st, x, dy, part, g, (unsigned)xbytes, (unsigned)dbytes);
+    ACG_CHECK_LAUNCH("wgrad_x3_krow_s");
+    return ACG_OK;
+}
+
 // stride-1 3x3, pad 1, same-size maps whose width is a multiple of the 32-pixel run, 128-multiple channels on both sides
 bool acg_wgrad_krow_ok(const WGeom &g, const Taps &t)
 {

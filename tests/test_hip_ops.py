@@ -55,6 +55,11 @@ CONV_CASES = [
     (3, 1, 1, "zero", 128, 256, 1, 5, 64),
     (3, 1, 1, "zero", 256, 128, 3, 4, 32),
     (3, 1, 1, "reflect", 128, 128, 1, 40, 96),   # several splits, runs that cross image rows within a split
+    # its 32 <-> 64 channel variant (128-pixel runs, waves split the pixels)
+    (3, 1, 1, "zero", 32, 64, 1, 3, 128),
+    (3, 1, 1, "reflect", 64, 32, 2, 4, 128),
+    (3, 1, 1, "zero", 64, 32, 2, 20, 128),       # several splits
+    (3, 1, 1, "reflect", 32, 64, 1, 5, 256),
 ]
 
 
