@@ -13,6 +13,7 @@
 // tap minor.  (Measured and dropped: LDS double buffering and 8x16 spatial M tiles — both lose to occupancy.)
 #include <stdlib.h>
 #include "conv_internal.h"
+#include <cstdlib>
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -25,7 +26,8 @@ __device__ __forceinline__ int reflect_coord(int i, int n)
 // REFLECT / THIN are compile-time so the plain zero-pad path keeps wave-uniform tap lookups (scalar loads) and a
 // branch-free gather: 32-bit offsets into a buffer resource, masked lanes get offset 0xFFFFFFFF, which the
 // hardware range check turns into zeros.
-template <int BM, int BN, int WM, int WN, int KC, bool REFLECT, bool THIN>
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+template <int BM, int BN, int WM, int WN, int KC, bool REFLECT, bool THIN, bool X3 = false>
 __global__ __launch_bounds__(256) void igemm_conv_f32(const float *__restrict__ in, const float *__restrict__ wp,
                                                       const float *__restrict__ bias, float *__restrict__ out,
                                                       Geom g, Taps taps, unsigned in_bytes, unsigned w_bytes)
@@ -173,6 +175,42 @@ __global__ __launch_bounds__(256) void igemm_conv_f32(const float *__restrict__ 
             if (tid + 256 * i < BCH) *(u32x4 *)&Bs[b_lds[i]] = rb[i];
         __syncthreads();
         if (s + 1 < S) load_stage(s + 1); // in flight under the MFMAs below
+        if constexpr (X3) {
+            // thin layers outside the strict fp32 mode: same loader, fp32 LDS tiles and packed weights, but the products run
+            // as bf16x3 on the bf16 matrix pipe (a lane's 8 consecutive k of a chunk are split hi/lo in registers): the
+            // fp32 MFMA made these HBM-sized layers matrix-bound (16 x 64 cycles per 32-deep stage and tile against 6 x 32)
+            static_assert(!X3 || KC == 32, "two 16-deep bf16 MFMA steps per stage");
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t ah[MB], al[MB], bh[NB], bl[NB];
+#pragma unroll
+                for (int i = 0; i < MB; ++i) {
+                    const float *p = &As[(2 * ks + (lane >> 5)) * AKS + (wm * TM + i * 32 + (lane & 31)) * 8];
+                    const f32x4 v0 = *(const f32x4 *)p, v1 = *(const f32x4 *)(p + 4);
+                    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    acg_u32x4 hi, lo;
+                    acg_split8(v, hi, lo);
+                    ah[i] = __builtin_bit_cast(bf16x8_t, hi); al[i] = __builtin_bit_cast(bf16x8_t, lo);
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const float *p = &Bs[(2 * ks + (lane >> 5)) * BKS + (wn * TN + j * 32 + (lane & 31)) * 8];
+                    const f32x4 v0 = *(const f32x4 *)p, v1 = *(const f32x4 *)(p + 4);
+                    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    acg_u32x4 hi, lo;
+                    acg_split8(v, hi, lo);
+                    bh[j] = __builtin_bit_cast(bf16x8_t, hi); bl[j] = __builtin_bit_cast(bf16x8_t, lo);
+                }
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else
 #pragma unroll
         for (int kc = 0; kc < NKC; ++kc) {
             f32x4 a[MB], b[NB];
@@ -218,17 +256,17 @@ extern "C" int acg_ncols_pad(int c)
     return (c + bn - 1) / bn * bn;
 }
 
-template <int KC, bool REFLECT, bool THIN>
+template <int KC, bool REFLECT, bool THIN, bool X3 = false>
 static void launch_v(int bn, dim3 grid, hipStream_t st, const float *in, const float *wp, const float *bias, float *out,
                      const Geom &g, const Taps &t, unsigned inb, unsigned wb)
 {
     dim3 block(256);
     if (bn == 128)
-        hipLaunchKernelGGL((igemm_conv_f32<128, 128, 2, 2, KC, REFLECT, THIN>), grid, block, 0, st, in, wp, bias, out, g, t, inb, wb);
+        hipLaunchKernelGGL((igemm_conv_f32<128, 128, 2, 2, KC, REFLECT, THIN, X3>), grid, block, 0, st, in, wp, bias, out, g, t, inb, wb);
     else if (bn == 64)
-        hipLaunchKernelGGL((igemm_conv_f32<128, 64, 2, 2, KC, REFLECT, THIN>), grid, block, 0, st, in, wp, bias, out, g, t, inb, wb);
+        hipLaunchKernelGGL((igemm_conv_f32<128, 64, 2, 2, KC, REFLECT, THIN, X3>), grid, block, 0, st, in, wp, bias, out, g, t, inb, wb);
     else
-        hipLaunchKernelGGL((igemm_conv_f32<128, 32, 4, 1, KC, REFLECT, THIN>), grid, block, 0, st, in, wp, bias, out, g, t, inb, wb);
+        hipLaunchKernelGGL((igemm_conv_f32<128, 32, 4, 1, KC, REFLECT, THIN, X3>), grid, block, 0, st, in, wp, bias, out, g, t, inb, wb);
 }
 
 int acg_igemm_launch(const float *in, const float *wp, const float *bias, float *out, const Geom &g0, const Taps &t0,
@@ -253,7 +291,12 @@ int acg_igemm_launch(const float *in, const float *wp, const float *bias, float 
     dim3 grid(tiles_m * tiles_n);
     const unsigned inb = (unsigned)in_bytes, wb = (unsigned)w_bytes;
     const bool kc32 = (g.Cin % 32 == 0) || g.thin;
-    if (g.thin) {
+    static const bool no_thin_x3 = getenv("ACG_NO_THIN_X3") != nullptr; // A/B switch
+    const bool x3 = g_acg_precision != ACG_PREC_F32 && g_acg_conv_impl == ACG_IMPL_MFMA && !no_thin_x3;
+    if (g.thin && x3) {
+        if (g.reflect) launch_v<32, true, true, true>(bn, grid, st, in, wp, bias, out, g, t, inb, wb);
+        else launch_v<32, false, true, true>(bn, grid, st, in, wp, bias, out, g, t, inb, wb);
+    } else if (g.thin) {
         if (g.reflect) launch_v<32, true, true>(bn, grid, st, in, wp, bias, out, g, t, inb, wb);
         else launch_v<32, false, true>(bn, grid, st, in, wp, bias, out, g, t, inb, wb);
     } else if (kc32) {

@@ -9,10 +9,12 @@
 // partials in a fixed order and scatters into torch's OIHW layout — no float atomics, so
 // results are bitwise reproducible run to run.
 #include "conv_internal.h"
+#include <cstdlib>
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int BCI, int BCO, int WI, int WJ, int WK, int KP>
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+template <int BCI, int BCO, int WI, int WJ, int WK, int KP, bool X3 = false>
 __global__ __launch_bounds__(256) void wgrad_f32(const float *__restrict__ x, const float *__restrict__ dy,
                                                  float *__restrict__ part, WGeom g, Taps taps, unsigned x_bytes,
                                                  unsigned d_bytes)
@@ -150,6 +152,42 @@ __global__ __launch_bounds__(256) void wgrad_f32(const float *__restrict__ x, co
         }
         __syncthreads();
         if (k0 + KP < mend) load_stage(k0 + KP);
+        if constexpr (X3) {
+            // thin layers outside the strict fp32 mode: products as bf16x3 (8 consecutive pixels of a column per lane, split
+            // hi/lo in registers); loader, fp32 LDS tiles and partial-sum layout unchanged
+            static_assert(!X3 || KW % 16 == 0, "16 pixels per bf16 MFMA step");
+#pragma unroll 2
+            for (int kk = wk * KW; kk < (wk + 1) * KW; kk += 16) {
+                bf16x8_t ah[MI], al[MI], bh[MJ], bl[MJ];
+                const int row = kk + 8 * (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = Xs[(row + e) * BCI + wi * TI + i * 32 + (lane & 31)];
+                    acg_u32x4 hi, lo;
+                    acg_split8(v, hi, lo);
+                    ah[i] = __builtin_bit_cast(bf16x8_t, hi); al[i] = __builtin_bit_cast(bf16x8_t, lo);
+                }
+#pragma unroll
+                for (int j = 0; j < MJ; ++j) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = Ds[(row + e) * BCO + wj * TJ + j * 32 + (lane & 31)];
+                    acg_u32x4 hi, lo;
+                    acg_split8(v, hi, lo);
+                    bh[j] = __builtin_bit_cast(bf16x8_t, hi); bl[j] = __builtin_bit_cast(bf16x8_t, lo);
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < MJ; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else
 #pragma unroll 4
         for (int kk = wk * KW; kk < (wk + 1) * KW; kk += 2) {
             float a[MI], bb[MJ];
@@ -249,6 +287,8 @@ int acg_wgrad_launch(const float *x, const float *dy, float *part, const WGeom &
         hipLaunchKernelGGL((wgrad_f32<32, 64, 1, 2, 2, 64>), grid, block, 0, st, x, dy, part, g, t, xb, db);
     else if (bci == 64 && bco == 32)
         hipLaunchKernelGGL((wgrad_f32<64, 32, 2, 1, 2, 64>), grid, block, 0, st, x, dy, part, g, t, xb, db);
+    else if (g.thin && g_acg_precision != ACG_PREC_F32 && g_acg_conv_impl == ACG_IMPL_MFMA && getenv("ACG_NO_THIN_X3") == nullptr)
+        hipLaunchKernelGGL((wgrad_f32<32, 32, 1, 1, 4, 128, true>), grid, block, 0, st, x, dy, part, g, t, xb, db);
     else
         hipLaunchKernelGGL((wgrad_f32<32, 32, 1, 1, 4, 128>), grid, block, 0, st, x, dy, part, g, t, xb, db);
     ACG_CHECK_LAUNCH("wgrad_f32");
