@@ -14,7 +14,8 @@ extern "C" int acg_set_conv_precision(int prec)
 // packed weights are bf16 (hi, and for BF16X3 also lo right behind it) whenever the bf16 matrix pipe is used
 static bool use_bf16() { return g_acg_precision != ACG_PREC_F32 && g_acg_conv_impl == ACG_IMPL_MFMA; }
 // thin-channel K-flattening (fp32 MFMA kernels): the gathered tensor has <= 4 real channels and K > 1
-// (thin layers use the fp32 thin kernels in BOTH precision modes: they beat the padded bf16 path)
+// (thin layers keep the fp32-tile thin kernels — loader, LDS tiles, packed weights — in every mode: they beat the padded bf16
+// path; outside the strict fp32 mode their products run as bf16x3, conv_igemm.hip / conv_wgrad.hip X3)
 static bool thin_ok(int creal, int K) { return creal >= 1 && creal <= 4 && K > 1 && g_acg_conv_impl == ACG_IMPL_MFMA; }
 // a layer is treated as thin on exactly one side (3->3 convolutions do not occur on this path and stay regular)
 static bool thin_in(const acg_conv_desc *d) { return thin_ok(d->Cir, d->K) && !thin_ok(d->Cor, d->K); }
