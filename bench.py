@@ -1,83 +1,200 @@
 #!/usr/bin/env python3
-"""Headline benchmark: training images/sec of the 256x256 Augmented CycleGAN step on MI355X.
+"""Headline benchmark: training images/sec of the Augmented CycleGAN step on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL; RANK/LOCAL_RANK/WORLD_SIZE from env)
+    python bench.py --gpus N --steps K --warmup W [--config 2|3|5]
 
-Workload at N = 1 (BASELINE.json configs[2], the configuration the metric is quoted on): 256x256x3 synthetic
-unpaired batches, 9-resblock generators + latent encoder + latent discriminator (the full Augmented CycleGAN
-step: AugmentedCycleGAN.train_instance), 32 (A,B) pairs per GPU, weak scaling (global batch = 32 N).
+N > 1: when RANK is not in the environment this process is only a LAUNCHER — before touching the GPU it starts N fresh
+child processes of this same file (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set), one rank per
+GPU over RCCL, relays rank 0's JSON line and exits non-zero if any child fails.  Under an external
+`python -m torch.distributed.run` the ranks find RANK in the environment and run directly.
+
+Workloads (BASELINE.json `configs`; `--config`):
+  3 (default) configs[2], the configuration the metric is quoted on: 256x256x3 synthetic unpaired batches, 9-resblock
+              generators + latent encoder + latent discriminator (the full AugmentedCycleGAN.train_instance), 32 (A,B) pairs
+              per GPU, conv arithmetic bf16x3.  With --gpus 8 this is configs[3] (global batch 256, weak scaling).
+  2           configs[1]: 128x128x3, 6 resblocks, batch 16, exact-fp32 conv arithmetic.
+  5           configs[4]: 512x512x1 "Livneh-shaped" fields, 9 resblocks, 16 pairs per GPU (global 128 on 8 GPUs), bf16x3.
 One "image" = one (A,B) pair consumed by train_instance (train.py:195).  Arithmetic (--precision): tensors, norms,
 losses and Adam are fp32 throughout; the convolution products run on the matrix cores as
-  bf16x3 (default) fp32 operands split hi + lo into bf16, three bf16 MFMAs per product, fp32 accumulate: 16-bit
-                   operand mantissas (the config names plain bf16 = 8), parity-tested at the 1e-3 bar;
-  f32              exact fp32 products on v_mfma_f32_32x32x2_f32 (strict mode, 1/16 of the bf16 MFMA rate);
-  bf16             operands rounded to bf16 (what the config names; NOT inside the parity bar, reported for reference).
+  bf16x3  fp32 operands split hi + lo into bf16, three bf16 MFMAs per product, fp32 accumulate: 16-bit operand
+          mantissas (config 3 names plain bf16 = 8), parity-tested at the 1e-3 bar;
+  f32     exact fp32 products on v_mfma_f32_32x32x2_f32 (strict mode, 1/16 of the bf16 MFMA rate);
+  bf16    operands rounded to bf16 (what config 3 names; NOT inside the parity bar, reported for reference).
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel: the 3x3 reflect-pad 128->128 resblock
-convolution forward, timed live with HIP events on its launch stream) and `cpu_baseline` (the oracle "port"
-timed on this box's host cores on a bounded sample).
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel: the 3x3 reflect-pad 128->128 resblock convolution forward),
+`roofline_hbm` (the stride-2 64->128 downsample convolution forward, HBM-bound) — both timed live with HIP events on the
+launch stream, kernel names read back from the dispatcher — and `cpu_baseline` (the oracle "port" on the host cores).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
+CONFIGS = {
+    2: dict(size=128, nc=3, blocks=6, batch=16, precision="f32", name="configs[1]"),
+    3: dict(size=256, nc=3, blocks=9, batch=32, precision="bf16x3", name="configs[2] (configs[3] at 8 GPUs)"),
+    5: dict(size=512, nc=1, blocks=9, batch=16, precision="bf16x3", name="configs[4]"),
+}
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)      # >= 50 timed steps after >= 10 warm-up steps
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5], help="BASELINE.json workload (4 = 3 on 8 GPUs)")
+    ap.add_argument("--batch", type=int, default=None, help="(A,B) pairs per GPU (default: the config's)")
+    ap.add_argument("--size", type=int, default=None)
+    ap.add_argument("--blocks", type=int, default=None)
+    ap.add_argument("--nc", type=int, default=None, help="image channels of both domains")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-bn", action="store_true", help="BatchNorm statistics over all ranks (default: per rank, as the "
+                                                           "reference's data_parallel)")
+    ap.add_argument("--precision", default=None, choices=["f32", "bf16x3", "bf16"],
+                    help="conv arithmetic, see the module docstring (default: the config's)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher test: ranks rendezvous over gloo on the CPU, exchange one all-reduce and print the line "
+                         "without touching a GPU")
+    a = ap.parse_args(argv)
+    c = CONFIGS[3 if a.config == 4 else a.config]
+    for k in ("batch", "size", "blocks", "nc", "precision"):
+        if getattr(a, k) is None:
+            setattr(a, k, c[k])
+    a.config_name = c["name"]
+    return a
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# launcher: N fresh ranks (never re-exec a process that touched the GPU; the parent makes no GPU call at all)
+# --------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(a, argv):
+    port = int(os.environ.get("MASTER_PORT") or _free_port())
+    env = dict(os.environ, WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    import tempfile
+    procs = []
+    cap = tempfile.TemporaryFile(mode="w+")      # rank 0's stdout (the JSON line); every other rank's stdout goes to stderr
+    for r in range(a.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=cap if r == 0 else sys.stderr, text=True))
+    codes = [None] * a.gpus
+    while any(c is None for c in codes):         # a rank that dies would leave the others waiting in a collective
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.kill()                     # exactly the children started above
+                    codes[i] = p.wait()
+        time.sleep(0.05)
+    cap.seek(0)
+    out0 = cap.read()
+    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    for ln in (out0 or "").splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if any(codes) or not lines:
+        print("bench.py: rank exit codes %s" % codes, file=sys.stderr)
+        sys.exit(1)
+    print(lines[-1], flush=True)
+
+
+# --------------------------------------------------------------------------------------------------------------------
 def make_opt(a, local_rank):
-    return argparse.Namespace(input_nc=3, output_nc=3, ngf=32, nef=32, ndf=64, nlatent=16, lr=2e-4, beta1=0.5,
+    return argparse.Namespace(input_nc=a.nc, output_nc=a.nc, ngf=32, nef=32, ndf=64, nlatent=16, lr=2e-4, beta1=0.5,
                               max_gnorm=500.0, lambda_A=1.0, lambda_B=1.0, lambda_z_B=0.025, lambda_sup_A=0.1,
                               lambda_sup_B=0.1, stoch_enc=False, z_gan=1, enc_A_B=1, no_lsgan=False, norm="instance",
                               use_dropout=False, which_model_netG="resnet", which_model_netD="basic",
                               gpu_ids=[local_rank], monitor_gnorm=True, niter_decay=25, expr_dir="/tmp",
-                              n_blocks=a.blocks)
+                              n_blocks=a.blocks, sync_bn=a.sync_bn)
+
+
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(a):
     """Oracle ("port": from-scratch C/NumPy restatement of the reference's networks.py/model.py path, pinned to the
-    reference by tests/golden) timed on the host cores.  Bounded sample: ONE (A,B) pair of the same step."""
+    reference by tests/golden) timed on the host cores.  Bounded sample: batch 2 of the same step, one warm-up step
+    (page faults, thread pool), then two timed steps."""
     # the 1-GPU box's CPU share is 16 cores; pin the OpenMP pool BEFORE the C library loads
     os.environ.setdefault("OMP_NUM_THREADS", str(min(16, len(os.sched_getaffinity(0)))))
     cores = int(os.environ["OMP_NUM_THREADS"])
     import numpy as np
     from oracle import recipe, step
-    opt = step.Opt(input_nc=3, output_nc=3, n_blocks=a.blocks)
+    opt = step.Opt(input_nc=a.nc, output_nc=a.nc, n_blocks=a.blocks)
     m = step.AugStep(opt, dtype=np.float32)
     m.load({n: recipe.values_for(net.shapes, n, 0, "init") for n, net in m.nets().items()})
-    A, B, z = recipe.inputs(0, 1, 3, 3, a.size, 16)
+    nb, timed = 2, 2
+    batches = [recipe.inputs(s, nb, a.nc, a.nc, a.size, 16) for s in range(1 + timed)]
+    m.train_instance(*batches[0])
     t0 = time.time()
-    m.train_instance(A, B, z)
-    dt = time.time() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "1 step of batch 1 (one A,B pair) of the same %dx%dx3 %d-resblock full Augmented CycleGAN step, "
-                      "fp32, %.1f s" % (a.size, a.size, a.blocks, dt)}
+    for b in batches[1:]:
+        m.train_instance(*b)
+    dt = (time.time() - t0) / timed
+    return {"value": round(nb / dt, 4), "unit": "images/s", "cores": cores, "cpu": _cpu_model(), "kind": "port",
+            "sample": "%d timed steps (after 1 warm-up step) of batch %d of the same %dx%dx%d %d-resblock full Augmented "
+                      "CycleGAN step, fp32, %.1f s per step" % (timed, nb, a.size, a.size, a.nc, a.blocks, dt),
+            "note": "plain-C loops, cache-blocked but not register-blocked: SURVEY.md §6 measured the reference's own "
+                    "torch-CPU (MKL-DNN) path at 0.45 images/s on 8 threads for the 256x256x3 3-resblock StochCycleGAN step "
+                    "(593 GFLOP/pair = 267 GFLOP/s); the 9-resblock full step is 1289 GFLOP/pair, i.e. about 0.2 images/s "
+                    "for the real reference on 8 cores.  This port is a baseline, slower than that library path; the GPU/CPU "
+                    "ratio is not a quality measure, roofline.frac is."}
+
+
+def dry_run(a):
+    """ranks rendezvous over gloo without touching a GPU (CPU test of the self-launch path)"""
+    import torch
+    import torch.distributed as td
+    ws, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if ws > 1:
+        td.init_process_group(backend="gloo")
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+        td.barrier()
+        assert float(t) == ws * (ws + 1) / 2.0
+    if rank == 0:
+        print(json.dumps({"metric": "training images/sec, 256x256 Augmented CycleGAN step, 1/2/4/8 MI355X", "dry_run": True,
+                          "value": None, "n_gpus": ws, "steps": a.steps, "warmup": a.warmup}), flush=True)
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="(A,B) pairs per GPU")
-    ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--blocks", type=int, default=9)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"],
-                    help="conv arithmetic, see the module docstring")
-    a = ap.parse_args()
+    argv = sys.argv[1:]
+    a = parse_args(argv)
+    if a.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(a, argv)          # parent: no torch.cuda / HIP call has happened in this process
+    if a.dry_run:
+        return dry_run(a)
 
-    import dtgan_amd
+    import torch
+    import dtgan_amd  # noqa: F401
     from dtgan_amd import dist as D, model as M, ops
     rank, ws = D.init_from_env()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    assert ws == a.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, ws)
+    assert ws == a.gpus, "WORLD_SIZE=%d but --gpus %d" % (ws, a.gpus)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ops.set_precision(a.precision)
@@ -85,9 +202,9 @@ def main():
     model = M.AugmentedCycleGAN(make_opt(a, local_rank), testing=True)
 
     g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
-    N, S = a.batch, a.size
-    real_A = torch.rand((N, 3, S, S), device=dev, generator=g) * 2 - 1
-    real_B = torch.rand((N, 3, S, S), device=dev, generator=g) * 2 - 1
+    N, S, nc = a.batch, a.size, a.nc
+    real_A = torch.rand((N, nc, S, S), device=dev, generator=g) * 2 - 1
+    real_B = torch.rand((N, nc, S, S), device=dev, generator=g) * 2 - 1
 
     def step():
         z = torch.randn((N, 16, 1, 1), device=dev, generator=g)       # train.py:193: fresh prior every step
@@ -100,52 +217,68 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    # dominant kernel: resblock 3x3 reflect conv 128->128 at S/2 (forward launches only)
-    timer = ops.ConvTimer(lambda d: d.K == 3 and d.Ci == 128 and d.Co == 128 and d.stride == 1 and d.pad_mode == 1)
-    ops.CONV_TIMER = timer
+    # dominant kernel: resblock 3x3 reflect conv 128->128 at S/2; HBM-bound companion: the stride-2 64->128 downsample
+    # (networks.py:168, 220) at full resolution — forward launches only, HIP events on the launch stream
+    t_res = ops.ConvTimer(lambda d: d.K == 3 and d.Ci == 128 and d.Co == 128 and d.stride == 1 and d.pad_mode == 1)
+    t_s2 = ops.ConvTimer(lambda d: d.K == 3 and d.Ci == 64 and d.Co == 128 and d.stride == 2 and d.Hi == S)
+    ops.CONV_TIMERS[:] = [t_res, t_s2]
     barrier()
     t0 = time.time()
     for _ in range(a.steps):
         losses, _, _ = step()
     barrier()
     dt = time.time() - t0
-    ops.CONV_TIMER = None
+    ops.CONV_TIMERS[:] = []
     if ws > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt)
     if rank != 0:
         return
-    ms = timer.ms()
+    ms = t_res.ms()
     kern_ms = sum(ms) / max(len(ms), 1)
     flops = 2.0 * N * (S // 2) * (S // 2) * 128 * 128 * 9
     achieved = flops / (kern_ms * 1e-3) / 1e12 if ms else None
     # dense MFMA peaks (MI355X_MICROARCH.md): fp32 157.3, bf16 2500 TFLOP/s; bf16x3 issues 3 bf16 MFMAs per
     # algorithmic product, so its ceiling for ALGORITHMIC flops is 2500 / 3
     peak = {"f32": 157.3, "bf16x3": round(2500.0 / 3, 1), "bf16": 2500.0}[a.precision]
-    kname = {"f32": "igemm_conv_f32<128,128,2,2,32,REFLECT,!THIN>", "bf16x3": "igemm_conv_x3_ws<REFLECT,STATS> (wave-specialised, 16x16x32 bf16 MFMA x3)",
-             "bf16": "igemm_conv_bf16<128,128,2,2,64,REFLECT,!SPLIT>"}[a.precision]
-    dtype = {"f32": "f32", "bf16x3": "f32 tensors; conv products as 3 bf16 MFMAs on hi/lo-split fp32 operands (~2^-17 operand rounding), fp32 accumulate",
+    dtype = {"f32": "f32",
+             "bf16x3": "f32 tensors; conv products as 3 bf16 MFMAs on hi/lo-split fp32 operands (~2^-17 operand rounding), fp32 "
+                       "accumulate; parity vs the reference goldens: losses / single-pass images / cycle reconstructions <= 1e-3 "
+                       "(3e-3 on rec_A/rec_B of the deliberately ill-conditioned 'rich' fixture only)",
              "bf16": "bf16 (MFMA operands; fp32 accumulate and fp32 tensors)"}[a.precision]
-    traffic = None
-    # measured by tools/profile_traffic.sh + tools/summarize_traffic.py (separate --pmc passes), committed per kernel
-    tj = os.path.join(ROOT, "profiles", {"f32": "r01_c_resblock_conv_traffic_f32.json",
-                                         "bf16x3": "r01_f_resblock_conv_traffic_bf16x3.json"}.get(a.precision, "-"))
-    if os.path.exists(tj) and (N, S) == (32, 256):
-        traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
+    # HBM traffic of the dominant kernel: measured by tools/profile_traffic.sh + tools/summarize_traffic.py (separate
+    # rocprofv3 --pmc passes; counters cannot be read inside the timed run), committed per kernel under profiles/
+    traffic, traffic_src = None, None
+    for cand in ({"f32": ["r01_c_resblock_conv_traffic_f32.json"],
+                  "bf16x3": ["r02_resblock_conv_traffic_bf16x3.json", "r01_f_resblock_conv_traffic_bf16x3.json"]}.get(a.precision, [])):
+        tj = os.path.join(ROOT, "profiles", cand)
+        if os.path.exists(tj) and (N, S, nc) == (32, 256, 3):
+            traffic, traffic_src = json.load(open(tj)).get("hbm_bytes_per_launch"), "profiles/" + cand
+            break
+    ms2 = t_s2.ms()
+    k2 = sum(ms2) / max(len(ms2), 1)
+    bytes2 = 4.0 * (N * S * S * 64 + N * (S // 2) * (S // 2) * 128 + 9 * 64 * 128)   # in + out + weights, each once
     out = {
         "metric": "training images/sec, 256x256 Augmented CycleGAN step, 1/2/4/8 MI355X",
         "value": round(ws * N * a.steps / dt, 3), "unit": "images/s", "n_gpus": ws, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
         "dtype": dtype, "data": "synthetic",
-        "config": {"workload": "%dx%dx3 synthetic unpaired, %d-resblock G + latent encoder (full Augmented CycleGAN "
-                               "train_instance), batch=%d per GPU (global %d)" % (S, S, a.blocks, N, N * ws),
-                   "parallelism": "dp%d" % ws, "loss_G_A": round(losses["G_A"], 5)},
-        "roofline": {"bound": "mfma", "kernel": kname + " (resblock 3x3 reflect 128->128 fwd)",
+        "config": {"workload": "%s: %dx%dx%d synthetic unpaired, %d-resblock G + latent encoder + latent discriminator (full "
+                               "Augmented CycleGAN train_instance), batch=%d per GPU (global %d)"
+                               % (a.config_name, S, S, nc, a.blocks, N, N * ws),
+                   "parallelism": "dp%d" % ws, "batchnorm": "sync" if a.sync_bn else "per-rank",
+                   "loss_G_A": round(losses["G_A"], 5)},
+        "roofline": {"bound": "mfma", "kernel": "%s (resblock 3x3 reflect 128->128 fwd)" % t_res.kernel,
                      "achieved": None if achieved is None else round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": None if achieved is None else round(achieved / peak, 4), "traffic": traffic,
-                     "launches_timed": len(ms), "avg_launch_ms": round(kern_ms, 4), "flops_per_launch": flops},
+                     "traffic_source": traffic_src, "launches_timed": len(ms), "avg_launch_ms": round(kern_ms, 4),
+                     "flops_per_launch": flops},
+        "roofline_hbm": {"bound": "hbm", "kernel": "%s (3x3 stride-2 64->128 downsample fwd)" % t_s2.kernel,
+                         "achieved": round(bytes2 / (k2 * 1e-3) / 1e9, 1) if ms2 else None, "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(bytes2 / (k2 * 1e-3) / 1e9 / 8000.0, 4) if ms2 else None,
+                         "launches_timed": len(ms2), "avg_launch_ms": round(k2, 4), "bytes_per_launch": bytes2},
     }
     if ws == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a)

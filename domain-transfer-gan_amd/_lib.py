@@ -31,6 +31,7 @@ _D = ctypes.POINTER(ConvDesc)
 SIGNATURES = {
     "acg_version": (c_int, []),
     "acg_last_error": (ctypes.c_char_p, []),
+    "acg_last_kernel": (ctypes.c_char_p, []),
     "acg_set_conv_impl": (c_int, [c_int]),
     "acg_set_conv_precision": (c_int, [c_int]),
     "acg_nchw_to_nhwc16": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),

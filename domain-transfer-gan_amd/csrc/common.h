@@ -9,6 +9,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void acg_set_error(const char *fmt, ...);
+void acg_note_kernel(const char *fmt, ...);
 extern int g_acg_conv_impl;
 
 #define ACG_REQUIRE(cond, ...)                 \

@@ -267,6 +267,8 @@ int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, fl
     else BF16_DISPATCH(16, false);
 #undef BF16_DISPATCH
     ACG_CHECK_LAUNCH("igemm_conv_bf16");
+    acg_note_kernel("igemm_conv_bf16<128,%d,KC=%d,REFLECT=%d,SPLIT=%d>", bn,
+                    split ? (g.Cin % 32 == 0 ? 32 : 16) : (g.Cin % 64 == 0 ? 64 : (g.Cin % 32 == 0 ? 32 : 16)), g.reflect ? 1 : 0, split ? 1 : 0);
     return ACG_OK;
 }
 
@@ -614,5 +616,6 @@ int acg_wgrad_bf16_launch(const float *x, const float *dy, float *part, const WG
     else WG_BF16(32, 32, 1, 1, 4, 256);
 #undef WG_BF16
     ACG_CHECK_LAUNCH("wgrad_bf16");
+    acg_note_kernel("wgrad_bf16<%d,%d,SPLIT=%d>", bci, bco, split ? 1 : 0);
     return ACG_OK;
 }

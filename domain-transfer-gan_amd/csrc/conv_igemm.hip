@@ -307,5 +307,6 @@ int acg_igemm_launch(const float *in, const float *wp, const float *bias, float 
         else launch_v<16, false, false>(bn, grid, st, in, wp, bias, out, g, t, inb, wb);
     }
     ACG_CHECK_LAUNCH("igemm_conv_f32");
+    acg_note_kernel("igemm_conv_f32<128,%d,KC=%d,REFLECT=%d,THIN=%d,X3=%d>", bn, (kc32 ? 32 : 16), g.reflect ? 1 : 0, g.thin ? 1 : 0, (g.thin && x3) ? 1 : 0);
     return ACG_OK;
 }

@@ -138,5 +138,6 @@ int acg_conv_patch16_launch(const float *in, const void *wp, const float *bias, 
         hipLaunchKernelGGL((conv_patch16_x3<false>), dim3((unsigned)blocks), dim3(256), 0, st, in, (const __bf16 *)wp, bias, out, g, t,
                            ymin, xmin, PH, PW, (unsigned)in_bytes, n_w_elems);
     ACG_CHECK_LAUNCH("conv_patch16_x3");
+    acg_note_kernel("conv_patch16_x3<REFLECT=%d>", g.reflect ? 1 : 0);
     return ACG_OK;
 }

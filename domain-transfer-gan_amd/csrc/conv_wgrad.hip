@@ -292,5 +292,6 @@ int acg_wgrad_launch(const float *x, const float *dy, float *part, const WGeom &
     else
         hipLaunchKernelGGL((wgrad_f32<32, 32, 1, 1, 4, 128>), grid, block, 0, st, x, dy, part, g, t, xb, db);
     ACG_CHECK_LAUNCH("wgrad_f32");
+    acg_note_kernel("wgrad_f32");
     return ACG_OK;
 }

@@ -485,6 +485,7 @@ int acg_wgrad_krow_s_launch(const float *x, const float *dy, float *part, const 
     if (g.Cin == 32) hipLaunchKernelGGL((wgrad_x3_krow_s<32, 64>), dim3(blocks), dim3(256), 0, st, x, dy, part, g, (unsigned)xbytes, (unsigned)dbytes);
     else hipLaunchKernelGGL((wgrad_x3_krow_s<64, 32>), dim3(blocks), dim3(256), 0, st, x, dy, part, g, (unsigned)xbytes, (unsigned)dbytes);
     ACG_CHECK_LAUNCH("wgrad_x3_krow_s");
+    acg_note_kernel("wgrad_x3_krow_s<%d,%d>", g.Cin, g.Cin == 32 ? 64 : 32);
     return ACG_OK;
 }
 
@@ -509,5 +510,6 @@ int acg_wgrad_krow_launch(const float *x, const float *dy, float *part, const WG
     ACG_REQUIRE(xbytes < (1LL << 32) && dbytes < (1LL << 32), "wgrad_x3_krow: operand exceeds the 4 GiB buffer-addressing limit");
     hipLaunchKernelGGL(wgrad_x3_krow, dim3(blocks), dim3(512), 0, st, x, dy, part, g, (unsigned)xbytes, (unsigned)dbytes);
     ACG_CHECK_LAUNCH("wgrad_x3_krow");
+    acg_note_kernel("wgrad_x3_krow");
     return ACG_OK;
 }

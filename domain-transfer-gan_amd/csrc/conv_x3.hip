@@ -436,6 +436,7 @@ int acg_igemm_x3_ws_launch(const float *in, const void *wp, const float *bias, f
 #undef X3_WS2
 #undef X3_WS
     ACG_CHECK_LAUNCH("igemm_conv_x3_ws");
+    acg_note_kernel("igemm_conv_x3_ws<REFLECT=%d,STATS=%d,ROWP=%d>", g.reflect ? 1 : 0, stats ? 1 : 0, kdim ? 1 : 0);
     return ACG_OK;
 }
 

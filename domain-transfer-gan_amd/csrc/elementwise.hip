@@ -20,6 +20,17 @@ void acg_set_error(const char *fmt, ...)
     va_end(ap);
 }
 extern "C" const char *acg_last_error(void) { return g_err; }
+// name (template arguments included) of the convolution kernel the calling thread dispatched last — bench.py labels its
+// roofline with what actually ran instead of a hard-coded string
+static thread_local char g_kern[160] = "";
+void acg_note_kernel(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kern, sizeof(g_kern), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *acg_last_kernel(void) { return g_kern; }
 extern "C" int acg_version(void) { return ACG_VERSION; }
 
 // ---------------------------------------------------------------- activation backward

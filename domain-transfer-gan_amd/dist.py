@@ -2,11 +2,17 @@
 ROCm; "gloo" for the CPU tests).
 
 The unpaired A/B minibatch shards by rank with no data-path collective; the only exchange is the
-gradient average of each optimiser phase: one all-reduce over the flat gradient
-buffers of D_A+D_B+D_z_B after loss_D.backward() and one over G_B_A+G_A_B+E_B after loss_G.backward(),
-both BEFORE the per-network clip (the clip coefficient depends on the global-batch gradient norm,
-model.py:447-449, 510-512).  The reference's nn.parallel.data_parallel (networks.py:194-195 etc.) is
-replaced, not translated.
+gradient average of each optimiser phase: the flat gradient buffers of D_A, D_B, D_z_B
+after loss_D.backward() and of G_B_A, G_A_B, E_B after loss_G.backward(), each BEFORE that network's
+clip (the clip coefficient depends on the global-batch gradient norm, model.py:447-449, 510-512).
+The reference's nn.parallel.data_parallel (networks.py:194-195 etc.) is replaced, not translated.
+
+Overlap (PhaseExchange): every parameter carries a post-accumulate-grad hook; when the last gradient of a
+network has been written — in the middle of the backward pass — that network's all-reduce is launched on
+RCCL's stream and runs beside the rest of the backward (and, for the D phase, beside the G-phase forwards
+that do not depend on the discriminators, model.py:467-494).  Nothing waits until the network's own
+clip + Adam.  The step's reported scalars travel in a small tail behind one gradient buffer, so a step
+issues exactly six collectives (seven with SyncBN's statistics excluded) and ONE device->host copy.
 """
 import os
 
@@ -15,8 +21,13 @@ import torch.distributed as td
 
 
 # test hook: ACGAN_DIST_FORCE=1 runs every collective in a ONE-rank group too, so that the RCCL path (init, all-reduce of
-# the flat gradient buffers, the float64 scalar reductions) can be exercised on a single-GPU box
+# the flat gradient buffers, the scalar tail) can be exercised on a single-GPU box
 _FORCE = os.environ.get("ACGAN_DIST_FORCE") == "1"
+
+# floats reserved behind every flat gradient buffer: [0, SUM_SLOTS) rank-averaged scalars, then 4 per rank for min/max monitors
+SUM_SLOTS = 32
+MAX_RANKS = 8
+SCALAR_TAIL = SUM_SLOTS + 4 * MAX_RANKS
 
 
 def is_on():
@@ -46,33 +57,122 @@ def init_from_env(backend=None):
     if backend == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     td.init_process_group(backend=backend)
+    if td.get_world_size() > MAX_RANKS:
+        raise RuntimeError("the scalar tail of the gradient buffers holds %d ranks (one node); got %d" % (MAX_RANKS, td.get_world_size()))
     return rank(), world_size()
+
+
+def _staged():
+    """test-only situation: gloo with CUDA tensors (2 ranks sharing the box's one GPU) -> stage through the host"""
+    return td.get_backend() == "gloo"
+
+
+class _Done(object):
+    def wait(self):
+        return True
+
+
+def _allreduce_avg_async(buf):
+    """Average `buf` over the ranks in place; returns a handle whose wait() orders the current stream behind it."""
+    ws = world_size()
+    if td.get_backend() == "nccl":   # RCCL averages in the collective itself (ncclAvg): no extra kernel
+        return td.all_reduce(buf, op=td.ReduceOp.AVG, async_op=True)
+    if buf.is_cuda:                  # gloo + device tensors (tests): blocking, through the host
+        h = buf.cpu()
+        td.all_reduce(h, op=td.ReduceOp.SUM)
+        buf.copy_(h.mul_(1.0 / ws))
+        return _Done()
+    td.all_reduce(buf, op=td.ReduceOp.SUM)   # gloo on host tensors (CPU tests)
+    buf.mul_(1.0 / ws)
+    return _Done()
 
 
 def allreduce_mean_(bufs):
     """In-place average of each flat buffer across ranks (async launches, one wait at the end)."""
-    ws = world_size()
     if not exchange_on():
         return
-    if td.get_backend() == "gloo" and bufs[0].is_cuda:
-        # test-only path (2 ranks sharing one GPU under gloo): stage through the host
-        for b in bufs:
-            h = b.cpu()
-            td.all_reduce(h, op=td.ReduceOp.SUM)
-            b.copy_(h.mul_(1.0 / ws))
-        return
-    works = [td.all_reduce(b, op=td.ReduceOp.SUM, async_op=True) for b in bufs]
-    for w in works:
+    for w in [_allreduce_avg_async(b) for b in bufs]:
         w.wait()
-    for b in bufs:
-        b.mul_(1.0 / ws)
+
+
+class PhaseExchange(object):
+    """The gradient exchange of ONE optimiser phase, overlapped with the backward pass that produces the gradients.
+
+    arm(buckets) before backward(): `buckets` are objects with `.g` (flat gradient buffer incl. its scalar tail) and
+    `.params`, in the order their gradients are expected to complete.  The per-parameter hooks (hook_params) call
+    param_done(); when a bucket has seen as many gradients as it did in this phase's previous step, its all-reduce is
+    launched — strictly in the armed order, so every rank issues the same sequence of collectives whatever order its
+    autograd engine happened to use.  flush() after backward() launches whatever is left (always everything on a phase's
+    first step, when nothing is known yet).  A gradient that arrives AFTER its bucket was launched means the graph
+    changed between steps: that raises instead of silently reducing a partial sum.
+    """
+
+    def __init__(self, name):
+        self.name = name
+        self.expected = {}     # id(bucket) -> gradients seen in the previous step of this phase
+        self.buckets, self.works, self.seen, self.launched = [], [], [], []
+        self.armed = False
+
+    def arm(self, buckets):
+        self.buckets = list(buckets)
+        n = len(self.buckets)
+        self.works, self.seen, self.launched, self.next = [None] * n, [0] * n, [False] * n, 0
+        for i, b in enumerate(self.buckets):
+            b._exchange = (self, i)
+        self.armed = True
+
+    def param_done(self, i):
+        if self.launched[i]:
+            raise RuntimeError("%s: a gradient of bucket %d arrived after its all-reduce was launched (the autograd graph "
+                               "changed between steps)" % (self.name, i))
+        self.seen[i] += 1
+        self._pump()
+
+    def _pump(self):
+        while self.next < len(self.buckets):
+            i = self.next
+            exp = self.expected.get(id(self.buckets[i]))
+            if exp is None or self.seen[i] < exp:
+                return
+            self._launch(i)
+
+    def _launch(self, i):
+        self.works[i] = _allreduce_avg_async(self.buckets[i].g)
+        self.launched[i] = True
+        self.next = i + 1
+
+    def flush(self):
+        """after backward(): launch the rest, remember how many gradients each bucket received"""
+        for i in range(self.next, len(self.buckets)):
+            self._launch(i)
+        for i, b in enumerate(self.buckets):
+            self.expected[id(b)] = self.seen[i]
+            b._exchange = None
+        self.armed = False
+
+    def wait(self, bucket):
+        for i, b in enumerate(self.buckets):
+            if b is bucket and self.works[i] is not None:
+                self.works[i].wait()
+                self.works[i] = None
+
+
+def hook_params(bucket):
+    """post-accumulate-grad hooks on every parameter of `bucket` (a model.FlatNet): route to the armed exchange, if any"""
+    def hook(_p):
+        ex = bucket._exchange
+        if ex is not None:
+            ex[0].param_done(ex[1])
+    bucket._exchange = None
+    for p in bucket.params:
+        p.register_post_accumulate_grad_hook(hook)
 
 
 def broadcast_params_(nets):
     """Rank 0's initial parameters/buffers to every rank (replicas must start identical)."""
     if not exchange_on():
         return
-    stage = td.get_backend() == "gloo"
+    stage = _staged()
     for n in nets:
         for t in list(n.parameters()) + list(n.buffers()):
             if stage and t.is_cuda:
@@ -83,23 +183,43 @@ def broadcast_params_(nets):
                 td.broadcast(t.data, src=0)
 
 
+def write_scalar_tail(tail, sums, minmax=None):
+    """Fill a gradient buffer's tail before its all-reduce: `sums` (device scalars, rank-AVERAGED by the collective) and
+    `minmax` = up to 4 device scalars kept per rank (slot of this rank; the other ranks contribute zeros, and the factor
+    world_size undoes the average), all without a host sync."""
+    if len(sums) > SUM_SLOTS:
+        raise RuntimeError("scalar tail: %d > %d slots" % (len(sums), SUM_SLOTS))
+    tail.zero_()
+    tail[:len(sums)].copy_(torch.stack([t.detach().reshape(()).float() for t in sums]))
+    if minmax:
+        r, ws = rank(), world_size()
+        v = torch.stack([t.detach().reshape(()).float() for t in minmax]) * float(ws)
+        tail[SUM_SLOTS + 4 * r: SUM_SLOTS + 4 * r + len(minmax)].copy_(v)
+
+
+def read_scalar_tail(tail, nsums, nminmax=0):
+    """-> (averaged sums [nsums], per-rank monitor matrix [world_size, nminmax]) as device tensors"""
+    ws = world_size()
+    mm = tail[SUM_SLOTS: SUM_SLOTS + 4 * ws].view(ws, 4)[:, :nminmax] if nminmax else None
+    return tail[:nsums], mm
+
+
 def average_scalars(vals, sq_keys=(), min_keys=(), max_keys=()):
-    """Reported scalars: rank-mean of the losses; gradient norms are already global (the gradients
-    were averaged before the norm); min/max monitors reduce accordingly.  `vals`: OrderedDict of floats."""
+    """Blocking host-side variant (kept for tools and tests; the training step uses the scalar tail instead):
+    rank-mean of `vals`, MIN / MAX for the named keys.  `vals`: OrderedDict of floats."""
     ws = world_size()
     if not exchange_on():
         return vals
     keys = list(vals.keys())
     dev = "cuda" if td.get_backend() == "nccl" else "cpu"
+    sign = [(-1.0 if k in min_keys else 1.0) for k in keys]          # min(x) = -max(-x): one MAX serves both
     t = torch.tensor([vals[k] for k in keys], dtype=torch.float64, device=dev)
     mean = t.clone(); td.all_reduce(mean, op=td.ReduceOp.SUM); mean /= ws
     out = type(vals)(zip(keys, mean.tolist()))
-    if min_keys:
-        mn = t.clone(); td.all_reduce(mn, op=td.ReduceOp.MIN)
-        for k in min_keys:
-            out[k] = float(mn[keys.index(k)])
-    if max_keys:
-        mx = t.clone(); td.all_reduce(mx, op=td.ReduceOp.MAX)
-        for k in max_keys:
-            out[k] = float(mx[keys.index(k)])
+    if min_keys or max_keys:
+        mx = t * torch.tensor(sign, dtype=torch.float64, device=dev)
+        td.all_reduce(mx, op=td.ReduceOp.MAX)
+        for k in list(min_keys) + list(max_keys):
+            i = keys.index(k)
+            out[k] = float(mx[i]) * sign[i]
     return out

@@ -95,7 +95,10 @@ class FlatNet(object):
             n += (p.numel() + 3) // 4 * 4
         self.n = n
         self.p = torch.zeros(n, device=dev, dtype=torch.float32)
-        self.g = torch.zeros(n, device=dev, dtype=torch.float32)
+        # the gradient buffer carries dist.SCALAR_TAIL extra floats: the all-reduce of the buffer also averages the
+        # step's reported scalars written there (no separate collective, no host sync)
+        self.g = torch.zeros(n + acg_dist.SCALAR_TAIL, device=dev, dtype=torch.float32)
+        self.gv, self.gtail = self.g[:n], self.g[n:]
         self.m = torch.zeros(n, device=dev, dtype=torch.float32)
         self.v = torch.zeros(n, device=dev, dtype=torch.float32)
         self.offs = offs
@@ -106,6 +109,9 @@ class FlatNet(object):
                 p.grad = self.g[o:o + p.numel()].view(p.shape)
         self.sumsq = torch.zeros((), device=dev, dtype=torch.float32)
         mark_dirty(net)
+        self._exchange = None
+        if acg_dist.exchange_on():
+            acg_dist.hook_params(self)
 
     def check(self):
         p0 = self.params[0]
@@ -141,10 +147,10 @@ class FusedAdam(object):
         self.t += 1
         out = []
         for f in self.flats:
-            ops.sumsq(f.g, f.sumsq)
+            ops.sumsq(f.gv, f.sumsq)
             out.append(f.sumsq)
         for f in self.flats:
-            ops.adam_step(f.p, f.g, f.m, f.v, f.sumsq, max_norm, g['lr'], g['betas'][0], g['betas'][1], g['eps'], self.t)
+            ops.adam_step(f.p, f.gv, f.m, f.v, f.sumsq, max_norm, g['lr'], g['betas'][0], g['betas'][1], g['eps'], self.t)
             mark_dirty(f.net)
         return out
 
@@ -174,12 +180,6 @@ class FusedAdam(object):
         self.param_groups[0]['lr'] = sd['param_groups'][0]['lr']
 
 
-def _finish_scalars(names, tensors):
-    """one D2H copy for every reported scalar"""
-    vals = torch.stack([t.detach().reshape(()).float() for t in tensors]).tolist()
-    return OrderedDict(zip(names, vals))
-
-
 class _Base(object):
     def _dev(self):
         return next(self.netG_A_B.parameters()).device
@@ -187,9 +187,44 @@ class _Base(object):
     def _nchw(self, x, C):
         return ops.ToNCHW.apply(x, C).detach()
 
-    def _allreduce(self, flats):
-        if acg_dist.exchange_on():
-            acg_dist.allreduce_mean_([f.g for f in flats])
+    def _backward(self, loss, phase, order, tail=None):
+        """loss.backward() with the gradient exchange of this optimiser phase overlapped (dist.PhaseExchange): `order` =
+        the FlatNets in the order their gradients complete; tail = (carrier FlatNet, sum scalars, min/max monitors) rides
+        behind the carrier's gradients.  Returns the exchange (wait(flat) before that network's clip) or None."""
+        if not acg_dist.exchange_on():
+            loss.backward()
+            return None
+        ex = self._exchanges.setdefault(phase, acg_dist.PhaseExchange(phase))
+        if tail is not None:
+            acg_dist.write_scalar_tail(tail[0].gtail, tail[1], tail[2] if len(tail) > 2 else None)
+        ex.arm(order)
+        try:
+            with _in_train_step():
+                loss.backward()
+        finally:
+            ex.flush()
+        return ex
+
+    @staticmethod
+    def _wait(ex, *flats):
+        if ex is not None:
+            for f in flats:
+                ex.wait(f)
+
+    def _scalars(self, ex, carrier, names, sums, mins=(), maxs=(), local=()):
+        """ONE device->host copy for every reported scalar.  `sums` are rank-averaged, `mins`/`maxs` reduced over ranks
+        (both through the carrier's gradient tail when the exchange is on), `local` = values that are already identical
+        on every rank (norms of the averaged gradients)."""
+        sums = [t.detach().reshape(()).float() for t in sums]
+        mm = [t.detach().reshape(()).float() for t in list(mins) + list(maxs)]
+        if ex is not None:
+            avg, per_rank = acg_dist.read_scalar_tail(carrier.gtail, len(sums), len(mm))
+            sums = list(avg.unbind(0))
+            if mm:
+                mm = [per_rank[:, i].min() for i in range(len(mins))] + \
+                     [per_rank[:, len(mins) + i].max() for i in range(len(maxs))]
+        vals = torch.stack(sums + [t.detach().reshape(()).float() for t in local] + mm).tolist()
+        return OrderedDict(zip(names, vals))
 
     # ---- north-star aliases (SURVEY D1) -----------------------------------------------------
     def set_input(self, data, prior_z_B=None):
@@ -211,6 +246,22 @@ class _Base(object):
             n.train()
 
 
+import contextlib  # noqa: E402
+
+
+@contextlib.contextmanager
+def _in_train_step():
+    """SyncBN collectives are issued only inside a training step, where every rank runs the same forward/backward; the
+    rank-0-only forwards of train.py (visualisation, evaluation) then use local statistics instead of posting
+    collectives the other ranks never join."""
+    from . import modules
+    prev, modules.IN_TRAIN_STEP = modules.IN_TRAIN_STEP, True
+    try:
+        yield
+    finally:
+        modules.IN_TRAIN_STEP = prev
+
+
 def _n_blocks(opt):
     from . import modules
     modules.SYNC_BN = bool(getattr(opt, 'sync_bn', False))   # extension: BatchNorm statistics over all ranks
@@ -222,6 +273,7 @@ class StochCycleGAN(_Base):
 
     def __init__(self, opt, ignore_noise=False, testing=False):
         self.ignore_noise = ignore_noise
+        self._exchanges = {}
         self.old_lr = opt.lr
         opt.use_sigmoid = opt.no_lsgan
         self.opt = opt
@@ -256,6 +308,10 @@ class StochCycleGAN(_Base):
         self.optimizer_D = FusedAdam([self.f_D_A, self.f_D_B], o.lr / 5., (o.beta1, 0.999))     # model.py:112-114
 
     def train_instance(self, real_A, real_B, prior_z_B):
+        with _in_train_step():
+            return self._train_instance(real_A, real_B, prior_z_B)
+
+    def _train_instance(self, real_A, real_B, prior_z_B):
         o = self.opt
         nA, nB = o.input_nc, o.output_nc
         for f in (self.f_G_A_B, self.f_G_B_A, self.f_D_A, self.f_D_B):
@@ -274,33 +330,33 @@ class StochCycleGAN(_Base):
         loss_D_A, loss_D_B = 0.5 * (l_fA + l_tA), 0.5 * (l_fB + l_tB)
         loss_D = loss_D_A + loss_D_B
         self.optimizer_D.zero_grad()
-        loss_D.backward()
-        self._allreduce(self.optimizer_D.flats)
-        ss_D_A, ss_D_B = self.optimizer_D.clip_and_step(o.max_gnorm)
-        ss_D_A, ss_D_B = ss_D_A.clone(), ss_D_B.clone()
+        ex_D = self._backward(loss_D, "stoch.D", [self.f_D_B, self.f_D_A])    # D_B was built last: its backward runs first
         m_tA, m_tB = ops.mean_valid(p_tA, 1), ops.mean_valid(p_tB, 1)
 
-        # ---- G phase with the UPDATED discriminators (model.py:167-190); D weight grads are not needed
-        self.f_D_A.set_requires_grad(False); self.f_D_B.set_requires_grad(False)
+        # ---- G phase (model.py:167-190).  The cycle forwards do not depend on the discriminators: they run while the
+        # D gradients are being all-reduced; the D forwards wait for the UPDATED discriminators (model.py:164-166)
+        rec_A = self.netG_B_A.forward_nhwc(fake_B); loss_cycle_A = ops.L1.apply(rec_A, A, nA)
+        rec_B = self.netG_A_B.forward_nhwc(fake_A, z); loss_cycle_B = ops.L1.apply(rec_B, B, nB)
+        self._wait(ex_D, self.f_D_A, self.f_D_B)
+        ss_D_A, ss_D_B = self.optimizer_D.clip_and_step(o.max_gnorm)
+        ss_D_A, ss_D_B = ss_D_A.clone(), ss_D_B.clone()
+        self.f_D_A.set_requires_grad(False); self.f_D_B.set_requires_grad(False)   # D weight grads are not needed
         try:
             p_fA = self.netD_A.forward_nhwc(fake_A); loss_G_A = _gan_loss(p_fA, True)
             p_fB = self.netD_B.forward_nhwc(fake_B); loss_G_B = _gan_loss(p_fB, True)
-            rec_A = self.netG_B_A.forward_nhwc(fake_B); loss_cycle_A = ops.L1.apply(rec_A, A, nA)
-            rec_B = self.netG_A_B.forward_nhwc(fake_A, z); loss_cycle_B = ops.L1.apply(rec_B, B, nB)
             loss_G = loss_G_A + loss_G_B + loss_cycle_A * o.lambda_A + loss_cycle_B * o.lambda_B
             self.optimizer_G.zero_grad()
-            loss_G.backward()
+            sums = [loss_D_A, loss_G_A, loss_cycle_A, loss_D_B, loss_G_B, loss_cycle_B,
+                    m_tA, ops.mean_valid(p_fA, 1), m_tB, ops.mean_valid(p_fB, 1)]
+            ex_G = self._backward(loss_G, "stoch.G", [self.f_G_B_A, self.f_G_A_B], tail=(self.f_G_A_B, sums))
         finally:
             self.f_D_A.set_requires_grad(True); self.f_D_B.set_requires_grad(True)
-        self._allreduce(self.optimizer_G.flats)
+        self._wait(ex_G, self.f_G_A_B, self.f_G_B_A)
         ss_G_A_B, ss_G_B_A = self.optimizer_G.clip_and_step(o.max_gnorm)
 
         names = ['D_A', 'G_A', 'Cyc_A', 'D_B', 'G_B', 'Cyc_B', 'P_t_A', 'P_f_A', 'P_t_B', 'P_f_B',
                  'gnorm_G_A_B', 'gnorm_G_B_A', 'gnorm_D_B', 'gnorm_D_A']
-        vals = _finish_scalars(names, [loss_D_A, loss_G_A, loss_cycle_A, loss_D_B, loss_G_B, loss_cycle_B,
-                                       m_tA, ops.mean_valid(p_fA, 1), m_tB, ops.mean_valid(p_fB, 1),
-                                       ss_G_A_B, ss_G_B_A, ss_D_B, ss_D_A])
-        vals = acg_dist.average_scalars(vals, sq_keys=names[10:])
+        vals = self._scalars(ex_G, self.f_G_A_B, names, sums, local=[ss_G_A_B, ss_G_B_A, ss_D_B, ss_D_A])
         losses = OrderedDict((k, vals[k]) for k in names[:10])                                   # model.py:193-196
         visuals = OrderedDict([('real_A', real_A.detach()), ('fake_B', self._nchw(fake_B, nB)),
                                ('rec_A', self._nchw(rec_A, nA)), ('real_B', real_B.detach()),
@@ -412,6 +468,7 @@ class AugmentedCycleGAN(_Base):
     """Augmented cycle gan — model.py:337-794"""
 
     def __init__(self, opt, testing=False):
+        self._exchanges = {}
         self.old_lr = opt.lr
         opt.use_sigmoid = opt.no_lsgan
         self.opt = opt
@@ -462,6 +519,10 @@ class AugmentedCycleGAN(_Base):
         return self.netE_B.forward_nhwc(x)
 
     def train_instance(self, real_A, real_B, prior_z_B):
+        with _in_train_step():
+            return self._train_instance(real_A, real_B, prior_z_B)
+
+    def _train_instance(self, real_A, real_B, prior_z_B):
         o = self.opt
         nA, nB, nl = o.input_nc, o.output_nc, o.nlatent
         flats_D = [self.f_D_A, self.f_D_B, self.f_D_z_B]
@@ -488,71 +549,85 @@ class AugmentedCycleGAN(_Base):
         l_rz = _gan_loss(self.netD_z_B.forward_dense(z), True)
         loss_D_A, loss_D_B, loss_D_z_B = 0.5 * (l_fA + l_tA), 0.5 * (l_fB + l_tB), 0.5 * (l_pz + l_rz)
         loss_D = loss_D_A + loss_D_B
-        if o.z_gan and not o.stoch_enc:
+        z_gan = bool(o.z_gan and not o.stoch_enc)
+        if z_gan:
             loss_D = loss_D + loss_D_z_B
         self.optimizer_D_A.zero_grad(); self.optimizer_D_B.zero_grad()
-        loss_D.backward()
-        self._allreduce(flats_D)
-        (ss_D_A,) = self.optimizer_D_A.clip_and_step(o.max_gnorm)
-        ss_D_B, ss_D_z = self.optimizer_D_B.clip_and_step(o.max_gnorm)
-        ss_D_A, ss_D_B, ss_D_z = ss_D_A.clone(), ss_D_B.clone(), ss_D_z.clone()
+        # completion order of the D backward = reverse build order: D_z_B, D_B, D_A (without the latent GAN term D_z_B
+        # receives no gradient at all, model.py:438-439, and goes last)
+        order_D = [self.f_D_z_B, self.f_D_B, self.f_D_A] if z_gan else [self.f_D_B, self.f_D_A, self.f_D_z_B]
+        ex_D = self._backward(loss_D, "aug.D", order_D)
         m_tA, m_tB = ops.mean_valid(p_tA, 1), ops.mean_valid(p_tB, 1)
 
-        # ---- G phase with the UPDATED discriminators (model.py:457-515)
-        for f in flats_D:
+        # ---- G phase (model.py:457-515).  The cycle / encoder forwards (model.py:467-494) do not depend on the
+        # discriminators: they are enqueued first and run while the D gradients are being all-reduced ...
+        rec_A = self.netG_B_A.forward_nhwc(fake_B); loss_cycle_A = ops.L1.apply(rec_A, A, nA)
+        mu_fB, lv_fB = self._encode(A, fake_B)                                                  # model.py:471-475
+        if o.stoch_enc:
+            lp = log_prob_gaussian(z, mu_fB[:, :nl], lv_fB[:, :nl])
+            loss_cycle_z_B = -1.0 * lp.mean(1).mean(0)                                          # model.py:480-484
+        else:
+            loss_cycle_z_B = ops.L1.apply(mu_fB, _pad_cols(z, mu_fB.shape[1]), nl)              # model.py:486-487
+        rec_B = self.netG_A_B.forward_nhwc(fake_A, post_z); loss_cycle_B = ops.L1.apply(rec_B, B, nB)
+        kld_z_B = kld_std_guss(mu_rB[:, :nl], lv_rB[:, :nl]).mean(0)                            # model.py:490
+        # ... the discriminator forwards need the UPDATED discriminators (model.py:455-457)
+        self._wait(ex_D, self.f_D_A)
+        (ss_D_A,) = self.optimizer_D_A.clip_and_step(o.max_gnorm)
+        self._wait(ex_D, self.f_D_B, self.f_D_z_B)
+        ss_D_B, ss_D_z = self.optimizer_D_B.clip_and_step(o.max_gnorm)
+        ss_D_A, ss_D_B, ss_D_z = ss_D_A.clone(), ss_D_B.clone(), ss_D_z.clone()
+        for f in flats_D:                                   # D weight gradients are not needed in the G phase
             f.set_requires_grad(False)
         try:
             p_fA = self.netD_A.forward_nhwc(fake_A); loss_G_A = _gan_loss(p_fA, True)
             p_fB = self.netD_B.forward_nhwc(fake_B); loss_G_B = _gan_loss(p_fB, True)
             loss_G_z_B = _gan_loss(self.netD_z_B.forward_dense(post_z), True)
-            rec_A = self.netG_B_A.forward_nhwc(fake_B); loss_cycle_A = ops.L1.apply(rec_A, A, nA)
-            mu_fB, lv_fB = self._encode(A, fake_B)                                              # model.py:471-475
-            if o.stoch_enc:
-                lp = log_prob_gaussian(z, mu_fB[:, :nl], lv_fB[:, :nl])
-                loss_cycle_z_B = -1.0 * lp.mean(1).mean(0)                                      # model.py:480-484
-            else:
-                loss_cycle_z_B = ops.L1.apply(mu_fB, _pad_cols(z, mu_fB.shape[1]), nl)          # model.py:486-487
-            rec_B = self.netG_A_B.forward_nhwc(fake_A, post_z); loss_cycle_B = ops.L1.apply(rec_B, B, nB)
             loss_G = loss_G_A + loss_G_B + loss_cycle_A * o.lambda_A + loss_cycle_B * o.lambda_B \
                 + loss_cycle_z_B * o.lambda_z_B
-            kld_z_B = kld_std_guss(mu_rB[:, :nl], lv_rB[:, :nl]).mean(0)                        # model.py:490
             if o.stoch_enc:
                 loss_G = loss_G + kld_z_B * o.lambda_z_B
-            if o.z_gan and not o.stoch_enc:
+            if z_gan:
                 loss_G = loss_G + loss_G_z_B
             self.optimizer_G_A.zero_grad(); self.optimizer_G_B.zero_grad()
-            loss_G.backward()
+            mu_v, lv_v = mu_rB.detach()[:, :nl], lv_rB.detach()[:, :nl]
+            sums = [loss_D_A, loss_G_A, loss_cycle_A, loss_cycle_z_B, kld_z_B, loss_D_B, loss_G_B, loss_cycle_B,
+                    loss_D_z_B, m_tA, ops.mean_valid(p_fA, 1), m_tB, ops.mean_valid(p_fB, 1)]
+            mins, maxs = [mu_v.min(), lv_v.min()], [mu_v.max(), lv_v.max()]
+            # completion order of the G backward: E_B (its first call is the last of the three first-pass networks to have
+            # been built), then G_B_A, then G_A_B — which therefore carries the scalar tail
+            ex_G = self._backward(loss_G, "aug.G", [self.f_E_B, self.f_G_B_A, self.f_G_A_B],
+                                  tail=(self.f_G_A_B, sums, mins + maxs))
         finally:
             for f in flats_D:
                 f.set_requires_grad(True)
-        self._allreduce([self.f_G_B_A, self.f_G_A_B, self.f_E_B])
+        self._wait(ex_G, self.f_G_B_A)
         (ss_G_B_A,) = self.optimizer_G_A.clip_and_step(o.max_gnorm)
+        self._wait(ex_G, self.f_G_A_B, self.f_E_B)
         ss_G_A_B, ss_E = self.optimizer_G_B.clip_and_step(o.max_gnorm)
 
-        mu_v, lv_v = mu_rB.detach()[:, :nl], lv_rB.detach()[:, :nl]
         names = ['D_A', 'G_A', 'Cyc_A', 'Cyc_z_B', 'KLD_z_B', 'D_B', 'G_B', 'Cyc_B', 'D_z_B',
                  'P_t_A', 'P_f_A', 'P_t_B', 'P_f_B',
                  'gnorm_G_A_B', 'gnorm_G_B_A', 'gnorm_E_B', 'gnorm_D_B', 'gnorm_D_z_B', 'gnorm_D_A',
-                 'mu_min', 'mu_max', 'logvar_min', 'logvar_max']
-        vals = _finish_scalars(names, [loss_D_A, loss_G_A, loss_cycle_A, loss_cycle_z_B, kld_z_B, loss_D_B, loss_G_B,
-                                       loss_cycle_B, loss_D_z_B, m_tA, ops.mean_valid(p_fA, 1), m_tB,
-                                       ops.mean_valid(p_fB, 1), ss_G_A_B, ss_G_B_A, ss_E, ss_D_B, ss_D_z, ss_D_A,
-                                       mu_v.min(), mu_v.max(), lv_v.min(), lv_v.max()])
-        vals = acg_dist.average_scalars(vals, sq_keys=names[13:19], min_keys=['mu_min', 'logvar_min'],
-                                        max_keys=['mu_max', 'logvar_max'])
+                 'mu_min', 'logvar_min', 'mu_max', 'logvar_max']
+        vals = self._scalars(ex_G, self.f_G_A_B, names, sums, mins, maxs,
+                             local=[ss_G_A_B, ss_G_B_A, ss_E, ss_D_B, ss_D_z, ss_D_A])
         losses = OrderedDict((k, vals[k]) for k in names[:13])                                  # model.py:518-523
         visuals = OrderedDict([('real_A', real_A.detach()), ('fake_B', self._nchw(fake_B, nB)),
                                ('rec_A', self._nchw(rec_A, nA)), ('real_B', real_B.detach()),
                                ('fake_A', self._nchw(fake_A, nA)), ('rec_B', self._nchw(rec_B, nB))])
         if o.monitor_gnorm:
             gnorms = OrderedDict((k, math.sqrt(max(vals[k], 0.0))) for k in names[13:19])       # model.py:527-533
-            for k in names[19:]:
+            for k in ('mu_min', 'mu_max', 'logvar_min', 'logvar_max'):
                 gnorms[k] = vals[k]
             return losses, visuals, gnorms
         return losses, visuals
 
     def supervised_train_instance(self, real_A, real_B, prior_z_B):
         """model.py:541-604 (paired step; off by default, --supervised)"""
+        with _in_train_step():
+            return self._supervised_train_instance(real_A, real_B, prior_z_B)
+
+    def _supervised_train_instance(self, real_A, real_B, prior_z_B):
         o = self.opt
         nA, nB, nl = o.input_nc, o.output_nc, o.nlatent
         A, B, z = ops.ToNHWC.apply(real_A), ops.ToNHWC.apply(real_B), as_latent(prior_z_B)
@@ -567,8 +642,8 @@ class AugmentedCycleGAN(_Base):
         l_rz = _gan_loss(self.netD_z_B.forward_dense(z), True)
         loss_D_z_B = 0.5 * (l_pz + l_rz)
         self.optimizer_D_B.zero_grad()
-        loss_D_z_B.backward()
-        self._allreduce([self.f_D_B, self.f_D_z_B])
+        ex_D = self._backward(loss_D_z_B, "sup.D", [self.f_D_z_B, self.f_D_B])
+        self._wait(ex_D, self.f_D_B, self.f_D_z_B)
         _, ss_D_z = self.optimizer_D_B.clip_and_step(o.max_gnorm)
         ss_D_z = ss_D_z.clone()
         self.f_D_z_B.set_requires_grad(False)
@@ -585,15 +660,17 @@ class AugmentedCycleGAN(_Base):
             if o.z_gan and not o.stoch_enc:
                 loss_G = loss_G + loss_G_z_B
             self.optimizer_G_A.zero_grad(); self.optimizer_G_B.zero_grad()
-            loss_G.backward()
+            sums = [loss_sup_A, loss_sup_B, kld_z_B, loss_D_z_B]
+            # backward order: G_B_A (built last), G_A_B, then the encoder behind post_z
+            ex_G = self._backward(loss_G, "sup.G", [self.f_G_B_A, self.f_G_A_B, self.f_E_B], tail=(self.f_E_B, sums))
         finally:
             self.f_D_z_B.set_requires_grad(True)
-        self._allreduce([self.f_G_B_A, self.f_G_A_B, self.f_E_B])
+        self._wait(ex_G, self.f_G_B_A)
         (ss_G_B_A,) = self.optimizer_G_A.clip_and_step(o.max_gnorm)
+        self._wait(ex_G, self.f_G_A_B, self.f_E_B)
         ss_G_A_B, ss_E = self.optimizer_G_B.clip_and_step(o.max_gnorm)
         names = ['S_A', 'S_B', 'KLD_z_B', 'D_z_B', 'gnorm_G_A_B', 'gnorm_G_B_A', 'gnorm_E_B', 'gnorm_D_z_B']
-        vals = _finish_scalars(names, [loss_sup_A, loss_sup_B, kld_z_B, loss_D_z_B, ss_G_A_B, ss_G_B_A, ss_E, ss_D_z])
-        vals = acg_dist.average_scalars(vals, sq_keys=names[4:])
+        vals = self._scalars(ex_G, self.f_E_B, names, sums, local=[ss_G_A_B, ss_G_B_A, ss_E, ss_D_z])
         for k in names[4:]:
             vals[k] = math.sqrt(max(vals[k], 0.0))
         return vals                                                                             # model.py:596-604

@@ -17,6 +17,9 @@ from .ops import ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, PAD_ZERO, PAD_REFLECT,
 
 USE_PYTORCH_IN = False  # modules.py:9
 SYNC_BN = False         # set by model.py from opt.sync_bn: BatchNorm statistics across all data-parallel ranks
+IN_TRAIN_STEP = False   # set by model.py around (supervised_)train_instance: the only place where every rank runs the same
+                        # BatchNorm forwards, i.e. where SyncBN may post collectives (train.py's visualisation and
+                        # evaluation forwards run on rank 0 only and use local statistics)
 
 
 def ops_dist_on():
@@ -101,7 +104,7 @@ class _BatchNormMixin(_Cached):
         if not self.training:  # eval mode: normalise with the running buffers (model.eval(), train.py:258)
             return ops.NormAct.apply(x, self.weight, self.bias, None, "bn_eval", act, self.eps, g, b,
                                      self.running_mean.contiguous(), self.running_var.contiguous(), 0.0)
-        if SYNC_BN and ops_dist_on():  # statistics over every rank's shard
+        if SYNC_BN and IN_TRAIN_STEP and ops_dist_on():  # statistics over every rank's shard
             y = ops.SyncBatchNormAct.apply(x, self.weight, self.bias, act, self.eps, g, b, self.running_mean,
                                            self.running_var, self.momentum)
             with torch.no_grad():

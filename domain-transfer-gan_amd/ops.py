@@ -190,13 +190,13 @@ class ConvTimer(object):
     so the roofline numerator/denominator come from the live timed region."""
 
     def __init__(self, match):
-        self.match, self.events = match, []
+        self.match, self.events, self.kernel = match, [], None
 
     def ms(self):
         return [a.elapsed_time(b) for a, b in self.events]
 
 
-CONV_TIMER = None
+CONV_TIMERS = []   # bench.py appends ConvTimer objects; every matching forward launch is bracketed by HIP events
 
 
 def conv_desc(N, Hi, Wi, Ci, Co, K, stride, pad, pad_mode, Cir=0, Cor=0):
@@ -239,7 +239,7 @@ class Conv2dFn(torch.autograd.Function):
         if d.Ho <= 0 or d.Wo <= 0:
             raise _lib.AcgError("conv: input %dx%d too small for kernel %d" % (Hi, Wi, packed.K))
         y = torch.empty((N, d.Ho, d.Wo, packed.Co), device=x.device, dtype=torch.float32)
-        timed = CONV_TIMER is not None and CONV_TIMER.match(d)
+        timed = [t for t in CONV_TIMERS if t.match(d)]
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -255,7 +255,9 @@ class Conv2dFn(torch.autograd.Function):
                       _ptr(y), act, _stream())
         if timed:
             e1.record()
-            CONV_TIMER.events.append((e0, e1))
+            for t in timed:
+                t.events.append((e0, e1))
+                t.kernel = _lib.query("acg_last_kernel").decode()   # what the dispatcher actually launched
         ctx.d, ctx.packed, ctx.act, ctx.has_bias = d, packed, act, bias is not None
         ctx.save_for_backward(x, y if act != ACT_NONE else None)
         if want_identity:
@@ -445,12 +447,14 @@ class SyncBatchNormAct(torch.autograd.Function):
         _lib.call("acg_norm_stats", _ptr(x), 1, P, C, eps, 0, _ptr(mean), _ptr(rstd), None, None, 0.0, _ptr(ws), nb, st)
         # local biased variance back from rstd, then combine across ranks: E[x], E[x^2] weighted by the pixel counts
         var = rstd.pow(-2) - eps
-        pack = torch.cat([mean * P, (var + mean * mean) * P, torch.full((1,), float(P), device=x.device)])
+        pack = torch.cat([mean * P, (var + mean * mean) * P])
         if td.get_backend() == "gloo" and pack.is_cuda:
             h = pack.cpu(); td.all_reduce(h); pack = h.to(x.device)
         else:
             td.all_reduce(pack)
-        Ptot = float(pack[-1])
+        # equal shards on every rank (the data-parallel contract: only then is the mean of the rank gradients the
+        # global-batch gradient, dist.py) -> the global pixel count is known on the host, no device->host sync here
+        Ptot = float(P) * td.get_world_size()
         gmean = pack[:C] / Ptot
         gvar = (pack[C:2 * C] / Ptot - gmean * gmean).clamp_(min=0.0)
         grstd = (gvar + eps).rsqrt()

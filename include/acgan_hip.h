@@ -53,6 +53,10 @@ typedef struct {
 
 int acg_version(void);
 const char *acg_last_error(void);
+/* Name, template arguments included, of the convolution kernel the calling thread dispatched last (e.g.
+ * "igemm_conv_x3_ws<REFLECT=1,STATS=1,ROWP=1>").  Diagnostic: the reference delegates algorithm choice to
+ * torch.nn.Conv2d / cuDNN (networks.py:158-189) and cannot say what ran; bench.py labels its roofline with this. */
+const char *acg_last_kernel(void);
 /* selects the convolution implementation for subsequent calls on this process
  * (MFMA implicit GEMM = product path; DIRECT = naive one-thread-per-output kernels kept
  * as an on-device cross-check).  Both are HIP kernels; there is no CPU path. */

@@ -126,3 +126,128 @@ def test_instance_norm_generator_is_per_sample():
         both = n(net.forward(t(B)))
         one = n(net.forward(t(B[:1])))
     assert rel(both[:1], one) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[1] (128x128x3, 6 resblocks, batch 16, fp32) and configs[4] (512x512x1, 9 resblocks) at full widths
+# ----------------------------------------------------------------------------------------------------------------------
+CFG2 = dict(input_nc=3, output_nc=3, ngf=32, nef=32, ndf=64, nlatent=16, n_blocks=6)
+CFG5 = dict(input_nc=1, output_nc=1, ngf=32, nef=32, ndf=64, nlatent=16, n_blocks=9)
+
+
+def _run_cfg(kw, S, Nb, prec, steps=1, seed=0, in_seed=60):
+    from hip_util import t, n, precision, load_recipe
+    from dtgan_amd import model as M
+    from oracle import recipe
+    with precision(prec):
+        m = M.AugmentedCycleGAN(make_opt(**kw), testing=True)
+        for k, net in m._net_dict().items():
+            load_recipe(net, k, seed, "init")
+        out = []
+        for s in range(steps):
+            A, B, z = recipe.inputs(in_seed + s, Nb, kw["input_nc"], kw["output_nc"], S, 16)
+            losses, visuals, gnorms = m.train_instance(t(A), t(B), t(z))
+            out.append((dict(losses), {k: n(v) for k, v in visuals.items()}, dict(gnorms)))
+    return out
+
+
+def _agree(rx3, r32):
+    from hip_util import rel
+    (lx3, vx3, gx3), (l32, v32, g32) = rx3, r32
+    a, b = np.array(list(lx3.values())), np.array(list(l32.values()))
+    bad = {k: (x, y) for k, x, y in zip(l32.keys(), a, b) if not np.isclose(x, y, rtol=1e-3, atol=2e-6)}
+    assert not bad, bad
+    for k in ("fake_A", "fake_B", "rec_A", "rec_B"):
+        assert rel(vx3[k], v32[k]) < 1e-3, (k, rel(vx3[k], v32[k]))
+    a, b = np.array(list(gx3.values())), np.array(list(g32.values()))
+    assert np.allclose(a, b, rtol=3e-3, atol=1e-6), dict(zip(g32.keys(), zip(a, b)))
+
+
+def test_config2_full_batch_step_fp32():
+    """configs[1] exactly as named: 128x128x3, 6-resblock generators, batch 16, exact-fp32 arithmetic — two steps (the second
+    runs on Adam-updated weights); the bf16x3 arithmetic agrees with it at the north-star bar on step 0."""
+    r32 = _run_cfg(CFG2, 128, 16, "f32", steps=2)
+    for losses, visuals, gnorms in r32:
+        assert all(np.isfinite(v) for v in losses.values()) and all(np.isfinite(v) for v in gnorms.values())
+        assert visuals["rec_B"].shape == (16, 3, 128, 128) and np.abs(visuals["fake_A"]).max() <= 1.0
+    assert r32[0][0] != r32[1][0]                      # the update was applied
+    _agree(_run_cfg(CFG2, 128, 16, "bf16x3")[0], r32[0])
+
+
+_ORACLE_CACHE = {}
+
+
+def _oracle_cfg2_step():
+    """(computed once for both precisions: ~15 s of host time)"""
+    if "cfg2" not in _ORACLE_CACHE:
+        from oracle import recipe, step
+        o = step.AugStep(step.Opt(**CFG2))
+        o.load({k: recipe.values_for(net.shapes, k, 2, "init") for k, net in o.nets().items()})
+        _ORACLE_CACHE["cfg2"] = o.train_instance(*recipe.inputs(70, 4, 3, 3, 128, 16))
+    return _ORACLE_CACHE["cfg2"]
+
+
+def _oracle_generators(cfg, S, nc, nb):
+    if ("gen", cfg) not in _ORACLE_CACHE:
+        from oracle import nets, recipe
+        from oracle.tape import T
+        A, B, z = recipe.inputs(80, 1, nc, nc, S, 16)
+        oB = nets.ResnetGenerator(nc, nc, 32, nb, np.float32); recipe.fill(oB, "netG_B_A", 4, "init")
+        oA = nets.CINResnetGenerator(16, nc, nc, 32, nb, np.float32); recipe.fill(oA, "netG_A_B", 4, "init")
+        _ORACLE_CACHE[("gen", cfg)] = (oB.forward(T(B)).v, oA.forward(T(A), T(z)).v)
+    return _ORACLE_CACHE[("gen", cfg)]
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_config2_step_matches_oracle(prec):
+    """configs[1] geometry at full widths, batch 4 (the oracle's C loops take a few seconds per pair here): the whole
+    Augmented CycleGAN step — 13 losses, 6 gradient norms, 4 images — against the fp32 oracle.  The encoder runs on a 5x5
+    map (S = 128): both sides use the spatial-mean extension."""
+    from hip_util import rel
+    (l1, v1, g1), = _run_cfg(CFG2, 128, 4, prec, seed=2, in_seed=70)
+    l0, v0, g0 = _oracle_cfg2_step()
+    lt, gt, vt = (2e-4, 1e-3, 1e-4) if prec == "f32" else (1e-3, 3e-3, 1e-3)
+    assert list(l1.keys()) == list(l0.keys())
+    assert np.allclose(list(l1.values()), list(l0.values()), rtol=lt, atol=2e-6), (l1, l0)
+    assert np.allclose(list(g1.values()), list(g0.values()), rtol=gt, atol=1e-6), (g1, g0)
+    for k in ("fake_A", "fake_B", "rec_A", "rec_B"):
+        assert rel(v1[k], v0[k]) < vt, (k, rel(v1[k], v0[k]))
+
+
+def test_config5_step_512x512x1():
+    """configs[4]: 512x512x1 Livneh-shaped fields, 9 resblocks (batch 4 of the 16 per GPU): the two parity arithmetics —
+    different kernels all the way down — agree at the north-star bar, on 1-channel images, 256x256 resblock maps
+    (largest operand of the full 16-image batch: 16 x 512 x 512 x 64 x 4 B = 1.07 GB, inside the 4 GiB buffer-addressing
+    limit of the conv launchers)."""
+    rx3 = _run_cfg(CFG5, 512, 4, "bf16x3")
+    r32 = _run_cfg(CFG5, 512, 4, "f32")
+    assert rx3[0][1]["rec_A"].shape == (4, 1, 512, 512)
+    _agree(rx3[0], r32[0])
+
+
+def test_config5_full_per_gpu_batch_runs():
+    """the full per-GPU batch of configs[4] (16 x 512x512x1): one bf16x3 step, finite, deterministic operand sizes"""
+    (losses, visuals, gnorms), = _run_cfg(CFG5, 512, 16, "bf16x3")
+    assert all(np.isfinite(v) for v in losses.values()) and all(np.isfinite(v) for v in gnorms.values())
+    assert visuals["fake_B"].shape == (16, 1, 512, 512)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg5"])
+def test_generator_forward_matches_oracle_at_full_size(cfg, prec):
+    """Both generators at the FULL geometry of configs[1], [2] and [4] (one image; the oracle's forward takes seconds)
+    against the fp32 oracle: generator activations within the north-star bar."""
+    from hip_util import t, n, rel, precision, load_recipe
+    from dtgan_amd import networks as Nw
+    from oracle import recipe
+    S, nc, nb = {"cfg2": (128, 3, 6), "cfg3": (256, 3, 9), "cfg5": (512, 1, 9)}[cfg]
+    A, B, z = recipe.inputs(80, 1, nc, nc, S, 16)
+    ref_A, ref_B = _oracle_generators(cfg, S, nc, nb)
+    with precision(prec):
+        gB = load_recipe(Nw.define_G(nc, nc, 32, gpu_ids=[0], n_blocks=nb), "netG_B_A", 4, "init")
+        gA = load_recipe(Nw.define_stochastic_G(16, nc, nc, 32, gpu_ids=[0], n_blocks=nb), "netG_A_B", 4, "init")
+        with torch.no_grad():
+            fake_A, fake_B = n(gB(t(B))), n(gA(t(A), t(z)))
+    tol = 1e-4 if prec == "f32" else 1e-3
+    assert rel(fake_A, ref_A) < tol, rel(fake_A, ref_A)
+    assert rel(fake_B, ref_B) < tol, rel(fake_B, ref_B)

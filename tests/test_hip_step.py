@@ -51,13 +51,35 @@ def test_train_instance_matches_reference_golden(name, prec):
         _check_steps(name, prec)
 
 
+# cycle reconstructions rec_A / rec_B (model.py:467, 493) chain two generators: (step 0, later steps) per precision and
+# fixture flavour.  'init' = the reference's own initialisation statistics (what training starts from): the north-star
+# 1e-3 bar holds in bf16x3.  'rich' = O(1) InstanceNorm gains everywhere, deliberately ill-conditioned
+# (tools/conditioning_probe.py: the EXACT-fp32 path itself moves rec_* by 4e-4..9e-4 under a 4e-6 input perturbation):
+# bf16x3 lands at 0.8-1.4e-3 there, allowed 3e-3.  After an Adam update the fp32 oracle itself is 1.9e-2 from the
+# reference on 'rich' (tests/test_oracle_golden.py).
+REC_TOL = {("f32", "init"): (2e-4, 5e-3), ("f32", "rich"): (3e-4, 4e-2),
+           ("bf16x3", "init"): (1e-3, 2e-2), ("bf16x3", "rich"): (3e-3, 6e-2)}
+
+
 def _check_steps(name, prec):
     from hip_util import t, n, rel
+    from dtgan_amd import model as M
     arr, meta = load(name)
     m = build_model(meta)
+    orig_reparam = M.gauss_reparametrize
     for st in range(meta["steps"]):
         A, B, z = (t(arr["s%d/%s" % (st, k)]) for k in ("real_A", "real_B", "prior_z_B"))
-        losses, visuals, gnorms = m.train_instance(A, B, z)
+        if "s%d/eps" % st in arr:   # --stoch_enc fixture: the reference ran with this reparametrisation noise injected
+            eps = t(arr["s%d/eps" % st])
+
+            def fixed_reparametrize(mu, logvar, n_sample=1, eps=eps):  # model.py:15-22 with the draw replaced by `eps`
+                zz = eps.mul(logvar.mul(0.5).exp()[:, None, :]).add(mu[:, None, :]).clamp(-4.0, 4.0)
+                return zz.view(zz.size(0) * zz.size(1), zz.size(2), 1, 1)
+            M.gauss_reparametrize = fixed_reparametrize
+        try:
+            losses, visuals, gnorms = m.train_instance(A, B, z)
+        finally:
+            M.gauss_reparametrize = orig_reparam
         assert list(losses.keys()) == meta["loss_keys"]
         assert list(gnorms.keys()) == meta["gnorm_keys"]
         lt, gt, vt = STEP_TOL[prec][0 if st == 0 else 1]
@@ -67,8 +89,11 @@ def _check_steps(name, prec):
         assert np.allclose(gg, gr, rtol=gt, atol=1e-6), (st, dict(zip(meta["gnorm_keys"], zip(gg, gr))))
         assert rel(n(visuals["fake_B"]), arr["s%d/fake_B" % st]) < vt
         assert rel(n(visuals["fake_A"]), arr["s%d/fake_A" % st]) < vt
-        for k in ("real_A", "rec_A", "real_B", "rec_B"):
-            assert visuals[k].shape == visuals["real_A" if k.endswith("A") else "real_B"].shape
+        rt = REC_TOL[(prec, meta["flavour"])][0 if st == 0 else 1]
+        for k in ("rec_A", "rec_B"):
+            assert rel(n(visuals[k]), arr["s%d/%s" % (st, k)]) < rt, (k, st, rel(n(visuals[k]), arr["s%d/%s" % (st, k)]))
+        for k in ("real_A", "real_B"):
+            assert np.array_equal(n(visuals[k]), arr["s%d/%s" % (st, k)])
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16x3"])
@@ -115,8 +140,9 @@ def _check_6_blocks(prec):
 @pytest.mark.parametrize("prec", ["f32", "bf16x3"])
 def test_stoch_enc_branch_against_oracle(prec, monkeypatch):
     """--stoch_enc (model.py:414-419, 501-502, 519-522): post_z is a clamped reparametrised sample, the KLD term joins
-    loss_G and the latent GAN terms drop out.  The reference draws its N(0,1) noise internally, so this branch is pinned
-    by the oracle only: the same eps is injected into both sides."""
+    loss_G and the latent GAN terms drop out.  Oracle-side variant at batch 8 with the same eps injected into both sides;
+    the reference-derived pin of this branch is the golden `step_aug_small_s64_stoch_enc` (tools/make_goldens.py patches the
+    normal_() draw inside the reference's gauss_reparametrize), run by test_train_instance_matches_reference_golden."""
     from hip_util import t, n, rel, load_recipe, precision
     from dtgan_amd import model as M
     from oracle import recipe, step

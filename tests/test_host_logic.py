@@ -111,6 +111,56 @@ assert torch.allclose(f.g, torch.full_like(f.g, (1 + ws) / 2.0)), f.g[:4]
 from collections import OrderedDict
 v = D.average_scalars(OrderedDict(a=float(r), lo=float(r), hi=float(r)), min_keys=["lo"], max_keys=["hi"])
 assert abs(v["a"] - (ws - 1) / 2.0) < 1e-12 and v["lo"] == 0.0 and v["hi"] == ws - 1
+
+# ---- PhaseExchange: all-reduce launched from the post-accumulate-grad hooks, in the armed order, overlapped with backward
+class Bucket(object):
+    def __init__(self, shapes):
+        n = sum(int(torch.tensor(s).prod()) for s in shapes)
+        self.g = torch.zeros(n + D.SCALAR_TAIL)
+        self.gtail = self.g[n:]
+        self.params, o = [], 0
+        for s in shapes:
+            p = torch.nn.Parameter(torch.ones(s)); k = p.numel()
+            p.grad = self.g[o:o + k].view(s); o += k
+            self.params.append(p)
+        D.hook_params(self)
+b1, b2 = Bucket([(3,), (2, 2)]), Bucket([(5,)])
+ex = D.PhaseExchange("test")
+trace = []
+orig_launch = ex._launch
+ex._launch = lambda i: (trace.append((i, [int(p.grad.abs().sum() > 0) for b in (b1, b2) for p in b.params])), orig_launch(i))[1]
+def step(use_second_param=True):
+    for b in (b1, b2):
+        b.g.zero_()
+    x = torch.full((1,), float(r + 1))
+    # build order b1 then b2 -> backward completes b2 first; armed order says so
+    y1 = (b1.params[0] * x).sum() + ((b1.params[1] * x).sum() if use_second_param else 0.0)
+    y2 = (b2.params[0] * x).sum() * 2.0
+    D.write_scalar_tail(b1.gtail, [torch.tensor(float(r)), torch.tensor(10.0 * r)], [torch.tensor(float(r)), torch.tensor(-float(r))])
+    ex.arm([b2, b1])
+    try:
+        (y1 + y2).backward()
+    finally:
+        ex.flush()
+    ex.wait(b1); ex.wait(b2)
+del trace[:]; step()
+assert [t[0] for t in trace] == [0, 1] and all(sum(t[1]) == 3 for t in trace), trace     # first step: nothing known -> flush launches
+mean_x = (1 + ws) / 2.0
+assert torch.allclose(b1.g[:7], torch.full((7,), mean_x)) and torch.allclose(b2.g[:5], torch.full((5,), 2 * mean_x))
+sums, mm = D.read_scalar_tail(b1.gtail, 2, 2)
+assert torch.allclose(sums, torch.tensor([(ws - 1) / 2.0, 10.0 * (ws - 1) / 2.0]))
+assert float(mm[:, 0].max()) == ws - 1 and float(mm[:, 1].min()) == -(ws - 1) and mm.shape == (ws, 2)
+del trace[:]; step()
+# second step: bucket b2 (index 0 in the armed order) is launched as soon as its one gradient is written, i.e. BEFORE b1's
+assert trace[0][0] == 0 and trace[0][1][:2] == [0, 0], trace
+assert torch.allclose(b1.g[:7], torch.full((7,), mean_x)) and torch.allclose(b2.g[:5], torch.full((5,), 2 * mean_x))
+# a graph that changes between steps (one gradient fewer, then one more) must not reduce partial sums silently
+step(use_second_param=False)
+try:
+    step(use_second_param=True)
+    raise SystemExit("late gradient not detected")
+except RuntimeError as e:
+    assert "arrived after" in str(e)
 print("rank", r, "ok")
 """
 
@@ -124,3 +174,21 @@ def test_two_rank_gradient_exchange_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without RANK in the environment (how the driver runs it) starts two fresh ranks itself,
+    relays rank 0's line and reports failure of any rank.  --dry-run: rendezvous + one all-reduce over gloo, no GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout                                  # ONE JSON line on stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["dry_run"] is True
+    # a rank that fails (no GPU here) makes the launcher exit non-zero instead of hanging in a collective
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    if not torch.cuda.is_available():
+        assert bad.returncode != 0 and "rank exit codes" in bad.stderr

@@ -87,7 +87,10 @@ def test_step_matches_reference(name):
     pre = {n: {k: p.v.copy() for k, p in net.params.items()} for n, net in m.nets().items()}
     for st in range(meta["steps"]):
         A, B, z = arr["s%d/real_A" % st], arr["s%d/real_B" % st], arr["s%d/prior_z_B" % st]
-        losses, visuals, gnorms = m.train_instance(A, B, z)
+        if "s%d/eps" % st in arr:   # --stoch_enc fixture: the reparametrisation noise the reference was given
+            losses, visuals, gnorms = m.train_instance(A, B, z, eps=arr["s%d/eps" % st])
+        else:
+            losses, visuals, gnorms = m.train_instance(A, B, z)
         assert list(losses.keys()) == meta["loss_keys"]
         assert list(gnorms.keys()) == meta["gnorm_keys"]
         got = np.array(list(losses.values()))
@@ -102,6 +105,11 @@ def test_step_matches_reference(name):
         assert np.allclose(gg, gr, rtol=gt, atol=1e-6), (st, dict(zip(meta["gnorm_keys"], zip(gg, gr))))
         assert rel_err(visuals["fake_B"], arr["s%d/fake_B" % st]) < (1e-4 if st == 0 else 5e-3)
         assert rel_err(visuals["fake_A"], arr["s%d/fake_A" % st]) < (1e-4 if st == 0 else 5e-3)
+        # the cycle reconstructions (model.py:467, 493) chain two generators (and the encoder for rec_B)
+        # (measured: <= 3.7e-5 at step 0 in fp32 AND fp64; after the first Adam update the 'rich' fixtures reach 1.9e-2
+        # in fp32 and 1.3e-2 in fp64 — the noise amplification described below, passed through two high-gain generators)
+        assert rel_err(visuals["rec_A"], arr["s%d/rec_A" % st]) < (1e-4 if st == 0 else 3e-2)
+        assert rel_err(visuals["rec_B"], arr["s%d/rec_B" % st]) < (1e-4 if st == 0 else 3e-2)
         # gradient digests (abs-sum, L2 per tensor) and post-step Adam-update digests.
         # Adam's update is g/(|g|+1e-8): where |g| is at fp32-noise level (conv biases feeding a
         # mean-removing norm have analytically zero gradient; 'init'-flavour inner-block tensors see
@@ -112,11 +120,14 @@ def test_step_matches_reference(name):
         # (noise-driven +-lr moves) and are covered by the losses / norms / images above.
         bad = []
         for n, net in (m.nets().items() if st == 0 else []):
-            gmax = max(float(np.max(np.abs(p.g))) for p in net.params.values() if p.g is not None)
+            # (--stoch_enc: D_z_B receives no gradient at all in the D phase, model.py:438-439)
+            gmax = max([float(np.max(np.abs(p.g))) for p in net.params.values() if p.g is not None] + [0.0])
             for k, p in net.params.items():
                 g = p.g if p.g is not None else np.zeros_like(p.v)
                 dg, rg = digest(g), arr["s%d/grad/%s/%s" % (st, n, k)]
-                floor = 3e-6 * gmax * np.array([g.size, np.sqrt(g.size)])
+                # noise floor: analytically-zero gradients (conv bias in front of a mean-removing norm) hold pure summation
+                # noise on both sides; the reference's reaches 1e-4 of the net-wide max per entry at N=4 (stoch_enc fixture)
+                floor = 3e-5 * gmax * np.array([g.size, np.sqrt(g.size)])
                 # 3e-3: at full width / 'init' flavour the REFERENCE's own fp32 gradients sit up to
                 # ~1.5e-3 from the fp64 oracle (L1-sign / ReLU-mask flips; e.g. netG_B_A model.19.bias:
                 # ref 7.1622, fp32 oracle 7.1742, fp64 oracle 7.1730), so fp32-vs-fp32 cannot be tighter.

@@ -169,6 +169,7 @@ def digest(a):
 class Recorder(object):
     def __init__(self):
         self.gan, self.l1, self.gn, self.predA, self.predB, self.enc = [], [], [], [], [], []
+        self.gAB, self.gBA, self.cycz = [], [], []   # generator outputs in call order; -mean log-prob (stoch_enc Cyc_z_B)
 
 
 def run_ref_step(m, rec, A, B, z, aug):
@@ -181,12 +182,26 @@ def run_ref_step(m, rec, A, B, z, aug):
         pass
 
 
-def step_case(name, aug, opt_kw, N, S, steps=2, seed=0, flavour="rich"):
+def step_case(name, aug, opt_kw, N, S, steps=2, seed=0, flavour="rich", eps_seed=None):
+    """eps_seed: for --stoch_enc cases — the N(0,1) draw inside the reference's gauss_reparametrize
+    (`std.data.new(N, 1, nl).normal_()`, model.py:19) is replaced by a fixed, recorded eps (torch.Tensor.normal_ is
+    patched for tensors of exactly that shape while the step runs), so the branch becomes a pure function of the inputs."""
     opt = ref_opt(**opt_kw)
     rec = Recorder()
     # recorders around the reference's own loss / clip functions
     orig_l1, orig_clip = rmodel.F.l1_loss, torch.nn.utils.clip_grad_norm
     orig_crit = rmodel.criterion_GAN
+    orig_lpg, orig_normal = rmodel.log_prob_gaussian, torch.Tensor.normal_
+    cur_eps = [None]
+
+    def lpg(z, mu, lv):
+        v = orig_lpg(z, mu, lv); rec.cycz.append(float(-1.0 * v.mean(1).mean(0))); return v
+
+    def normal_(self, *a, **kw):
+        e = cur_eps[0]
+        if e is not None and tuple(self.shape) == e.shape:
+            self.copy_(torch.from_numpy(e)); return self
+        return orig_normal(self, *a, **kw)
 
     def l1(a, b, *k, **kw):
         v = orig_l1(a, b, *k, **kw); rec.l1.append(float(v)); return v
@@ -198,10 +213,8 @@ def step_case(name, aug, opt_kw, N, S, steps=2, seed=0, flavour="rich"):
         v = orig_clip(params, max_norm, *k, **kw); rec.gn.append(float(v)); return v
 
     rmodel.F.l1_loss, rmodel.criterion_GAN, torch.nn.utils.clip_grad_norm = l1, crit, clip
-    try:
-        m = rmodel.AugmentedCycleGAN(opt, testing=True) if aug else rmodel.StochCycleGAN(opt, testing=True)
-    finally:
-        pass
+    rmodel.log_prob_gaussian = lpg
+    m = rmodel.AugmentedCycleGAN(opt, testing=True) if aug else rmodel.StochCycleGAN(opt, testing=True)
     names = ["netG_A_B", "netG_B_A", "netD_A", "netD_B"] + (["netE_B", "netD_z_B"] if aug else [])
     for n in names:
         load_recipe(getattr(m, n), n, seed, flavour)
@@ -214,6 +227,8 @@ def step_case(name, aug, opt_kw, N, S, steps=2, seed=0, flavour="rich"):
             o = f(*a); sink.append(fn(o)); return o
         net.forward = g
 
+    wrap_forward(m.netG_A_B, rec.gAB, lambda o: o.detach().numpy().copy())   # call 0 = fake_B, call 1 = rec_B
+    wrap_forward(m.netG_B_A, rec.gBA, lambda o: o.detach().numpy().copy())   # call 0 = fake_A, call 1 = rec_A
     wrap_forward(m.netD_A, rec.predA, lambda o: float(o.mean()))
     wrap_forward(m.netD_B, rec.predB, lambda o: float(o.mean()))
     if aug:
@@ -224,21 +239,34 @@ def step_case(name, aug, opt_kw, N, S, steps=2, seed=0, flavour="rich"):
         for st in range(steps):
             A, B, z = recipe.inputs(seed + st, N, opt.input_nc, opt.output_nc, S, opt.nlatent)
             arr["s%d/real_A" % st], arr["s%d/real_B" % st], arr["s%d/prior_z_B" % st] = A, B, z
-            # visuals: recompute pre-step with the same weights (harness-side, forward only)
-            with torch.no_grad():
-                tA, tB, tz = torch.from_numpy(A), torch.from_numpy(B), torch.from_numpy(z)
-                fake_B = m.netG_A_B.model(tA, tz); fake_A = m.netG_B_A.model(tB)
-                arr["s%d/fake_B" % st], arr["s%d/fake_A" % st] = fake_B.numpy().copy(), fake_A.numpy().copy()
-            for lst in (rec.gan, rec.l1, rec.gn, rec.predA, rec.predB, rec.enc):
+            for lst in (rec.gan, rec.l1, rec.gn, rec.predA, rec.predB, rec.enc, rec.gAB, rec.gBA, rec.cycz):
                 del lst[:]
-            run_ref_step(m, rec, A, B, z, aug)
+            if eps_seed is not None:
+                cur_eps[0] = np.random.RandomState(eps_seed + st).normal(0, 1, (N, 1, opt.nlatent)).astype(np.float32)
+                arr["s%d/eps" % st] = cur_eps[0]
+                torch.Tensor.normal_ = normal_
+            try:
+                run_ref_step(m, rec, A, B, z, aug)
+            finally:
+                torch.Tensor.normal_ = orig_normal
+            # visuals (model.py:524-525 / 199-200): the tensors the reference's own forward calls returned in this step
+            arr["s%d/fake_B" % st], arr["s%d/rec_B" % st] = rec.gAB[0], rec.gAB[1]
+            arr["s%d/fake_A" % st], arr["s%d/rec_A" % st] = rec.gBA[0], rec.gBA[1]
             if aug:
                 # call order (model.py:423-464): D_A f/t, D_B f/t, D_z post/prior, G_A, G_B, G_z
                 g = rec.gan
-                mu = rec.enc[0][0]
+                mu, lv = rec.enc[0]
+                if opt.stoch_enc:   # l1 calls: Cyc_A, Cyc_B; Cyc_z_B is the Gaussian NLL (model.py:478-484)
+                    cyc_z, cyc_B = rec.cycz[0], rec.l1[1]
+                    mu64, lv64 = mu.astype(np.float64), lv.astype(np.float64)
+                    kld = float((-0.5 * (lv64 + 1.0 - mu64 ** 2 - np.exp(lv64)).sum(1)).mean())   # model.py:45-53
+                else:               # l1 calls: Cyc_A, Cyc_z_B, Cyc_B; logvar is zeroed (model.py:419)
+                    cyc_z, cyc_B = rec.l1[1], rec.l1[2]
+                    lv = lv * 0.0
+                    kld = float((0.5 * (mu.astype(np.float64) ** 2).sum(1)).mean())
                 losses = OrderedDict([("D_A", 0.5 * (g[0] + g[1])), ("G_A", g[6]), ("Cyc_A", rec.l1[0]),
-                                      ("Cyc_z_B", rec.l1[1]), ("KLD_z_B", float((0.5 * (mu.astype(np.float64) ** 2).sum(1)).mean())),
-                                      ("D_B", 0.5 * (g[2] + g[3])), ("G_B", g[7]), ("Cyc_B", rec.l1[2]),
+                                      ("Cyc_z_B", cyc_z), ("KLD_z_B", kld),
+                                      ("D_B", 0.5 * (g[2] + g[3])), ("G_B", g[7]), ("Cyc_B", cyc_B),
                                       ("D_z_B", 0.5 * (g[4] + g[5])),
                                       ("P_t_A", rec.predA[1]), ("P_f_A", rec.predA[2]),
                                       ("P_t_B", rec.predB[1]), ("P_f_B", rec.predB[2])])
@@ -246,8 +274,10 @@ def step_case(name, aug, opt_kw, N, S, steps=2, seed=0, flavour="rich"):
                 gn = OrderedDict([("gnorm_G_A_B", rec.gn[3]), ("gnorm_G_B_A", rec.gn[4]), ("gnorm_E_B", rec.gn[5]),
                                   ("gnorm_D_B", rec.gn[1]), ("gnorm_D_z_B", rec.gn[2]), ("gnorm_D_A", rec.gn[0]),
                                   ("mu_min", float(mu.min())), ("mu_max", float(mu.max())),
-                                  ("logvar_min", 0.0), ("logvar_max", 0.0)])
+                                  ("logvar_min", float(lv.min())), ("logvar_max", float(lv.max()))])
                 arr["s%d/mu_z_realB" % st] = mu
+                if opt.stoch_enc:
+                    arr["s%d/logvar_z_realB" % st] = lv
             else:
                 g = rec.gan  # D_A f/t, D_B f/t, G_A, G_B (model.py:139-171)
                 losses = OrderedDict([("D_A", 0.5 * (g[0] + g[1])), ("G_A", g[4]), ("Cyc_A", rec.l1[0]),
@@ -274,6 +304,7 @@ def step_case(name, aug, opt_kw, N, S, steps=2, seed=0, flavour="rich"):
                     arr["final/buf/%s/%s" % (n, k)] = b.detach().numpy().copy()
     finally:
         rmodel.F.l1_loss, rmodel.criterion_GAN, torch.nn.utils.clip_grad_norm = orig_l1, orig_crit, orig_clip
+        rmodel.log_prob_gaussian = orig_lpg
     save(name, arr, kind="step", aug=bool(aug), seed=seed, flavour=flavour, N=N, S=S, steps=steps,
          opt={k: v for k, v in opt_kw.items()}, loss_keys=loss_keys, gnorm_keys=gn_keys)
 
@@ -285,6 +316,9 @@ def make_step_goldens():
     step_case("step_stoch_small_s64", False, dict(small, input_nc=3, output_nc=1), N=2, S=64, steps=2, flavour="rich")
     # BASELINE config 1 at full reference widths (64x64x1, batch 4, reference-faithful 3 blocks)
     step_case("step_aug_cfg1_full", True, dict(input_nc=1, output_nc=1), N=4, S=64, steps=1, flavour="init")
+    # --stoch_enc branch (model.py:15-22, 414-419, 478-484, 501-502) with the reparametrisation noise injected
+    step_case("step_aug_small_s64_stoch_enc", True, dict(small, stoch_enc=True), N=4, S=64, steps=2, flavour="init",
+              eps_seed=77)
 
 
 if __name__ == "__main__":
