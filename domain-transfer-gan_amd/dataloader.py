@@ -52,7 +52,9 @@ def split_train_dev(trainA, trainB, shuffle=True):
         random.shuffle(idx)
         trainA, trainB = trainA[idx], trainB[idx]
         random.setstate(state)
-    n = min(DEV_SIZE, len(trainA) // 2)
+    # the reference always takes DEV_SIZE samples (dataloader.py:53-57) and is left without training data below that;
+    # only there (tiny synthetic sets) the split falls back to half / half
+    n = DEV_SIZE if len(trainA) > DEV_SIZE else len(trainA) // 2
     return trainA[n:], trainB[n:], trainA[:n], trainB[:n]
 
 

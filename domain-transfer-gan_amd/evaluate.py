@@ -38,18 +38,29 @@ class _frozen(object):
             p.requires_grad_(True)
 
 
-def variational_ubo(model, real_A, real_B, steps, logvar_B=None, verbose=False):
+def variational_ubo(model, real_A, real_B, steps, logvar_B=None, verbose=False, dequant=None, eps_seq=None, trace=None):
+    """dequant / eps_seq / trace are test hooks (not in the reference): the dequantisation noise, the reparametrisation
+    noise of iterate i (eps_seq[i], shape (N, 1, nlatent)) and a list receiving (ubo, kld, bpp) of every iterate — the
+    golden `eval_aug_small_s64` was produced by the reference's model with exactly these draws."""
     with _frozen(model.netG_A_B):
-        return _variational_ubo(model, real_A, real_B, steps, logvar_B, verbose)
+        return _variational_ubo(model, real_A, real_B, steps, logvar_B, verbose, dequant, eps_seq, trace)
 
 
-def _variational_ubo(model, real_A, real_B, steps, logvar_B=None, verbose=False):
+def _reparametrize(mu, logvar, eps):
+    if eps is None:
+        return gauss_reparametrize(mu, logvar)
+    z = eps.mul(logvar.mul(0.5).exp()[:, None, :]).add(mu[:, None, :]).clamp(-4., 4.)      # model.py:15-22 with a given eps
+    return z.view(z.size(0) * z.size(1), z.size(2), 1, 1)
+
+
+def _variational_ubo(model, real_A, real_B, steps, logvar_B=None, verbose=False, dequant=None, eps_seq=None, trace=None):
     """evaluate.py:39-148 without the PNG dumps.  Returns (ubo, kld, bpp) of the LAST evaluated iterate."""
     size = real_A.size()
     nl = model.opt.nlatent
     npx = real_B[0].numel()
     dev = real_A.device
-    dequant = torch.zeros_like(real_B).uniform_(0, 1. / 127.5)
+    if dequant is None:
+        dequant = torch.zeros_like(real_B).uniform_(0, 1. / 127.5)
     mu = torch.zeros(size[0], nl, device=dev, requires_grad=True)
     logvar = torch.full((size[0], nl), math.log(0.01), device=dev, requires_grad=True)
     if logvar_B is None:
@@ -64,13 +75,15 @@ def _variational_ubo(model, real_A, real_B, steps, logvar_B=None, verbose=False)
     real_B = real_B + dequant
     ubo_val = kld_val = bpp = float('nan')
     for i in range(steps):
-        z_B = gauss_reparametrize(mu, logvar)
+        z_B = _reparametrize(mu, logvar, None if eps_seq is None else eps_seq[i])
         fake_B = model.predict_B(real_A, z_B)
         log_prob = log_prob_laplace(real_B, fake_B, logvar_B).view(size[0], -1).sum(1)
         kld = kld_std_guss(mu, logvar)
         ubo = (-log_prob + kld) + npx * math.log(127.5)
         ubo_val, kld_val = float(ubo.detach().mean(0)), float(kld.detach().mean(0))
         bpp = ubo_val / (npx * math.log(2.))
+        if trace is not None:
+            trace.append((ubo_val, kld_val, bpp))
         if verbose:
             print('[%d] UBO: %.4f, KLD: %.4f, BPP: %.4f' % (i, ubo_val, kld_val, bpp))
         opt.zero_grad()

@@ -329,6 +329,29 @@ def run_sequence(mods, x, C, z=None, res=None):
     return x, C
 
 
+# padding of the residual blocks' 3x3 convolutions: 'reflect' = a ReflectionPad2d(1) module in front of an unpadded conv,
+# 'zero' = the conv's own padding=1
+_PADDING = {"reflect": (lambda: [nn.ReflectionPad2d(1)], 0), "zero": (lambda: [], 1)}
+
+
+def _padding(padding_type):
+    if padding_type not in _PADDING:
+        raise NotImplementedError('padding [%s] is not implemented' % padding_type)
+    return _PADDING[padding_type]
+
+
+def _pad_front(padding_type):
+    return _padding(padding_type)[0]()
+
+
+def _conv_pad(padding_type):
+    return _padding(padding_type)[1]
+
+
+def _dropout(use_dropout):
+    return [nn.Dropout(0.5)] if use_dropout else []
+
+
 ######################################################################
 # CINResnetBlock  (modules.py:139-188)
 ######################################################################
@@ -344,29 +367,12 @@ class CINResnetBlock(TwoInputModule):
             self.add_module(str(idx), module)
 
     def build_conv_block(self, x_dim, z_dim, padding_type, norm_layer, use_dropout, use_bias):
-        conv_block = []
-        p = 0
-        if padding_type == 'reflect':
-            conv_block += [nn.ReflectionPad2d(1)]
-        elif padding_type == 'zero':
-            p = 1
-        else:
-            raise NotImplementedError('padding [%s] is not implemented' % padding_type)
-        conv_block += [MergeModule(Conv2d(x_dim, x_dim, kernel_size=3, padding=p, bias=use_bias),
-                                   norm_layer(x_dim, z_dim)),
-                       nn.ReLU(True)]
-        if use_dropout:
-            conv_block += [nn.Dropout(0.5)]
-        p = 0
-        if padding_type == 'reflect':
-            conv_block += [nn.ReflectionPad2d(1)]
-        elif padding_type == 'zero':
-            p = 1
-        else:
-            raise NotImplementedError('padding [%s] is not implemented' % padding_type)
-        conv_block += [Conv2d(x_dim, x_dim, kernel_size=3, padding=p, bias=use_bias),
-                       InstanceNorm2d(x_dim, affine=True)]
-        return TwoInputSequential(*conv_block)
+        # stage 1 normalises with the latent-conditioned norm (MergeModule threads z to it), stage 2 with a plain
+        # InstanceNorm; module ORDER is the checkpoint schema (state_dict keys conv_block.1.module1..., conv_block.4/5)
+        conv = lambda: Conv2d(x_dim, x_dim, kernel_size=3, padding=_conv_pad(padding_type), bias=use_bias)
+        stages = [[MergeModule(conv(), norm_layer(x_dim, z_dim)), nn.ReLU(True)] + _dropout(use_dropout),
+                  [conv(), InstanceNorm2d(x_dim, affine=True)]]
+        return TwoInputSequential(*[m for st in stages for m in _pad_front(padding_type) + st])
 
     def forward_nhwc(self, x, z):
         y, _ = run_sequence(list(self.conv_block._modules.values()), x, None, z, res=x)
@@ -387,28 +393,11 @@ class ResnetBlock(nn.Module):
         self.relu = nn.ReLU(True)
 
     def build_conv_block(self, dim, padding_type, norm_layer, use_dropout, use_bias):
-        conv_block = []
-        p = 0
-        if padding_type == 'reflect':
-            conv_block += [nn.ReflectionPad2d(1)]
-        elif padding_type == 'zero':
-            p = 1
-        else:
-            raise NotImplementedError('padding [%s] is not implemented' % padding_type)
-        conv_block += [Conv2d(dim, dim, kernel_size=3, padding=p, bias=use_bias)]
-        conv_block += [nn.ReLU(True)]
-        if use_dropout:
-            conv_block += [nn.Dropout(0.5)]
-        p = 0
-        if padding_type == 'reflect':
-            conv_block += [nn.ReflectionPad2d(1)]
-        elif padding_type == 'zero':
-            p = 1
-        else:
-            raise NotImplementedError('padding [%s] is not implemented' % padding_type)
-        conv_block += [Conv2d(dim, dim, kernel_size=3, padding=p, bias=use_bias)]
-        conv_block += [norm_layer(dim)]
-        return Sequential(*conv_block)
+        # two 3x3 stages; only the SECOND is normalised (no norm after the first conv: modules.py:211-215)
+        conv = lambda: Conv2d(dim, dim, kernel_size=3, padding=_conv_pad(padding_type), bias=use_bias)
+        stages = [[conv(), nn.ReLU(True)] + _dropout(use_dropout),
+                  [conv(), norm_layer(dim)]]
+        return Sequential(*[m for st in stages for m in _pad_front(padding_type) + st])
 
     def forward_nhwc(self, x, z=None):
         y, _ = run_sequence(list(self.conv_block._modules.values()), x, None, None, res=x)

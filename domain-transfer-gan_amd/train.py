@@ -157,7 +157,8 @@ class Trainer(object):
             self.model = StochCycleGAN(o, ignore_noise=(o.model == 'cycle_gan'))
         else:
             raise NotImplementedError('Specified model is not implemented.')
-        self.log("model [%s] was created" % self.model.__class__.__name__)
+        self.log("model [%s] was created (conv arithmetic: %s, %d rank%s)"
+                 % (self.model.__class__.__name__, ops.get_precision(), self.ws, "" if self.ws == 1 else "s"))
         if o.continue_train:
             chk = os.path.join(o.expr_dir, o.which_epoch)
             self.model.load(chk)

@@ -65,6 +65,28 @@ def test_data_pipeline_and_iterators():
     assert not np.array_equal(dA[:, 0], np.arange(200))
 
 
+def test_data_pipeline_matches_reference_fixture(tmp_path):
+    """tests/golden/data_pipeline.npz was produced by the reference's own dataloader.py (executed from its text under
+    Python 3, tools/make_goldens.py data_case): load_numpy_data on raw npz files with a NaN, a constant plane and an all-zero
+    sample (dataloader.py:13-59), and the two iterators (dataloader.py:61-156) under a fixed numpy seed."""
+    from golden_util import load
+    arr, _ = load("data_pipeline")
+    root = str(tmp_path)
+    for k in ("trainA", "trainB", "testA", "testB"):
+        np.savez(os.path.join(root, k + ".npz"), data=arr["raw/" + k])
+    out = DL.load_numpy_data(root, shuffle=False, grid_size=None)
+    for k, v in zip(("trainA", "trainB", "devA", "devB", "testA", "testB"), out):
+        ref = arr["out/" + k]
+        assert v.shape == ref.shape and v.dtype == ref.dtype, k
+        assert np.array_equal(v, ref), (k, np.abs(v - ref).max())
+    A = np.arange(10, dtype=np.float32).reshape(10, 1, 1, 1)
+    np.random.seed(11)
+    un = DL.UnalignedIterator(A, -A, batch_size=4)
+    got = [np.stack([b["A"].numpy().ravel(), b["B"].numpy().ravel()]) for _ in range(2) for b in un]
+    assert np.array_equal(np.stack(got), arr["unaligned_batches"])
+    assert [b["A"].shape[0] for b in DL.AlignedIterator(A, -A, batch_size=4)] == list(arr["aligned_sizes"])
+
+
 def test_png_writer(tmp_path):
     from dtgan_amd.train import save_image_grid
     p = str(tmp_path / "g.png")

@@ -128,3 +128,91 @@ def test_stoch_cyclegan_ignore_noise_and_aliases():
     m3.set_input({"A": t(recipe.inputs(7, 3, 3, 3, 64, 4)[0]), "B": t(recipe.inputs(7, 3, 3, 3, 64, 4)[1])})
     out = m3.optimize_parameters()
     assert len(out) == 3 and "G_A" in out[0]
+
+
+def _oracle_twin(seed=0, flavour="rich", **kw):
+    from oracle import recipe, step
+    d = dict(input_nc=3, output_nc=3, ngf=8, nef=8, ndf=8, nlatent=4, n_blocks=3)
+    d.update(kw)
+    o = step.AugStep(step.Opt(**d))
+    o.load({k: recipe.values_for(net.shapes, k, seed, flavour) for k, net in o.nets().items()})
+    return o
+
+
+def test_public_discriminate_and_criterion_gan_match_oracle():
+    """model.py:327-334 `discriminate(net, crit, fake, real)` and model.py:56-72 `criterion_GAN` on PUBLIC (NCHW) tensors —
+    the form evaluate.py / a user script calls them in (the step itself uses the fused NHWC path)."""
+    from hip_util import t, n, rel
+    from dtgan_amd import model as M
+    from oracle import recipe, step
+    from oracle.tape import T
+    m, o = _model(), _oracle_twin()
+    A, B, z = recipe.inputs(12, 3, 3, 3, 64, 4)
+    for net, onet, fake, real in ((m.netD_A, o.netD_A, B, A), (m.netD_B, o.netD_B, A, B)):
+        lf, lt, pf, pt = M.discriminate(net, m.criterionGAN, t(fake), t(real))
+        olf, olt, opf, opt_ = step.discriminate(onet, T(fake), T(real))
+        assert pf.shape == opf.v.shape and rel(n(pf), opf.v) < 1e-3 and rel(n(pt), opt_.v) < 1e-3
+        assert abs(float(lf) - float(olf.v)) < 1e-3 * abs(float(olf.v)) and abs(float(lt) - float(olt.v)) < 1e-3 * abs(float(olt.v))
+    # latent discriminator: (N, nl, 1, 1) input, (N, 1) prediction
+    lf, lt, pf, pt = M.discriminate(m.netD_z_B, m.criterionGAN, t(z), t(z[::-1].copy()))
+    olf, olt, opf, opt_ = step.discriminate(o.netD_z_B, T(z), T(z[::-1].copy()))
+    assert pf.shape == (3, 1) and rel(n(pf), opf.v.reshape(3, 1)) < 1e-3
+    assert abs(float(lt) - float(olt.v)) < 1e-3 * abs(float(olt.v))
+    # gradients flow through the public form too
+    x = t(A, grad=True)
+    M.criterion_GAN(m.netD_A(x), True, use_sigmoid=False).backward()
+    assert x.grad is not None and float(x.grad.abs().max()) > 0
+    with pytest.raises(NotImplementedError):
+        M.criterion_GAN(m.netD_A(t(A)), True, use_sigmoid=True)
+
+
+def test_generate_multi_and_inference_multi_values_match_oracle():
+    """model.py:687-733: values, not only shapes — each A repeated `num` times against `num` latent codes
+    (generate_multi), and every A against the posterior codes of every B (inference_multi)."""
+    from hip_util import t, n, rel
+    from oracle import ops as oops, recipe
+    from oracle.tape import T
+    m, o = _model(), _oracle_twin()
+    A, B, z = recipe.inputs(13, 3, 3, 3, 32, 4)
+    num = 2
+    mz = np.random.RandomState(5).normal(0, 1, (3 * num, 4, 1, 1)).astype(np.float32)
+    got = n(m.generate_multi(t(A), t(mz)))
+    ref = o.netG_A_B.forward(T(np.repeat(A, num, axis=0)), T(mz)).v
+    assert got.shape == ref.shape and rel(got, ref) < 1e-3
+    # inference_multi needs S = 64 for the encoder's 1x1 map
+    A, B, z = recipe.inputs(14, 3, 3, 3, 64, 4)
+    got = n(m.inference_multi(t(A), t(B)))
+    fake_A = o.netG_B_A.forward(T(B))
+    mu, _ = o.netE_B.forward(oops.cat_channels(fake_A, T(B)))
+    post = mu.v.reshape(3, 4, 1, 1)
+    ref = o.netG_A_B.forward(T(np.repeat(A, 3, axis=0)), T(np.tile(post, (3, 1, 1, 1)))).v
+    assert got.shape == ref.shape == (9, 3, 64, 64) and rel(got, ref) < 1e-3
+    # generate_cycle: all six images
+    A, B, z = recipe.inputs(15, 3, 3, 3, 64, 4)
+    vis = m.generate_cycle(t(A), t(B), t(z))
+    fB = o.netG_A_B.forward(T(A), T(z)); fA = o.netG_B_A.forward(T(B))
+    mu, _ = o.netE_B.forward(oops.cat_channels(fA, T(B)))
+    rA = o.netG_B_A.forward(fB); rB = o.netG_A_B.forward(fA, T(mu.v.reshape(3, 4, 1, 1)))
+    for k, r in (("fake_B", fB), ("fake_A", fA), ("rec_A", rA), ("rec_B", rB)):
+        assert rel(n(vis[k]), r.v) < (1e-3 if k.startswith("fake") else 3e-3), k     # 'rich' weights: see test_hip_step.REC_TOL
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_evaluation_numbers_match_reference_golden(prec):
+    """evaluate.py:10-19 (eval_mse_A) and evaluate.py:39-148 (variational_ubo: RMSprop on (mu, logvar) THROUGH predict_B):
+    the golden was computed by the reference's own model and model.py helpers with the same noise draws."""
+    from hip_util import t, precision
+    from dtgan_amd import evaluate as E
+    arr, meta = load("eval_aug_small_s64")
+    with precision(prec):
+        m = _model(**meta["opt"])
+        A, B = t(arr["real_A"]), t(arr["real_B"])
+        mse = E.eval_mse_A([{"A": A, "B": B}], m, use_gpu=True)
+        assert abs(mse - float(arr["mse_A"])) < 1e-3 * float(arr["mse_A"])
+        trace = []
+        eps = [t(e) for e in arr["eps"]]
+        ubo, kld, bpp = E.variational_ubo(m, A, B, meta["steps"], dequant=t(arr["dequant"]), eps_seq=eps, trace=trace)
+        ref = arr["trace"]
+        tol = 1e-4 if prec == "f32" else 1e-3      # sums over 12288 pixels of |x - fake_B| / sd: relative on the bound
+        assert np.allclose(np.array(trace), ref, rtol=tol), (trace, ref)
+        assert (ubo, kld, bpp) == trace[-1]

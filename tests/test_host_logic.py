@@ -39,6 +39,23 @@ def test_state_dict_keys_match_reference_fixture():
         assert got == ref[k], k
 
 
+def test_seeded_initialisation_equals_the_reference_tensor_for_tensor():
+    """networks.py:47 `net.apply(weights_init)` + the constructors' own draws, incl. the double visit of every CINResnetBlock
+    convolution (modules.py:145-146): after the same torch.manual_seed the six networks hold the reference's values."""
+    from golden_util import digest
+    arr, meta = load("init_seeded")
+    builders = dict(netG_A_B=lambda: N.define_stochastic_G(16, 3, 3, 32), netG_B_A=lambda: N.define_G(3, 3, 32),
+                    netD_A=lambda: N.define_D_A(3, 32, "basic", "instance"), netD_B=lambda: N.define_D_B(3, 64, "basic", "instance"),
+                    netD_z_B=lambda: N.define_LAT_D(16, 64), netE_B=lambda: N.define_E(16, 6, 32, "batch"))
+    seen = 0
+    for k, mk in builders.items():
+        torch.manual_seed(meta["seed"])
+        for name, v in mk().state_dict().items():
+            assert np.array_equal(digest(v.detach().numpy()), arr["%s/%s" % (k, name)]), (k, name)
+            seen += 1
+    assert seen == len(arr)
+
+
 def test_n_blocks_is_honoured_and_init_follows_reference_distributions():
     g3, g9 = N.define_G(3, 3, 8), N.define_G(3, 3, 8, n_blocks=9)
     assert len(g9.state_dict()) - len(g3.state_dict()) == 6 * 6

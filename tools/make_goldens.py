@@ -372,6 +372,146 @@ def make_key_fixture():
     save("statedict_keys", dict(keys_json=np.frombuffer(json.dumps(keys).encode(), dtype=np.uint8)), kind="keys")
 
 
+def make_init_fixture(seed=1234):
+    """Seed-for-seed initialisation (networks.py:13-21, 47; modules.py:78-81, 145-146): the reference's six networks built
+    on the CPU after torch.manual_seed(seed).  `net.apply(weights_init)` visits the convolutions of every CINResnetBlock
+    TWICE (the block re-registers its children under numeric names), so the draw sequence depends on the exact module tree;
+    the fixture stores a digest of every tensor."""
+    arr = {}
+    builders = dict(netG_A_B=lambda: rnet.define_stochastic_G(16, 3, 3, 32), netG_B_A=lambda: rnet.define_G(3, 3, 32),
+                    netD_A=lambda: rnet.define_D_A(3, 32, "basic", "instance"),
+                    netD_B=lambda: rnet.define_D_B(3, 64, "basic", "instance"),
+                    netD_z_B=lambda: rnet.define_LAT_D(16, 64), netE_B=lambda: rnet.define_E(16, 6, 32, "batch"))
+    for k, mk in builders.items():
+        torch.manual_seed(seed)
+        for name, v in mk().state_dict().items():
+            arr["%s/%s" % (k, name)] = digest(v.detach().numpy())
+    save("init_seeded", arr, kind="init", seed=seed)
+
+
+def eval_case(name, opt_kw, N, S, steps=3, seed=0, flavour="rich"):
+    """Evaluation numbers (evaluate.py:10-19 eval_mse_A, evaluate.py:39-148 variational_ubo).  evaluate.py itself is
+    Python 2 and hard-codes .cuda(), so it cannot be imported here; the harness walks through its algorithm with the
+    reference's OWN model (predict_A / predict_B / predict_enc_params) and model.py helpers (gauss_reparametrize,
+    log_prob_laplace, kld_std_guss) on the CPU, with the two random draws — the dequantisation noise and the
+    reparametrisation noise of every iterate — fixed and recorded."""
+    import math
+    opt = ref_opt(**opt_kw)
+    m = rmodel.AugmentedCycleGAN(opt, testing=True)
+    for n in ["netG_A_B", "netG_B_A", "netD_A", "netD_B", "netE_B", "netD_z_B"]:
+        load_recipe(getattr(m, n), n, seed, flavour)
+    A, B, _ = recipe.inputs(seed + 50, N, opt.input_nc, opt.output_nc, S, opt.nlatent)
+    rs = np.random.RandomState(seed + 51)
+    dequant = rs.uniform(0, 1. / 127.5, B.shape).astype(np.float32)
+    eps = rs.normal(0, 1, (steps + 1, N, 1, opt.nlatent)).astype(np.float32)
+    tA, tB = torch.from_numpy(A), torch.from_numpy(B)
+    mse_A = float(torch.nn.functional.mse_loss(m.predict_A(tB), tA))                    # evaluate.py:17-18
+    orig_normal, cur = torch.Tensor.normal_, [None]
+
+    def normal_(self, *a, **kw):
+        if cur[0] is not None and tuple(self.shape) == cur[0].shape:
+            self.copy_(torch.from_numpy(cur[0])); return self
+        return orig_normal(self, *a, **kw)
+    torch.Tensor.normal_ = normal_
+    try:
+        npx = opt.output_nc * S * S                                                     # 64*64*3 in evaluate.py:104
+        params = m.predict_enc_params(tA, tB)                                           # evaluate.py:56-62
+        mu = params[0].detach().clone().requires_grad_(True)
+        logvar = torch.full((N, opt.nlatent), math.log(0.01)).requires_grad_(True)
+        if len(params) == 2:
+            logvar = params[1].detach().clone().requires_grad_(True)
+        logvar_B = torch.full((1, opt.output_nc, S, S), math.log(0.01))
+        it = torch.optim.RMSprop([mu, logvar], lr=1e-2)                                 # evaluate.py:65
+        rB = tB + torch.from_numpy(dequant)
+        cur[0] = eps[0]
+        z_B = rmodel.gauss_reparametrize(mu, logvar)
+        fake_B = m.predict_B(tA, z_B)
+        trace = []
+        for i in range(steps):                                                          # evaluate.py:93-126
+            log_prob = rmodel.log_prob_laplace(rB, fake_B, logvar_B).view(N, -1).sum(1)
+            kld = rmodel.kld_std_guss(mu, logvar)
+            ubo = (-log_prob + kld) + npx * math.log(127.5)
+            trace.append([float(ubo.mean(0)), float(kld.mean(0)), float(ubo.mean(0)) / (npx * math.log(2.))])
+            it.zero_grad()
+            ubo.mean(0).backward()
+            it.step()
+            cur[0] = eps[i + 1]
+            z_B = rmodel.gauss_reparametrize(mu, logvar)
+            fake_B = m.predict_B(tA, z_B)
+    finally:
+        torch.Tensor.normal_ = orig_normal
+    save(name, dict(real_A=A, real_B=B, dequant=dequant, eps=eps, mse_A=np.array(mse_A), trace=np.array(trace, np.float64),
+                    mu_final=mu.detach().numpy().copy(), logvar_final=logvar.detach().numpy().copy()),
+         kind="eval", seed=seed, flavour=flavour, N=N, S=S, steps=steps, opt=dict(opt_kw))
+
+
+def _py3_source(path):
+    """Read a Python-2 reference file as TEXT and make it executable under Python 3 without changing its arithmetic:
+    print statements -> print(), and the integer division of the iterators' batch counts (`num_samples / batch_size` on
+    ints is floor division in Python 2) -> //.  The transformed text exists only in this process."""
+    import re
+    src = open(path).read()
+    src = re.sub(r'^(\s*)print (.+)$', r'\1print(\2)', src, flags=re.M)
+    src = src.replace("self.num_samples / batch_size", "self.num_samples // batch_size")
+    src = src.replace("self.num_samples / self.batch_size", "self.num_samples // self.batch_size")
+    return src
+
+
+def data_case(name="data_pipeline"):
+    """Data path (dataloader.py:13-59 load_numpy_data, 61-156 Aligned/UnalignedIterator).  The reference file is Python 2
+    and imports skimage / torchvision (absent): it is executed from its text through _py3_source with stub modules for
+    the two imports.  Pinned: NaN handling, channel selection, per-sample/channel min-max, layout, dev split, iterator
+    batch counts and the last-batch wrap.  NOT pinnable here: skimage.transform.resize (not installed) and Python 2's
+    random.shuffle permutation for seed 123 (Python 3's differs) — the fixture runs with grid_size=None, shuffle=False."""
+    import tempfile
+    import types
+    for modname in ("torchvision", "torchvision.transforms", "skimage", "skimage.transform"):
+        sys.modules.setdefault(modname, types.ModuleType(modname))
+    sys.modules["skimage.transform"].resize = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("skimage is not installed"))
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    ns = {"__name__": "ref_dataloader"}
+    exec(compile(_py3_source(os.path.join(REF, "dataloader.py")), "dataloader.py(py3 view)", "exec"), ns)
+    rs = np.random.RandomState(3)
+    n_tr, n_te = 206, 5                                      # DEV_SIZE = 200 samples go to the dev split
+    raw = dict(trainA=rs.normal(3, 2, (n_tr, 6, 5, 4)), trainB=rs.gamma(2.0, 1.5, (n_tr, 6, 5, 1)),
+               testA=rs.normal(-1, 4, (n_te, 6, 5, 4)), testB=rs.gamma(1.0, 1.0, (n_te, 6, 5, 1)))
+    raw["trainA"][0, 0, 0, 0] = np.nan
+    raw["trainA"][1, :, :, 2] = 7.0                          # constant plane: 0/0 in the min-max
+    raw["testB"][2] = 0.0
+    root = tempfile.mkdtemp()
+    for k, v in raw.items():
+        np.savez(os.path.join(root, k + ".npz"), data=v)
+    out = ns["load_numpy_data"](root, shuffle=False, grid_size=None)
+    arr = {"raw/" + k: v for k, v in raw.items()}
+    for k, v in zip(("trainA", "trainB", "devA", "devB", "testA", "testB"), out):
+        arr["out/" + k] = v
+    # iterators: numpy's global RNG decides the permutations
+    A = np.arange(10, dtype=np.float32).reshape(10, 1, 1, 1)
+    np.random.seed(11)
+    un = ns["UnalignedIterator"](A, -A, batch_size=4)
+    batches = []
+    for _ in range(2):                                       # two epochs: StopIteration resets
+        while True:
+            try:
+                b = un.next()
+            except StopIteration:
+                break
+            batches.append(np.stack([b["A"].numpy().ravel(), b["B"].numpy().ravel()]))
+    arr["unaligned_batches"] = np.stack(batches)
+    al = ns["AlignedIterator"](A, -A, batch_size=4)
+    sizes = []
+    while True:
+        try:
+            sizes.append(al.next()["A"].shape[0])
+        except StopIteration:
+            break
+    arr["aligned_sizes"] = np.array(sizes)
+    save(name, arr, kind="data")
+
+
 if __name__ == "__main__":
     make_key_fixture()
+    make_init_fixture()
+    eval_case("eval_aug_small_s64", dict(input_nc=3, output_nc=3, ngf=8, nef=8, ndf=8, nlatent=4), N=4, S=64)
+    data_case()
     sup_case("sup_aug_small_s64", dict(input_nc=3, output_nc=3, ngf=8, nef=8, ndf=8, nlatent=4), N=4, S=64)
