@@ -47,10 +47,10 @@ SIGNATURES = {
     "acg_conv2d_bwd_data_workspace_bytes": (c_size_t, [_D]),
     "acg_conv2d_bwd_data": (c_int, [_D, _P, _P, _P, _P, c_size_t, _P]),
     "acg_conv2d_bwd_weight_workspace_bytes": (c_size_t, [_D]),
-    "acg_conv2d_bwd_weight": (c_int, [_D, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
+    "acg_conv2d_bwd_weight": (c_int, [_D, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
     "acg_conv_transpose2d_fwd": (c_int, [_D, _P, _P, _P, _P, c_int, _P]),
     "acg_conv_transpose2d_bwd_data": (c_int, [_D, _P, _P, _P, _P]),
-    "acg_conv_transpose2d_bwd_weight": (c_int, [_D, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
+    "acg_conv_transpose2d_bwd_weight": (c_int, [_D, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
     "acg_norm_workspace_bytes": (c_size_t, [c_int, c_size_t, c_int]),
     "acg_conv2d_fwd_stats_supported": (c_int, [_P]),
     "acg_conv2d_bwd_data_add_supported": (c_int, [_P]),
@@ -59,9 +59,9 @@ SIGNATURES = {
     "acg_norm_stats_from_partials": (c_int, [_P, c_int, c_size_t, c_int, c_int, c_float, c_int, _P, _P, _P]),
     "acg_norm_stats": (c_int, [_P, c_int, c_size_t, c_int, c_float, c_int, _P, _P, _P, _P, c_float, _P, c_size_t, _P]),
     "acg_bn_eval_stats": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P, _P]),
-    "acg_norm_apply": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_size_t, c_int, c_int, _P]),
-    "acg_norm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_size_t, c_int, c_int, c_int,
-                             _P, c_size_t, _P]),
+    "acg_norm_apply": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_size_t, c_int, c_int, _P]),
+    "acg_norm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_size_t, c_int, c_int,
+                             c_int, _P, c_size_t, _P]),
     "acg_norm_bwd_sums": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_size_t, c_int, c_int, _P, c_size_t, _P]),
     "acg_norm_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_size_t, c_size_t, c_int, c_int, c_int, _P]),
     "acg_act_bwd": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),

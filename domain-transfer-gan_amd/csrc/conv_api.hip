@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__rest
 }
 // one block per 16 channels: 16 partial-block lanes per channel, fixed-order LDS tree (deterministic)
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restrict__ part, int nblk, int C, int Cr,
-                                                           float *__restrict__ db)
+                                                           float *__restrict__ db, int accumulate)
 {
     __shared__ float red[256];
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), k = threadIdx.x >> 4;
@@ -428,15 +428,15 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restri
         if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x < 16 && c < Cr) db[c] = red[threadIdx.x];
+    if (threadIdx.x < 16 && c < Cr) db[c] = (accumulate ? db[c] : 0.f) + red[threadIdx.x];
 }
 static size_t colsum_ws_bytes(long long M, int C) { return (size_t)acg_cdiv(M, COLSUM_ROWS) * C * sizeof(float); }
-static int colsum_launch(const float *dy, long long M, int C, int Cr, float *db, float *ws, hipStream_t st)
+static int colsum_launch(const float *dy, long long M, int C, int Cr, float *db, float *ws, hipStream_t st, int accumulate)
 {
     ACG_REQUIRE(C % 4 == 0 && C / 4 <= 256, "colsum: C=%d unsupported", C);
     const int nblk = acg_cdiv(M, COLSUM_ROWS);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, st, dy, M, C, ws);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(acg_cdiv(Cr, 16)), dim3(256), 0, st, ws, nblk, C, Cr, db);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(acg_cdiv(Cr, 16)), dim3(256), 0, st, ws, nblk, C, Cr, db, accumulate);
     ACG_CHECK_LAUNCH("colsum");
     return ACG_OK;
 }
@@ -446,9 +446,29 @@ static int colsum_launch(const float *dy, long long M, int C, int Cr, float *db,
 // part[nsplit][KK][CiP][CoP]
 // ------------------------------------------------------------------------------------------
 // thin: part[nsplit][1][CiP][CoP] with row = tap*4 + ci
-__global__ void wgrad_reduce_kernel(const float *__restrict__ part, int nsplit, int KK, int CiP, int CoP, int Or,
-                                    int Ir, float *__restrict__ dw, int thin)
+// accumulate != 0: dw (and db) are ADDED to — the caller passes the parameter's .grad itself, so no separate accumulation
+// kernel runs per parameter (torch's AccumulateGrad launched 564 five-microsecond adds per training step).
+// The bias reduction rides in the same launch: blocks [wblocks, wblocks + ceil(Cr/16)) reduce bias_part[nsplit][Cp] -> db
+// (16 channels per block, 16 split-lanes each, fixed-order tree: deterministic).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int nsplit, int KK, int CiP, int CoP, int Or,
+                                    int Ir, float *__restrict__ dw, int thin, int accumulate, int wblocks,
+                                    const float *__restrict__ bias_part, int Cp, int Cr, float *__restrict__ db)
 {
+    if ((int)blockIdx.x >= wblocks) {
+        __shared__ float red[256];
+        const int c = ((int)blockIdx.x - wblocks) * 16 + (threadIdx.x & 15), k0 = threadIdx.x >> 4;
+        float s = 0.f;
+        if (c < Cr)
+            for (int k = k0; k < nsplit; k += 16) s += bias_part[(long long)k * Cp + c];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int st = 128; st >= 16; st >>= 1) {
+            if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x < 16 && c < Cr) db[c] = (accumulate ? db[c] : 0.f) + red[threadIdx.x];
+        return;
+    }
     const long long total = (long long)KK * Ir * Or;
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -463,25 +483,8 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ part, int nsplit, 
                                : part + ((long long)tap * CiP + ci) * CoP + o;
 #pragma unroll 8 // same summation order, eight loads in flight (the rolled loop paid one memory latency per split)
     for (int k = 0; k < nsplit; ++k) s += p[k * stride];
-    dw[((long long)o * Ir + ci) * KK + tap] = s;
-}
-
-// bias_part[nsplit][Cp] -> db[c] (first Cr channels): 16 channels per block, 16 split-lanes each, fixed-order tree
-__global__ __launch_bounds__(256) void bias_reduce_kernel(const float *__restrict__ part, int nsplit, int Cp, int Cr,
-                                                          float *__restrict__ db)
-{
-    __shared__ float red[256];
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15), k0 = threadIdx.x >> 4;
-    float s = 0.f;
-    if (c < Cr)
-        for (int k = k0; k < nsplit; k += 16) s += part[(long long)k * Cp + c];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int st = 128; st >= 16; st >>= 1) {
-        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
-        __syncthreads();
-    }
-    if (threadIdx.x < 16 && c < Cr) db[c] = red[threadIdx.x];
+    float *dst = dw + ((long long)o * Ir + ci) * KK + tap;
+    *dst = (accumulate ? *dst : 0.f) + s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -564,7 +567,7 @@ __global__ void direct_dgrad_kernel(acg_conv_desc d, const float *__restrict__ d
 
 // dw[o][i][kh][kw] (real Or x Ir), one thread per weight, serial over all pixels (tests only)
 __global__ void direct_wgrad_kernel(acg_conv_desc d, const float *__restrict__ x, const float *__restrict__ dy,
-                                    float *__restrict__ dw, int Or, int Ir)
+                                    float *__restrict__ dw, int Or, int Ir, int accumulate)
 {
     const int KK = d.K * d.K;
     const long long total = (long long)Or * Ir * KK;
@@ -588,7 +591,7 @@ __global__ void direct_wgrad_kernel(acg_conv_desc d, const float *__restrict__ x
                 acc += x[(((long long)n * d.Hi + iy) * d.Wi + ix) * d.Ci + ci] *
                        dy[(((long long)n * d.Ho + oy) * d.Wo + ox) * d.Co + co];
             }
-    dw[i] = acc;
+    dw[i] = (accumulate ? dw[i] : 0.f) + acc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -886,13 +889,13 @@ extern "C" size_t acg_conv2d_bwd_weight_workspace_bytes(const acg_conv_desc *d)
 // x_side: conv-input-side tensor (N,Hi,Wi,Ci); g_side: conv-output-side tensor (N,Ho,Wo,Co)
 // bias_from: 0 none; 1 db[c] = column sums of g_side (Conv2d bias, Or entries); 2 of x_side (ConvTranspose bias, Ir entries)
 static int wgrad_common(const acg_conv_desc *d, const float *x_side, const float *g_side, float *dw, int Or, int Ir,
-                        void *ws, size_t ws_bytes, hipStream_t st, int bias_from = 0, float *db = nullptr,
+                        void *ws, size_t ws_bytes, hipStream_t st, int accumulate, int bias_from = 0, float *db = nullptr,
                         bool thin_conv = false)
 {
     ACG_REQUIRE(Or <= d->Co && Ir <= d->Ci, "wgrad: Or=%d Ir=%d exceed padded dims", Or, Ir);
     if (g_acg_conv_impl == ACG_IMPL_DIRECT) {
         const long long total = (long long)Or * Ir * d->K * d->K;
-        hipLaunchKernelGGL(direct_wgrad_kernel, dim3(acg_cdiv(total, 64)), dim3(64), 0, st, *d, x_side, g_side, dw, Or, Ir);
+        hipLaunchKernelGGL(direct_wgrad_kernel, dim3(acg_cdiv(total, 64)), dim3(64), 0, st, *d, x_side, g_side, dw, Or, Ir, accumulate);
         ACG_CHECK_LAUNCH("direct_wgrad_kernel");
         return ACG_OK;
     }
@@ -913,14 +916,11 @@ static int wgrad_common(const acg_conv_desc *d, const float *x_side, const float
     g.bias_part = (float *)((char *)ws + acg_round_up(need, 256));
     int rc = acg_wgrad_launch(x_side, g_side, (float *)ws, g, t, st);
     if (rc) return rc;
-    if (g.bias_from) {
-        const int Cp = bias_from == 1 ? g.CoP : g.CiP, Cr = bias_from == 1 ? Or : Ir;
-        hipLaunchKernelGGL(bias_reduce_kernel, dim3(acg_cdiv(Cr, 16)), dim3(256), 0, st, (const float *)g.bias_part, g.nsplit, Cp,
-                           Cr, db);
-    }
+    const int Cp = bias_from == 1 ? g.CoP : g.CiP, Cr = g.bias_from ? (bias_from == 1 ? Or : Ir) : 0;
     const long long total = (long long)t.n * Ir * Or;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(acg_cdiv(total, 256)), dim3(256), 0, st, (const float *)ws, g.nsplit,
-                       t.n, g.CiP, g.CoP, Or, Ir, dw, g.thin);
+    const int wblocks = acg_cdiv(total, 256);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + acg_cdiv(Cr, 16)), dim3(256), 0, st, (const float *)ws, g.nsplit,
+                       t.n, g.CiP, g.CoP, Or, Ir, dw, g.thin, accumulate, wblocks, (const float *)g.bias_part, Cp, Cr, db);
     ACG_CHECK_LAUNCH("wgrad_reduce_kernel");
     return ACG_OK;
 }
@@ -929,7 +929,7 @@ static int wgrad_common(const acg_conv_desc *d, const float *x_side, const float
 //   dW[co][ci][kh,kw] = sum_{iy,ix} x[iy,ix][ci] * dy[iy-kh+p, ix-kw+p][co]
 // GEMM rows (gathered, thin) = (tap, co<4) from dy, columns = ci from the plain x rows, K = input pixels.
 static int wgrad_thin_out(const acg_conv_desc *d, const float *x, const float *dy, float *dw, int Or, int Ir, void *ws,
-                          size_t ws_bytes, hipStream_t st)
+                          size_t ws_bytes, hipStream_t st, int accumulate)
 {
     WGeom g; Taps t;
     const int K = d->K, p = d->pad;
@@ -960,7 +960,7 @@ static int wgrad_thin_out(const acg_conv_desc *d, const float *x, const float *d
     if (rc) return rc;
     const long long total = (long long)t.n * Ir * Or;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(acg_cdiv(total, 256)), dim3(256), 0, st, (const float *)ws, g.nsplit, t.n,
-                       g.CiP, g.CoP, Or, Ir, dw, 2);
+                       g.CiP, g.CoP, Or, Ir, dw, 2, accumulate, acg_cdiv(total, 256), (const float *)nullptr, 0, 0, (float *)nullptr);
     ACG_CHECK_LAUNCH("wgrad_reduce_kernel");
     return ACG_OK;
 }
@@ -975,7 +975,7 @@ static float *colsum_area(const acg_conv_desc *d, void *ws, size_t ws_bytes, siz
 }
 
 extern "C" int acg_conv2d_bwd_weight(const acg_conv_desc *d, const float *x, const float *dy, float *dw, float *db,
-                                     int Or, int Ir, void *ws, size_t ws_bytes, void *stream)
+                                     int Or, int Ir, void *ws, size_t ws_bytes, int accumulate, void *stream)
 {
     int rc = check_desc(d, "acg_conv2d_bwd_weight");
     if (rc) return rc;
@@ -986,15 +986,15 @@ extern "C" int acg_conv2d_bwd_weight(const acg_conv_desc *d, const float *x, con
     const bool tout = thin_out(d) && d->stride == 1 && !(d->pad_mode == ACG_PAD_REFLECT && d->pad > 0);
     const bool fused = dw != nullptr && db != nullptr && g_acg_conv_impl == ACG_IMPL_MFMA && !tout;
     if (dw != nullptr) {
-        rc = tout ? wgrad_thin_out(d, x, dy, dw, Or, Ir, ws, ws_bytes, st)
-                  : wgrad_common(d, x, dy, dw, Or, Ir, ws, ws_bytes, st, 1, fused ? db : nullptr, true);
+        rc = tout ? wgrad_thin_out(d, x, dy, dw, Or, Ir, ws, ws_bytes, st, accumulate)
+                  : wgrad_common(d, x, dy, dw, Or, Ir, ws, ws_bytes, st, accumulate, 1, fused ? db : nullptr, true);
         if (rc) return rc;
     }
     if (db != nullptr && !fused) {
         size_t avail; float *cw = colsum_area(d, ws, ws_bytes, &avail);
         const long long M = (long long)d->N * d->Ho * d->Wo;
         ACG_REQUIRE(avail >= colsum_ws_bytes(M, d->Co), "acg_conv2d_bwd_weight: colsum workspace");
-        rc = colsum_launch(dy, M, d->Co, Or, db, cw, st);
+        rc = colsum_launch(dy, M, d->Co, Or, db, cw, st, accumulate);
     }
     return rc;
 }
@@ -1023,7 +1023,8 @@ extern "C" int acg_conv_transpose2d_bwd_data(const acg_conv_desc *d, const float
 }
 
 extern "C" int acg_conv_transpose2d_bwd_weight(const acg_conv_desc *d, const float *x, const float *dy, float *dw,
-                                               float *db, int Or, int Ir, void *ws, size_t ws_bytes, void *stream)
+                                               float *db, int Or, int Ir, void *ws, size_t ws_bytes, int accumulate,
+                                               void *stream)
 {
     // underlying Conv2d: input side = ConvTranspose OUTPUT gradient dy (N,Hi,Wi,Ci), output side = x (N,Ho,Wo,Co);
     // weight (Cin_T, Cout_T, k, k) == OIHW of that Conv2d.  Bias gradient sums dy over pixels (Cout_T = Ir).
@@ -1035,14 +1036,14 @@ extern "C" int acg_conv_transpose2d_bwd_weight(const acg_conv_desc *d, const flo
     // visits only a strided subset of its pixels; one separate column-sum pass per generator is cheap.
     const bool fused = false;
     if (dw != nullptr) {
-        rc = wgrad_common(d, dy, x, dw, Or, Ir, ws, ws_bytes, st, 0, nullptr);
+        rc = wgrad_common(d, dy, x, dw, Or, Ir, ws, ws_bytes, st, accumulate, 0, nullptr);
         if (rc) return rc;
     }
     if (db != nullptr && !fused) {
         size_t avail; float *cw = colsum_area(d, ws, ws_bytes, &avail);
         const long long M = (long long)d->N * d->Hi * d->Wi;
         ACG_REQUIRE(avail >= colsum_ws_bytes(M, d->Ci), "acg_conv_transpose2d_bwd_weight: colsum workspace");
-        rc = colsum_launch(dy, M, d->Ci, Ir, db, cw, st);
+        rc = colsum_launch(dy, M, d->Ci, Ir, db, cw, st, accumulate);
     }
     return rc;
 }

@@ -114,13 +114,18 @@ __global__ __launch_bounds__(256) void norm_stats_final(const float *__restrict_
 // ACT / HAS_RES are template parameters: with run-time switches the body is a web of scalar branches with
 // s_waitcnt vmcnt(0) between them and the loads of a thread are issued one at a time (2.7-3.6 TB/s); specialised, all
 // loads of a thread go out back to back like a streaming copy.
-template <int ACT, bool HAS_RES>
+//
+// MASK: also store one bit per output element, (y > 0) — all the backward pass needs of y when a residual was added
+// before the activation (without a residual it recomputes the sign from x).  Bit e%32 of word e/32 for the element at
+// float index e; a thread's float4 is one nibble, 8 consecutive lanes own one word (OR-butterfly over lanes ^1, ^2, ^4).
+// The backward passes then read 1/32 of a tensor instead of y itself: -2 of the 8 tensor streams of a block-output norm.
+template <int ACT, bool HAS_RES, bool MASK>
 __global__ __launch_bounds__(256) void norm_apply_kernel(const float *__restrict__ x, const float *__restrict__ mean,
                                                          const float *__restrict__ rstd,
                                                          const float *__restrict__ gamma,
                                                          const float *__restrict__ beta, int gstride,
                                                          const float *__restrict__ res, float *__restrict__ y,
-                                                         long long P, int C)
+                                                         long long P, int C, unsigned *__restrict__ mask)
 {
     const int C4 = C / 4;
     const int g = blockIdx.y;
@@ -153,18 +158,35 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float *__restrict
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = acg_apply_act(o[k], ACT);
         if (ok[u]) *(f32x4 *)(y + base + (i0 + u * 256) * 4) = o;
+        if (MASK) {
+            const long long f = base / 4 + i0 + u * 256;   // float4 index; (f & 7) == (lane & 7): the launcher checks P*C/4 % 8 == 0
+            unsigned v = ok[u] ? ((o[0] > 0.f ? 1u : 0u) | (o[1] > 0.f ? 2u : 0u) | (o[2] > 0.f ? 4u : 0u) | (o[3] > 0.f ? 8u : 0u)) : 0u;
+            v <<= 4 * (threadIdx.x & 7);
+            v |= __shfl_xor(v, 1);
+            v |= __shfl_xor(v, 2);
+            v |= __shfl_xor(v, 4);
+            if ((threadIdx.x & 7) == 0 && ok[u]) mask[f >> 3] = v;
+        }
     }
+}
+
+// the nibble of the float4 at float4-index f
+__device__ __forceinline__ unsigned norm_mask_nibble(const unsigned *__restrict__ mask, long long f)
+{
+    return (mask[f >> 3] >> (4 * (int)(f & 7))) & 15u;
 }
 
 // backward pass 1: per (group, chunk) partial sums of gy and gy*xhat, gy = dy*act'(y)
 // part[((g*nchunks + chunk)*2 + {0:S1,1:S2})*C + c]
 // y == nullptr: the activation mask is recomputed from x (pre = xhat*gamma + beta) instead of read — valid when no
 // residual was added before the activation; saves one tensor stream per pass.
+// mask != nullptr: the sign bits norm_apply_kernel<.., MASK> stored replace y
 __global__ __launch_bounds__(256) void norm_bwd_partial(const float *__restrict__ dy, const float *__restrict__ y,
                                                         const float *__restrict__ x, const float *__restrict__ mean,
                                                         const float *__restrict__ rstd, const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, int gstride, long long P, int C,
-                                                        int nchunks, int act, float *__restrict__ part)
+                                                        int nchunks, int act, float *__restrict__ part,
+                                                        const unsigned *__restrict__ mask)
 {
     __shared__ float sa[256 * 4], sb[256 * 4];
     const int C4 = C / 4;
@@ -180,7 +202,7 @@ __global__ __launch_bounds__(256) void norm_bwd_partial(const float *__restrict_
         const f32x4 mu = *(const f32x4 *)(mean + g * C + c4 * 4);
         const f32x4 rs = *(const f32x4 *)(rstd + g * C + c4 * 4);
         f32x4 ga = {0.f, 0.f, 0.f, 0.f}, be = ga;
-        const bool recompute = act != ACG_ACT_NONE && y == nullptr;
+        const bool recompute = act != ACG_ACT_NONE && y == nullptr && mask == nullptr;
         if (recompute) {
             ga = *(const f32x4 *)(gamma + g * gstride + c4 * 4);
             be = *(const f32x4 *)(beta + g * gstride + c4 * 4);
@@ -192,7 +214,11 @@ __global__ __launch_bounds__(256) void norm_bwd_partial(const float *__restrict_
             const f32x4 xv = *(const f32x4 *)(x + o);
             if (act != ACG_ACT_NONE) {
                 f32x4 yy;
-                if (recompute) yy = (xv - mu) * rs * ga + be;   // same expression as norm_apply_kernel (sign is all we need)
+                if (mask != nullptr) {
+                    const unsigned nb = norm_mask_nibble(mask, o >> 2);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) yy[k] = (nb >> k) & 1u ? 1.f : -1.f;
+                } else if (recompute) yy = (xv - mu) * rs * ga + be;   // same expression as norm_apply_kernel (sign is all we need)
                 else yy = *(const f32x4 *)(y + o);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) gy[k] *= acg_act_grad_from_y(yy[k], act);
@@ -218,8 +244,10 @@ __global__ __launch_bounds__(256) void norm_bwd_partial(const float *__restrict_
 }
 
 // sums[(g*2 + {0,1})*C + c] = sum over chunks (fixed order)
+// dgamma_gc / dbeta_gc (CondInstanceNorm: per-sample affine, gstride == C): the sums ARE the parameter gradients
 __global__ __launch_bounds__(256) void norm_bwd_final(const float *__restrict__ part, int G, int C, int nchunks,
-                                                      float *__restrict__ sums)
+                                                      float *__restrict__ sums, float *__restrict__ dgamma_gc,
+                                                      float *__restrict__ dbeta_gc)
 {
     __shared__ float sa[FIN_KQ][FIN_CH], sb[FIN_KQ][FIN_CH];
     const int cc = threadIdx.x % FIN_CH, kq = threadIdx.x / FIN_CH;
@@ -242,29 +270,25 @@ __global__ __launch_bounds__(256) void norm_bwd_final(const float *__restrict__ 
     for (int q = 0; q < FIN_KQ; ++q) { a += sa[q][cc]; b += sb[q][cc]; }
     sums[(g * 2) * C + c] = a;
     sums[(g * 2 + 1) * C + c] = b;
+    if (dbeta_gc) dbeta_gc[g * C + c] = a;
+    if (dgamma_gc) dgamma_gc[g * C + c] = b;
 }
 
-// parameter gradients: gstride==0 -> dgamma[c] = sum_g S2, dbeta[c] = sum_g S1 ; else per (g,c)
-__global__ void norm_bwd_params(const float *__restrict__ sums, int G, int C, int gstride, float *__restrict__ dgamma,
-                                float *__restrict__ dbeta)
+// parameter gradients of a shared affine (InstanceNorm / BatchNorm, gstride == 0): dgamma[c] = sum_g S2, dbeta[c] = sum_g S1
+// for the first `nparam` (real, unpadded) channels; accumulate != 0 adds to the destination (the parameter's .grad)
+__global__ void norm_bwd_params(const float *__restrict__ sums, int G, int C, int nparam, int accumulate,
+                                float *__restrict__ dgamma, float *__restrict__ dbeta)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gstride == 0) {
-        if (i >= C) return;
-        float a = 0.f, b = 0.f;
-        for (int g = 0; g < G; ++g) { a += sums[(g * 2) * C + i]; b += sums[(g * 2 + 1) * C + i]; }
-        if (dbeta) dbeta[i] = a;
-        if (dgamma) dgamma[i] = b;
-    } else {
-        if (i >= G * C) return;
-        const int g = i / C, c = i - g * C;
-        if (dbeta) dbeta[g * gstride + c] = sums[(g * 2) * C + c];
-        if (dgamma) dgamma[g * gstride + c] = sums[(g * 2 + 1) * C + c];
-    }
+    if (i >= nparam) return;
+    float a = 0.f, b = 0.f;
+    for (int g = 0; g < G; ++g) { a += sums[(g * 2) * C + i]; b += sums[(g * 2 + 1) * C + i]; }
+    if (dbeta) dbeta[i] = (accumulate ? dbeta[i] : 0.f) + a;
+    if (dgamma) dgamma[i] = (accumulate ? dgamma[i] : 0.f) + b;
 }
 
 // backward pass 2: dx = gamma*rstd*(gy - S1/P - xhat*S2/D) ; dres = gy
-template <int ACT, bool RECOMPUTE, bool HAS_DRES> // RECOMPUTE: activation mask from x (y == nullptr); see norm_apply_kernel
+template <int ACT, int MSRC, bool HAS_DRES> // activation mask: MSRC 0 = read y, 1 = recompute from x (y == nullptr), 2 = sign bitmask
 __global__ __launch_bounds__(256) void norm_bwd_apply(const float *__restrict__ dy, const float *__restrict__ y,
                                                       const float *__restrict__ x, const float *__restrict__ mean,
                                                       const float *__restrict__ rstd,
@@ -272,8 +296,9 @@ __global__ __launch_bounds__(256) void norm_bwd_apply(const float *__restrict__ 
                                                       const float *__restrict__ beta, int gstride,
                                                       const float *__restrict__ sums, float *__restrict__ dx,
                                                       float *__restrict__ dres, long long P, int C, float invP,
-                                                      float invD)
+                                                      float invD, const unsigned *__restrict__ mask)
 {
+    constexpr bool RECOMPUTE = MSRC == 1;
     const int C4 = C / 4;
     const int g = blockIdx.y;
     const long long total = P * C4;
@@ -288,7 +313,12 @@ __global__ __launch_bounds__(256) void norm_bwd_apply(const float *__restrict__ 
         const long long o = base + (ok[u] ? i0 + u * 256 : 0) * 4;
         gv[u] = *(const f32x4 *)(dy + o);
         xv[u] = *(const f32x4 *)(x + o);
-        if (ACT != ACG_ACT_NONE && !RECOMPUTE) yv[u] = *(const f32x4 *)(y + o);
+        if (ACT != ACG_ACT_NONE && MSRC == 0) yv[u] = *(const f32x4 *)(y + o);
+        if (ACT != ACG_ACT_NONE && MSRC == 2) {
+            const unsigned nb = norm_mask_nibble(mask, o >> 2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) yv[u][k] = (nb >> k) & 1u ? 1.f : -1.f;
+        }
     }
     int c = (int)(i0 % C4) * 4;
     f32x4 mu, rs, ga, be = {0.f, 0.f, 0.f, 0.f}, s1, s2;
@@ -333,12 +363,13 @@ __global__ __launch_bounds__(256) void norm_bwd_apply(const float *__restrict__ 
 
 static void launch_norm_apply(dim3 grid, hipStream_t st, const float *x, const float *mean, const float *rstd,
                               const float *gamma, const float *beta, int gstride, const float *res, float *y, long long P,
-                              int C, int act)
+                              int C, int act, unsigned *mask)
 {
 #define M(A)                                                                                                              \
     do {                                                                                                                  \
-        if (res) hipLaunchKernelGGL((norm_apply_kernel<A, true>), grid, dim3(256), 0, st, x, mean, rstd, gamma, beta, gstride, res, y, P, C); \
-        else hipLaunchKernelGGL((norm_apply_kernel<A, false>), grid, dim3(256), 0, st, x, mean, rstd, gamma, beta, gstride, res, y, P, C);   \
+        if (res && mask) hipLaunchKernelGGL((norm_apply_kernel<A, true, true>), grid, dim3(256), 0, st, x, mean, rstd, gamma, beta, gstride, res, y, P, C, mask); \
+        else if (res) hipLaunchKernelGGL((norm_apply_kernel<A, true, false>), grid, dim3(256), 0, st, x, mean, rstd, gamma, beta, gstride, res, y, P, C, mask); \
+        else hipLaunchKernelGGL((norm_apply_kernel<A, false, false>), grid, dim3(256), 0, st, x, mean, rstd, gamma, beta, gstride, res, y, P, C, mask);   \
     } while (0)
     NORM_ACT_SWITCH(act, M)
 #undef M
@@ -347,16 +378,18 @@ static void launch_norm_apply(dim3 grid, hipStream_t st, const float *x, const f
 static void launch_norm_bwd_apply(dim3 grid, hipStream_t st, const float *dy, const float *y, const float *x,
                                   const float *mean, const float *rstd, const float *gamma, const float *beta, int gstride,
                                   const float *sums, float *dx, float *dres, long long P, int C, int act, float invP,
-                                  float invD)
+                                  float invD, const unsigned *mask)
 {
-#define L(A, R, D) hipLaunchKernelGGL((norm_bwd_apply<A, R, D>), grid, dim3(256), 0, st, dy, y, x, mean, rstd, gamma, beta, gstride, sums, dx, dres, P, C, invP, invD)
+#define L(A, R, D) hipLaunchKernelGGL((norm_bwd_apply<A, R, D>), grid, dim3(256), 0, st, dy, y, x, mean, rstd, gamma, beta, gstride, sums, dx, dres, P, C, invP, invD, mask)
 #define M(A)                                                                         \
     do {                                                                             \
-        const bool rc = y == nullptr;                                                \
-        if (rc && dres) L(A, true, true);                                            \
-        else if (rc) L(A, true, false);                                              \
-        else if (dres) L(A, false, true);                                            \
-        else L(A, false, false);                                                     \
+        const bool rc = y == nullptr && mask == nullptr;                             \
+        if (mask && dres) L(A, 2, true);                                             \
+        else if (mask) L(A, 2, false);                                               \
+        else if (rc && dres) L(A, 1, true);                                          \
+        else if (rc) L(A, 1, false);                                                 \
+        else if (dres) L(A, 0, true);                                                \
+        else L(A, 0, false);                                                         \
     } while (0)
     NORM_ACT_SWITCH(act, M)
 #undef M
@@ -442,14 +475,16 @@ static int ew_blocks(long long total)
 }
 
 extern "C" int acg_norm_apply(const float *x, const float *mean, const float *rstd, const float *gamma,
-                              const float *beta, int gstride, const float *res, float *y, int G, size_t P, int C,
-                              int act, void *stream)
+                              const float *beta, int gstride, const float *res, float *y, unsigned *mask, int G, size_t P,
+                              int C, int act, void *stream)
 {
     int rc = check_norm(G, P, C, "acg_norm_apply");
     if (rc) return rc;
     ACG_REQUIRE(gstride == 0 || gstride == C, "acg_norm_apply: gstride must be 0 or C");
+    ACG_REQUIRE(mask == nullptr || (res != nullptr && ((long long)P * (C / 4)) % 8 == 0 && (act == ACG_ACT_RELU || act == ACG_ACT_LRELU)),
+                "acg_norm_apply: the sign bitmask needs a residual, ReLU / LeakyReLU and P*C/4 %% 8 == 0");
     launch_norm_apply(dim3(ew_blocks((long long)P * (C / 4)), G), (hipStream_t)stream, x, mean, rstd, gamma, beta, gstride, res,
-                      y, (long long)P, C, act);
+                      y, (long long)P, C, act, mask);
     ACG_CHECK_LAUNCH("norm_apply_kernel");
     return ACG_OK;
 }
@@ -469,8 +504,9 @@ extern "C" int acg_norm_bwd_sums(const float *dy, const float *y, const float *x
     const int nch = nchunks_of(P);
     ACG_REQUIRE(act == ACG_ACT_NONE || y != nullptr, "acg_norm_bwd_sums: y required");
     hipLaunchKernelGGL(norm_bwd_partial, dim3(nch, G), dim3(256), 0, st, dy, y, x, mean, rstd, (const float *)nullptr,
-                       (const float *)nullptr, 0, (long long)P, C, nch, act, (float *)ws);
-    hipLaunchKernelGGL(norm_bwd_final, dim3(G * acg_cdiv(C, FIN_CH)), dim3(256), 0, st, (const float *)ws, G, C, nch, sums);
+                       (const float *)nullptr, 0, (long long)P, C, nch, act, (float *)ws, (const unsigned *)nullptr);
+    hipLaunchKernelGGL(norm_bwd_final, dim3(G * acg_cdiv(C, FIN_CH)), dim3(256), 0, st, (const float *)ws, G, C, nch, sums,
+                       (float *)nullptr, (float *)nullptr);
     ACG_CHECK_LAUNCH("norm_bwd_sums");
     return ACG_OK;
 }
@@ -486,18 +522,21 @@ extern "C" int acg_norm_bwd_apply(const float *dy, const float *y, const float *
     const float invD = unbiased == 2 ? 0.f : (unbiased ? 1.f / (float)(Ptot - 1) : invP);
     ACG_REQUIRE(act == ACG_ACT_NONE || y != nullptr, "acg_norm_bwd_apply: y required");
     launch_norm_bwd_apply(dim3(ew_blocks((long long)P * (C / 4)), G), (hipStream_t)stream, dy, y, x, mean, rstd, gamma,
-                          (const float *)nullptr, gstride, sums, dx, dres, (long long)P, C, act, invP, invD);
+                          (const float *)nullptr, gstride, sums, dx, dres, (long long)P, C, act, invP, invD, (const unsigned *)nullptr);
     ACG_CHECK_LAUNCH("norm_bwd_apply");
     return ACG_OK;
 }
 
-extern "C" int acg_norm_bwd(const float *dy, const float *y, const float *x, const float *mean, const float *rstd,
+extern "C" int acg_norm_bwd(const float *dy, const float *y, const unsigned *mask, const float *x, const float *mean,
+                            const float *rstd,
                             const float *gamma, const float *beta, int gstride, float *dx, float *dres, float *dgamma,
-                            float *dbeta, int G, size_t P, int C, int act, int unbiased, void *ws, size_t ws_bytes,
-                            void *stream)
+                            float *dbeta, int nparam, int accumulate, int G, size_t P, int C, int act, int unbiased,
+                            void *ws, size_t ws_bytes, void *stream)
 {
     int rc = check_norm(G, P, C, "acg_norm_bwd");
     if (rc) return rc;
+    ACG_REQUIRE(gstride != 0 || (nparam >= 0 && nparam <= C), "acg_norm_bwd: nparam=%d exceeds C=%d", nparam, C);
+    ACG_REQUIRE(gstride == 0 || accumulate == 0, "acg_norm_bwd: accumulate is for shared (gstride == 0) parameters");
     ACG_REQUIRE(gstride == 0 || gstride == C, "acg_norm_bwd: gstride must be 0 or C");
     ACG_REQUIRE(act == ACG_ACT_NONE || act == ACG_ACT_RELU || act == ACG_ACT_LRELU, "acg_norm_bwd: act %d", act);
     if (ws == nullptr || ws_bytes < acg_norm_workspace_bytes(G, P, C)) {
@@ -508,19 +547,21 @@ extern "C" int acg_norm_bwd(const float *dy, const float *y, const float *x, con
     const int nch = nchunks_of(P);
     float *part = (float *)ws;
     float *sums = part + (size_t)G * nch * 2 * C;
-    ACG_REQUIRE(act == ACG_ACT_NONE || y != nullptr || beta != nullptr, "acg_norm_bwd: y or beta required for the activation mask");
+    ACG_REQUIRE(act == ACG_ACT_NONE || y != nullptr || mask != nullptr || beta != nullptr,
+                "acg_norm_bwd: y, the sign bitmask or beta required for the activation mask");
+    ACG_REQUIRE(mask == nullptr || ((long long)P * (C / 4)) % 8 == 0, "acg_norm_bwd: bitmask layout needs P*C/4 %% 8 == 0");
     hipLaunchKernelGGL(norm_bwd_partial, dim3(nch, G), dim3(256), 0, st, dy, y, x, mean, rstd, gamma, beta, gstride,
-                       (long long)P, C, nch, act, part);
+                       (long long)P, C, nch, act, part, mask);
     hipLaunchKernelGGL(norm_bwd_final, dim3(G * acg_cdiv(C, FIN_CH)), dim3(256), 0, st, (const float *)part, G, C,
-                       nch, sums);
-    if (dgamma != nullptr || dbeta != nullptr)
-        hipLaunchKernelGGL(norm_bwd_params, dim3(acg_cdiv((long)G * C, 256)), dim3(256), 0, st, (const float *)sums, G, C,
-                           gstride, dgamma, dbeta);
+                       nch, sums, gstride ? dgamma : (float *)nullptr, gstride ? dbeta : (float *)nullptr);
+    if (gstride == 0 && nparam > 0 && (dgamma != nullptr || dbeta != nullptr))
+        hipLaunchKernelGGL(norm_bwd_params, dim3(acg_cdiv(nparam, 256)), dim3(256), 0, st, (const float *)sums, G, C, nparam,
+                           accumulate, dgamma, dbeta);
     // unbiased == 2: statistics are constants (BatchNorm eval mode) -> dx = gamma * rstd * gy
     const float invP = unbiased == 2 ? 0.f : 1.f / (float)P;
     const float invD = unbiased == 2 ? 0.f : (unbiased ? 1.f / (float)(P - 1) : invP);
     launch_norm_bwd_apply(dim3(ew_blocks((long long)P * (C / 4)), G), st, dy, y, x, mean, rstd, gamma, beta, gstride,
-                          (const float *)sums, dx, dres, (long long)P, C, act, invP, invD);
+                          (const float *)sums, dx, dres, (long long)P, C, act, invP, invD, mask);
     ACG_CHECK_LAUNCH("norm_bwd");
     return ACG_OK;
 }

@@ -166,6 +166,7 @@ def hook_params(bucket):
     bucket._exchange = None
     for p in bucket.params:
         p.register_post_accumulate_grad_hook(hook)
+        p._acg_grad_hook = hook   # ops fires it by hand where a kernel adds into .grad itself (no AccumulateGrad runs)
 
 
 def broadcast_params_(nets):

@@ -107,6 +107,7 @@ class FlatNet(object):
                 self.p[o:o + p.numel()].copy_(p.reshape(-1))
                 p.data = self.p[o:o + p.numel()].view(p.shape)
                 p.grad = self.g[o:o + p.numel()].view(p.shape)
+                p._acg_direct_grad = True    # ops: weight-gradient kernels add straight into this view
         self.sumsq = torch.zeros((), device=dev, dtype=torch.float32)
         mark_dirty(net)
         self._exchange = None

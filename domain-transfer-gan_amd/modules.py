@@ -110,14 +110,21 @@ class _BatchNormMixin(_Cached):
             with torch.no_grad():
                 self.num_batches_tracked += 1
             return y
-        rm = torch.zeros(C, device=x.device, dtype=torch.float32)
-        rv = torch.ones(C, device=x.device, dtype=torch.float32)
-        rm[:self.num_features].copy_(self.running_mean)
-        rv[:self.num_features].copy_(self.running_var)
-        y = ops.NormAct.apply(x, self.weight, self.bias, None, "bn", act, self.eps, g, b, rm, rv, self.momentum)
+        if C == self.num_features and self.running_mean.is_contiguous() and self.running_var.is_contiguous():
+            # no channel padding (every BatchNorm of the reference's networks: widths are multiples of 16): the statistics
+            # kernel updates the running buffers in place
+            y = ops.NormAct.apply(x, self.weight, self.bias, None, "bn", act, self.eps, g, b, self.running_mean,
+                                  self.running_var, self.momentum)
+        else:
+            rm = torch.zeros(C, device=x.device, dtype=torch.float32)
+            rv = torch.ones(C, device=x.device, dtype=torch.float32)
+            rm[:self.num_features].copy_(self.running_mean)
+            rv[:self.num_features].copy_(self.running_var)
+            y = ops.NormAct.apply(x, self.weight, self.bias, None, "bn", act, self.eps, g, b, rm, rv, self.momentum)
+            with torch.no_grad():
+                self.running_mean.copy_(rm[:self.num_features])
+                self.running_var.copy_(rv[:self.num_features])
         with torch.no_grad():
-            self.running_mean.copy_(rm[:self.num_features])
-            self.running_var.copy_(rv[:self.num_features])
             self.num_batches_tracked += 1
         return y
 

@@ -221,6 +221,38 @@ def take_conv_stats(x):
     return None
 
 
+# Parameter gradients straight into .grad: a model.FlatNet marks its parameters `_acg_direct_grad`; their .grad tensors are
+# preset views of the network's flat gradient buffer, and the weight-gradient / norm-parameter kernels ADD into them
+# (accumulate=1) instead of returning a fresh tensor for autograd's AccumulateGrad to add with one more kernel per parameter
+# (564 five-microsecond launches per training step).  The Function then returns None for that parameter, so the
+# post-accumulate hooks of the data-parallel exchange (dist.hook_params) are fired by hand.
+DIRECT_GRAD = os.environ.get("ACGAN_NO_DIRECT_GRAD") is None   # A/B switch
+
+
+def _direct_grad(*params):
+    """-> list of .grad targets when EVERY given parameter (None entries skipped) takes direct accumulation, else None"""
+    if not DIRECT_GRAD:
+        return None
+    out = []
+    for p in params:
+        if p is None:
+            out.append(None)
+            continue
+        g = getattr(p, "grad", None)
+        if not getattr(p, "_acg_direct_grad", False) or g is None or not g.is_contiguous() or g.dtype != torch.float32:
+            return None
+        out.append(g)
+    return out
+
+
+def _grads_done(*params):
+    for p in params:
+        if p is not None:
+            h = getattr(p, "_acg_grad_hook", None)
+            if h is not None:
+                h(p)
+
+
 class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d (+ preceding ReflectionPad2d) + bias + fused activation.  want_stats: the caller runs an
     (Cond)InstanceNorm on the output next — where the kernel supports it the epilogue emits that norm's per-tile
@@ -259,6 +291,7 @@ class Conv2dFn(torch.autograd.Function):
                 t.events.append((e0, e1))
                 t.kernel = _lib.query("acg_last_kernel").decode()   # what the dispatcher actually launched
         ctx.d, ctx.packed, ctx.act, ctx.has_bias = d, packed, act, bias is not None
+        ctx.wparam, ctx.bparam = weight, bias
         ctx.save_for_backward(x, y if act != ACT_NONE else None)
         if want_identity:
             return y, x.view_as(x)
@@ -288,12 +321,19 @@ class Conv2dFn(torch.autograd.Function):
                 if dskip is not None:
                     dx = dx + dskip
         if ctx.needs_input_grad[1]:
-            dw = torch.empty((pk.Or, pk.Ir, pk.K, pk.K), device=x.device, dtype=torch.float32)
-            db = torch.empty(pk.Or, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+            direct = _direct_grad(ctx.wparam, ctx.bparam)
+            if direct is not None:
+                dw, db = direct
+            else:
+                dw = torch.empty((pk.Or, pk.Ir, pk.K, pk.K), device=x.device, dtype=torch.float32)
+                db = torch.empty(pk.Or, device=x.device, dtype=torch.float32) if ctx.has_bias else None
             nb = _lib.query("acg_conv2d_bwd_weight_workspace_bytes", ctypes.byref(d))
             ws = workspace(nb)
             _lib.call("acg_conv2d_bwd_weight", ctypes.byref(d), _ptr(x), _ptr(g), _ptr(dw), _ptr(db), pk.Or, pk.Ir, _ptr(ws),
-                      nb, st)
+                      nb, 1 if direct is not None else 0, st)
+            if direct is not None:
+                dw = db = None
+                _grads_done(ctx.wparam, ctx.bparam)
         return dx, dw, db, None, None, None, None, None, None, None
 
 
@@ -319,6 +359,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
         _lib.call("acg_conv_transpose2d_fwd", ctypes.byref(d), _ptr(x), _ptr(packed.wb),
                   _ptr(packed.bias if bias is not None else None), _ptr(y), act, _stream())
         ctx.d, ctx.packed, ctx.act, ctx.has_bias = d, packed, act, bias is not None
+        ctx.wparam, ctx.bparam = weight, bias
         ctx.save_for_backward(x, y if act != ACT_NONE else None)
         return y
 
@@ -338,18 +379,28 @@ class ConvTranspose2dFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             _lib.call("acg_conv_transpose2d_bwd_data", ctypes.byref(d), _ptr(g), _ptr(pk.wf), _ptr(dx), st)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty((pk.Or, pk.Ir, pk.K, pk.K), device=x.device, dtype=torch.float32)
-            db = torch.empty(pk.Ir, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+            direct = _direct_grad(ctx.wparam, ctx.bparam)
+            if direct is not None:
+                dw, db = direct
+            else:
+                dw = torch.empty((pk.Or, pk.Ir, pk.K, pk.K), device=x.device, dtype=torch.float32)
+                db = torch.empty(pk.Ir, device=x.device, dtype=torch.float32) if ctx.has_bias else None
             nb = _lib.query("acg_conv2d_bwd_weight_workspace_bytes", ctypes.byref(d))
             ws = workspace(nb)
             _lib.call("acg_conv_transpose2d_bwd_weight", ctypes.byref(d), _ptr(x), _ptr(g), _ptr(dw), _ptr(db), pk.Or,
-                      pk.Ir, _ptr(ws), nb, st)
+                      pk.Ir, _ptr(ws), nb, 1 if direct is not None else 0, st)
+            if direct is not None:
+                dw = db = None
+                _grads_done(ctx.wparam, ctx.bparam)
         return dx, dw, db, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------
 # normalisation (+ fused activation / residual)
 # ----------------------------------------------------------------------------------------------
+NORM_SIGN_MASK = os.environ.get("ACGAN_NO_NORM_MASK") is None   # A/B switch
+
+
 class NormAct(torch.autograd.Function):
     """y = act(norm(x) * gamma + beta [+ res]).
 
@@ -396,32 +447,45 @@ class NormAct(torch.autograd.Function):
         y = torch.empty_like(x)
         if res is not None:
             res = res.contiguous()
-        _lib.call("acg_norm_apply", _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gp), _ptr(bp), gstride, _ptr(res), _ptr(y), G, P, C,
-                  act, st)
-        ctx.cfg = (kind, act, G, P, C, unbiased, gstride, res is not None, gamma.shape)
-        # without a residual the backward recomputes the activation mask from x (gamma/beta): y is neither saved nor read
+        # without a residual the backward recomputes the activation mask from x (gamma/beta): y is neither saved nor read.
+        # With one it needs sign(y): the apply pass stores it as one bit per element (1/32 of a tensor) where it can.
         need_y = act != ACT_NONE and res is not None
-        ctx.save_for_backward(x, y if need_y else None, mean, rstd, gp, bp)
+        mask = None
+        if need_y and NORM_SIGN_MASK and act in (ACT_RELU, ACT_LRELU) and (P * (C // 4)) % 8 == 0 and any(ctx.needs_input_grad):
+            mask = torch.empty((G * P * C + 31) // 32, device=x.device, dtype=torch.int32)
+        _lib.call("acg_norm_apply", _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gp), _ptr(bp), gstride, _ptr(res), _ptr(y), _ptr(mask),
+                  G, P, C, act, st)
+        ctx.cfg = (kind, act, G, P, C, unbiased, gstride, res is not None, gamma.shape)
+        ctx.gparam, ctx.bparam = (gamma, beta) if kind != "cin" else (None, None)
+        ctx.save_for_backward(x, y if (need_y and mask is None) else None, mean, rstd, gp, bp, mask)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, mean, rstd, gp, bp = ctx.saved_tensors
+        x, y, mean, rstd, gp, bp, mask = ctx.saved_tensors
         kind, act, G, P, C, unbiased, gstride, has_res, gshape = ctx.cfg
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
-        npar = G * C if gstride else C
-        dgamma = torch.empty(npar, device=x.device, dtype=torch.float32)
-        dbeta = torch.empty(npar, device=x.device, dtype=torch.float32)
+        direct = _direct_grad(ctx.gparam, ctx.bparam) if (kind != "cin" and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]) else None
+        if direct is not None:      # shared affine parameters: add into their .grad (first gshape[0] = real channels)
+            dgamma, dbeta = direct
+        else:
+            npar = G * C if gstride else gshape[0]
+            dgamma = torch.empty(npar, device=x.device, dtype=torch.float32)
+            dbeta = torch.empty(npar, device=x.device, dtype=torch.float32)
         nb = _lib.query("acg_norm_workspace_bytes", G, P, C)
         ws = workspace(nb)
-        _lib.call("acg_norm_bwd", _ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gp), _ptr(bp), gstride, _ptr(dx),
-                  _ptr(dres), _ptr(dgamma), _ptr(dbeta), G, P, C, act, unbiased, _ptr(ws), nb, _stream())
+        _lib.call("acg_norm_bwd", _ptr(dy), _ptr(y), _ptr(mask), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gp), _ptr(bp), gstride, _ptr(dx),
+                  _ptr(dres), _ptr(dgamma), _ptr(dbeta), 0 if gstride else gshape[0], 1 if direct is not None else 0, G, P, C,
+                  act, unbiased, _ptr(ws), nb, _stream())
         if kind == "cin":
             dg, db = dgamma.view(G, C), dbeta.view(G, C)
+        elif direct is not None:
+            dg = db = None
+            _grads_done(ctx.gparam, ctx.bparam)
         else:
-            dg, db = dgamma[:gshape[0]], dbeta[:gshape[0]]
+            dg, db = dgamma, dbeta
         if has_res and act == ACT_NONE:
             dres = dy
         return dx, dg, db, dres, None, None, None, None, None, None, None, None
@@ -465,7 +529,7 @@ class SyncBatchNormAct(torch.autograd.Function):
                 run_var.mul_(1 - momentum).add_(gvar[:nreal] * (Ptot / max(Ptot - 1, 1)), alpha=momentum)
         gmean, grstd = gmean.contiguous(), grstd.contiguous()
         y = torch.empty_like(x)
-        _lib.call("acg_norm_apply", _ptr(x), _ptr(gmean), _ptr(grstd), _ptr(gamma_p), _ptr(beta_p), 0, None, _ptr(y), 1, P, C,
+        _lib.call("acg_norm_apply", _ptr(x), _ptr(gmean), _ptr(grstd), _ptr(gamma_p), _ptr(beta_p), 0, None, _ptr(y), None, 1, P, C,
                   act, st)
         ctx.cfg = (act, P, int(Ptot), C, gamma.shape)
         ctx.save_for_backward(x, y if act != ACT_NONE else None, gmean, grstd, gamma_p)

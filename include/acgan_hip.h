@@ -113,10 +113,12 @@ int acg_conv2d_bwd_data_add_supported(const acg_conv_desc *d);
 int acg_conv2d_bwd_data_add(const acg_conv_desc *d, const float *dy, const float *wb, const float *addend, float *dx,
                             void *ws, size_t ws_bytes, void *stream);
 /* weight (+bias) gradient: x, dy -> dw in torch OIHW layout (Or x Ir real channels), db[Or] (may be NULL).
- * Deterministic split-K over pixels with a second-stage reduction (no atomics). */
+ * Deterministic split-K over pixels with a second-stage reduction (no atomics).  accumulate != 0: the result is ADDED to
+ * dw / db — pass the parameter's .grad (what autograd's AccumulateGrad does after loss.backward(), model.py:445, 509,
+ * with one extra element-wise kernel per parameter); 0: dw / db are overwritten. */
 size_t acg_conv2d_bwd_weight_workspace_bytes(const acg_conv_desc *d);
 int acg_conv2d_bwd_weight(const acg_conv_desc *d, const float *x, const float *dy, float *dw_oihw, float *db,
-                          int Or, int Ir, void *workspace, size_t ws_bytes, void *stream);
+                          int Or, int Ir, void *workspace, size_t ws_bytes, int accumulate, void *stream);
 
 /* ---- nn.ConvTranspose2d(k3,s2,p1,op1) — networks.py:178-179, 231-234.  `d` describes the
  *      Conv2d it is the adjoint of (Hi,Wi,Ci = the LARGE side = ConvTranspose output). ---- */
@@ -124,7 +126,8 @@ int acg_conv_transpose2d_fwd(const acg_conv_desc *d, const float *x, const float
                              int act, void *stream);
 int acg_conv_transpose2d_bwd_data(const acg_conv_desc *d, const float *dy, const float *wf, float *dx, void *stream);
 int acg_conv_transpose2d_bwd_weight(const acg_conv_desc *d, const float *x, const float *dy, float *dw_oihw,
-                                    float *db, int Or, int Ir, void *workspace, size_t ws_bytes, void *stream);
+                                    float *db, int Or, int Ir, void *workspace, size_t ws_bytes, int accumulate,
+                                    void *stream);
 
 /* ---- normalisation: InstanceNorm (modules.py:64-97, biased var), CondInstanceNorm
  *      (modules.py:104-132, UNBIASED var, per-sample affine), BatchNorm2d/1d train mode
@@ -144,14 +147,23 @@ int acg_bn_eval_stats(const float *run_mean, const float *run_var, int C, int Cp
                       void *stream);
 /* y = act((x-mean)*rstd*gamma + beta [+ res]); gamma/beta indexed [g*gstride + c] (gstride 0 or C) */
 int acg_norm_apply(const float *x, const float *mean, const float *rstd, const float *gamma, const float *beta,
-                   int gstride, const float *res, float *y, int G, size_t P, int C, int act, void *stream);
-/* backward: dy (w.r.t. y), y, x -> dx, dres (if has_res; = dy*act'(y)), dgamma/dbeta
- * ([C] summed over groups when gstride==0, else [G*C]).  y may be NULL when no residual was added: the activation
- * mask is then recomputed from x with gamma/beta (one tensor stream less per pass). unbiased as in acg_norm_stats; unbiased == 2 means the
- * statistics were constants (BatchNorm eval mode): dx = gamma*rstd*dy*act'. */
-int acg_norm_bwd(const float *dy, const float *y, const float *x, const float *mean, const float *rstd,
+                   int gstride, const float *res, float *y, unsigned *sign_mask, int G, size_t P, int C, int act,
+                   void *stream);
+/* sign_mask (may be NULL; needs res, ReLU/LeakyReLU, P*C/4 % 8 == 0): ceil(G*P*C/32) words, bit e%32 of word e/32 =
+ * (y[e] > 0).  acg_norm_bwd takes it in place of y: the backward of ReLU(x + IN(conv(..))) (modules.py:185-188, 232-235)
+ * needs only the sign of y, and reads 1/32 of a tensor instead of the tensor, twice. */
+/* backward: dy (w.r.t. y), y, x -> dx, dres (if has_res; = dy*act'(y)), dgamma/dbeta.
+ * gstride == 0 (InstanceNorm / BatchNorm): dgamma/dbeta hold the first `nparam` (real, unpadded) channels, summed over the
+ * groups; accumulate != 0 ADDS them to the destination (pass the parameter's .grad: no separate accumulation kernel).
+ * gstride == C (CondInstanceNorm): dgamma/dbeta are [G*C] (gradients of the per-sample scale / shift), nparam and accumulate
+ * are ignored (must be 0).  y may be NULL when no residual was added: the activation mask is then recomputed from x with
+ * gamma/beta (one tensor stream less per pass).  unbiased as in acg_norm_stats; unbiased == 2 means the statistics were
+ * constants (BatchNorm eval mode): dx = gamma*rstd*dy*act'. */
+int acg_norm_bwd(const float *dy, const float *y, const unsigned *sign_mask, const float *x, const float *mean,
+                 const float *rstd,
                  const float *gamma, const float *beta, int gstride, float *dx, float *dres, float *dgamma, float *dbeta,
-                 int G, size_t P, int C, int act, int unbiased, void *workspace, size_t ws_bytes, void *stream);
+                 int nparam, int accumulate, int G, size_t P, int C, int act, int unbiased, void *workspace, size_t ws_bytes,
+                 void *stream);
 
 /* the two halves of acg_norm_bwd, for SyncBN: local sums[(g*2+{0,1})*C+c] = (sum gy, sum gy*xhat), then — after the
  * caller has all-reduced them — the apply pass with the GLOBAL pixel count Ptot. */

@@ -362,6 +362,36 @@ def test_residual_norm_relu_fusion():
         assert np.max(np.abs(n(p.grad) - P[k].g)) < 2e-4 * np.max(np.abs(P[k].g)) + 2e-6 * gmax, k
 
 
+@pytest.mark.parametrize("shape", [(2, 10, 10, 16), (3, 16, 24, 128), (2, 9, 7, 16), (1, 5, 5, 48)])
+def test_norm_sign_bitmask_equals_reading_y(shape):
+    """The backward of ReLU(res + IN(x)) needs only sign(y): the apply pass stores it as one bit per element and the two
+    backward passes read that instead of y.  Same bits -> bit-identical gradients to the path that reads y; shapes whose
+    float4 count per image is not a multiple of 8 (9x7x16, 5x5x48: 252, 300) fall back to reading y."""
+    from hip_util import t, n
+    from dtgan_amd import ops
+    N, H, W, C = shape
+    rs = np.random.RandomState(H * W + C)
+    x, res, r = (rs.normal(0, 1, shape).astype(np.float32) for _ in range(3))
+    gam, bet = rs.normal(1, 0.3, C).astype(np.float32), rs.normal(0, 0.3, C).astype(np.float32)
+    out = {}
+    for use_mask in (True, False):
+        ops.NORM_SIGN_MASK = use_mask
+        try:
+            xt, rt, gt, bt = t(x, grad=True), t(res, grad=True), t(gam, grad=True), t(bet, grad=True)
+            y = ops.NormAct.apply(xt, gt, bt, rt, "in", ops.ACT_RELU, 1e-5, gt.detach(), bt.detach(), None, None, 0.0)
+            y.backward(t(r))
+            out[use_mask] = [n(v) for v in (y, xt.grad, rt.grad, gt.grad, bt.grad)]
+        finally:
+            ops.NORM_SIGN_MASK = True
+    for a, b in zip(out[True], out[False]):
+        assert np.array_equal(a, b)
+    # and against the formula
+    mu = x.mean(axis=(1, 2), keepdims=True); var = x.var(axis=(1, 2), keepdims=True)
+    yy = np.maximum(res + (x - mu) / np.sqrt(var + 1e-5) * gam + bet, 0)
+    assert np.allclose(out[True][0], yy, rtol=1e-4, atol=1e-5)
+    assert np.allclose(out[True][2], r * (yy > 0), rtol=0, atol=0)
+
+
 def test_losses_and_optimizer():
     from hip_util import t, n
     from dtgan_amd import ops
@@ -458,7 +488,7 @@ def test_c_abi_error_convention():
     ok = _lib.ConvDesc(1, 8, 8, 16, 8, 8, 16, 3, 1, 1, 1, 0, 0)           # reflect dgrad needs a workspace
     assert lib.acg_conv2d_bwd_data(ctypes.byref(ok), P(y), P(w), P(x), None, 0, st) == -2
     assert b"workspace" in lib.acg_last_error()
-    assert lib.acg_conv2d_bwd_weight(ctypes.byref(ok), P(x), P(y), P(w), None, 16, 16, None, 0, st) == -1
+    assert lib.acg_conv2d_bwd_weight(ctypes.byref(ok), P(x), P(y), P(w), None, 16, 16, None, 0, 0, st) == -1
     assert lib.acg_norm_stats(P(x), 1, 64, 18, 1e-5, 0, P(y), P(y), None, None, 0.0, P(w), 1 << 20, st) == -1   # C % 4
     assert lib.acg_set_conv_precision(7) == -1 and lib.acg_set_conv_impl(9) == -1
     with pytest.raises(_lib.AcgError):

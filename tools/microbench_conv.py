@@ -74,13 +74,13 @@ def main():
             calls = {
                 "fwd": lambda: _lib.call("acg_conv_transpose2d_fwd", ctypes.byref(d), P(dy), P(pk.wb), P(pk.bias), P(dx), 0, st),
                 "dgrad": lambda: _lib.call("acg_conv_transpose2d_bwd_data", ctypes.byref(d), P(x), P(pk.wf), P(y), st),
-                "wgrad": lambda: _lib.call("acg_conv_transpose2d_bwd_weight", ctypes.byref(d), P(dy), P(x), P(dw), P(db), Cor, Cir, P(ws), nb_w, st),
+                "wgrad": lambda: _lib.call("acg_conv_transpose2d_bwd_weight", ctypes.byref(d), P(dy), P(x), P(dw), P(db), Cor, Cir, P(ws), nb_w, 0, st),
             }
         else:
             calls = {
                 "fwd": lambda: _lib.call("acg_conv2d_fwd", ctypes.byref(d), P(x), P(pk.wf), P(pk.bias), P(y), 1, st),
                 "dgrad": lambda: _lib.call("acg_conv2d_bwd_data", ctypes.byref(d), P(dy), P(pk.wb), P(dx), P(ws), nb_d, st),
-                "wgrad": lambda: _lib.call("acg_conv2d_bwd_weight", ctypes.byref(d), P(x), P(dy), P(dw), P(db), Cor, Cir, P(ws), nb_w, st),
+                "wgrad": lambda: _lib.call("acg_conv2d_bwd_weight", ctypes.byref(d), P(x), P(dy), P(dw), P(db), Cor, Cir, P(ws), nb_w, 0, st),
             }
         flops = 2.0 * N * d.Ho * d.Wo * Cor * Cir * K * K
         algo = 4.0 * (N * H * W * Cir + N * d.Ho * d.Wo * Cor + K * K * Cir * Cor)     # each tensor once, real channels
