@@ -40,6 +40,10 @@ struct Geom {
     int fold_p = 0, fold_H = 0, fold_W = 0;
     float *out2 = nullptr;
     const float *addend = nullptr; // fold_p > 0 only: tensor of out2's shape added to the result (residual-path gradient)
+    // fold_p > 0 only: tensor of out2's shape whose SIGN masks the result (value > 0 ? keep : 0) before the addend — the
+    // convolution's own input when that input is the ReLU output of the layer in front: dx is then already the gradient
+    // w.r.t. that layer's pre-activation and its separate activation-backward pass (3 tensor streams) disappears
+    const float *relu_src = nullptr;
     int thin;             // 1: K flattened over (tap, 4 channels): stage s = taps 8s..8s+7, channels 0..3 of each
     int bk8;              // 8-float k-chunks per packed weight slab (Cin/8; thin: 4*ceil(ntaps/8), single slab)
     long long Mtot;       // N*GH*GW

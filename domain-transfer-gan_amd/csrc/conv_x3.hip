@@ -64,6 +64,7 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
     __shared__ __attribute__((aligned(16))) __bf16 lds[L::TOTAL];
     __shared__ float *out_ptr[BM]; // output row of every tile pixel (nullptr past the end)
     __shared__ const float *add_ptr[BM]; // row of Geom.addend to add on the way out (nullptr: none)
+    __shared__ const float *msk_ptr[BM]; // row of Geom.relu_src whose sign masks the result (nullptr: none)
     __shared__ float red[2][2][64]; // [wn][wm][column]: cross-wave fold of the per-tile statistics
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -80,7 +81,7 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
     if (tid < BM) {
         const long long m = m0 + tid;
         float *ptr = nullptr;
-        const float *aptr = nullptr;
+        const float *aptr = nullptr, *mptr = nullptr;
         if (m < g.Mtot) {
             const int n = (int)(m / GHW);
             const int r = (int)(m - (long long)n * GHW);
@@ -95,11 +96,13 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
                     const long long o2 = (((long long)n * g.fold_H + iy) * g.fold_W + ix) * g.Cout;
                     ptr = g.out2 + o2;
                     if (g.addend != nullptr) aptr = g.addend + o2;
+                    if (g.relu_src != nullptr) mptr = g.relu_src + o2;
                 }
             }
         }
         out_ptr[tid] = ptr;
         add_ptr[tid] = aptr;
+        msk_ptr[tid] = mptr;
     }
 
     if (wave >= 4) {
@@ -391,6 +394,12 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
         float *dst = out_ptr[row];
         if (dst != nullptr && n0 + c4 * 4 < g.Cout) {
             f32x4 v = *(const f32x4 *)&tile[row * TS + c4 * 4];
+            const float *mp = msk_ptr[row];
+            if (mp != nullptr) {
+                const f32x4 mv = *(const f32x4 *)(mp + n0 + c4 * 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = mv[q] > 0.f ? v[q] : 0.f;
+            }
             const float *ap = add_ptr[row];
             if (ap != nullptr) v += *(const f32x4 *)(ap + n0 + c4 * 4);
             *(f32x4 *)(dst + n0 + c4 * 4) = v;

@@ -66,13 +66,14 @@ class Conv2d(nn.Conv2d, _Cached):
     def packed(self):
         return self._cached(lambda: ops.PackedConv(self.weight, self.bias, cpad(self.in_channels), cpad(self.out_channels)))
 
-    def forward_nhwc(self, x, act=ACT_NONE, reflect_pad=0, want_stats=False, want_identity=False):
+    def forward_nhwc(self, x, act=ACT_NONE, reflect_pad=0, want_stats=False, want_identity=False, link_out=None,
+                     link_in=None):
         if reflect_pad:
             pad, mode = reflect_pad, PAD_REFLECT
         else:
             pad, mode = self.padding[0], PAD_ZERO
         return ops.Conv2dFn.apply(x, self.weight, self.bias, self.packed(), self.stride[0], pad, mode, act, want_stats,
-                                  want_identity)
+                                  want_identity, link_out, link_in)
 
     def forward(self, input):
         return ops.ToNCHW.apply(self.forward_nhwc(ops.ToNHWC.apply(input)), self.out_channels)
@@ -273,6 +274,7 @@ def run_sequence(mods, x, C, z=None, res=None):
                      or (isinstance(m, MergeModule))] + [-1]) if res is not None else -1
     reflect = 0
     skip_routed = False
+    relu_link = None   # set by a conv+ReLU whose output goes straight into the next convolution (ops.ReluLink)
     while i < n:
         m = mods[i]
         if isinstance(m, nn.ReflectionPad2d):
@@ -313,7 +315,14 @@ def run_sequence(mods, x, C, z=None, res=None):
             x = conv.forward_nhwc(x, cact)
         else:  # an (Cond)InstanceNorm right behind the conv can take its statistics from the conv epilogue
             skip_here = res is not None and not skip_routed and x is res  # the block's FIRST convolution
-            x = conv.forward_nhwc(x, cact, reflect, isinstance(norm, (InstanceNorm, CondInstanceNorm)), skip_here)
+            link_in, relu_link = relu_link, None
+            link_out = None
+            if cact == ACT_RELU:  # pad-conv-ReLU-pad-conv: the next convolution's data gradient applies this ReLU's mask
+                k = i + 1 if (i < n and isinstance(mods[i], nn.ReflectionPad2d)) else i
+                if k < n and isinstance(mods[k], Conv2d):
+                    link_out = relu_link = ops.ReluLink()
+            x = conv.forward_nhwc(x, cact, reflect, isinstance(norm, (InstanceNorm, CondInstanceNorm)), skip_here,
+                                  link_out, link_in)
             if skip_here:  # the skip connection continues from the conv's identity output: its gradient is added
                 x, res = x  # inside that conv's data-gradient epilogue
                 skip_routed = True

@@ -253,6 +253,20 @@ def _grads_done(*params):
                 h(p)
 
 
+class ReluLink(object):
+    """Hand-off between the two convolutions of a pad-conv-ReLU-pad-conv chain (ResnetBlock, modules.py:211-227): the
+    SECOND convolution's data-gradient epilogue can mask its result with the sign of its own input (= the first one's ReLU
+    output), which makes it the gradient w.r.t. the first convolution's pre-activation; it then sets `done`, and the first
+    convolution's backward skips its activation-backward pass (3 tensor streams).  Valid only where the ReLU output has no
+    other consumer."""
+
+    def __init__(self):
+        self.done = False
+
+
+RELU_LINK = os.environ.get("ACGAN_NO_RELU_LINK") is None   # A/B switch
+
+
 class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d (+ preceding ReflectionPad2d) + bias + fused activation.  want_stats: the caller runs an
     (Cond)InstanceNorm on the output next — where the kernel supports it the epilogue emits that norm's per-tile
@@ -261,7 +275,8 @@ class Conv2dFn(torch.autograd.Function):
     inside the data-gradient epilogue (acg_conv2d_bwd_data_add) instead of by a separate autograd accumulation."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, packed, stride, pad, pad_mode, act, want_stats=False, want_identity=False):
+    def forward(ctx, x, weight, bias, packed, stride, pad, pad_mode, act, want_stats=False, want_identity=False,
+                link_out=None, link_in=None):
         x = x.contiguous()
         _check(x)
         N, Hi, Wi, Ci = x.shape
@@ -292,6 +307,7 @@ class Conv2dFn(torch.autograd.Function):
                 t.kernel = _lib.query("acg_last_kernel").decode()   # what the dispatcher actually launched
         ctx.d, ctx.packed, ctx.act, ctx.has_bias = d, packed, act, bias is not None
         ctx.wparam, ctx.bparam = weight, bias
+        ctx.link_out, ctx.link_in = (link_out if act == ACT_RELU else None), link_in
         ctx.save_for_backward(x, y if act != ACT_NONE else None)
         if want_identity:
             return y, x.view_as(x)
@@ -303,7 +319,10 @@ class Conv2dFn(torch.autograd.Function):
         d, pk = ctx.d, ctx.packed
         dy = dy.contiguous()
         st = _stream()
-        if ctx.act != ACT_NONE:
+        if ctx.link_out is not None and ctx.link_out.done:
+            ctx.link_out.done = False   # the consumer's data-gradient epilogue already applied this ReLU's mask
+            g = dy
+        elif ctx.act != ACT_NONE:
             g = torch.empty_like(dy)
             _lib.call("acg_act_bwd", _ptr(dy), _ptr(y), _ptr(g), dy.numel(), ctx.act, st)
         else:
@@ -316,6 +335,10 @@ class Conv2dFn(torch.autograd.Function):
             if dskip is not None and _lib.query("acg_conv2d_bwd_data_add_supported", ctypes.byref(d)):
                 _lib.call("acg_conv2d_bwd_data_add", ctypes.byref(d), _ptr(g), _ptr(pk.wb), _ptr(dskip.contiguous()), _ptr(dx),
                           _ptr(ws), nb, st)
+            elif (dskip is None and ctx.link_in is not None and RELU_LINK
+                  and _lib.query("acg_conv2d_bwd_data_add_supported", ctypes.byref(d))):
+                _lib.call("acg_conv2d_bwd_data_relu", ctypes.byref(d), _ptr(g), _ptr(pk.wb), _ptr(x), _ptr(dx), _ptr(ws), nb, st)
+                ctx.link_in.done = True
             else:
                 _lib.call("acg_conv2d_bwd_data", ctypes.byref(d), _ptr(g), _ptr(pk.wb), _ptr(dx), _ptr(ws), nb, st)
                 if dskip is not None:
@@ -334,7 +357,7 @@ class Conv2dFn(torch.autograd.Function):
             if direct is not None:
                 dw = db = None
                 _grads_done(ctx.wparam, ctx.bparam)
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
 class ConvTranspose2dFn(torch.autograd.Function):

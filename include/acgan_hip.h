@@ -112,6 +112,11 @@ int acg_conv2d_bwd_data(const acg_conv_desc *d, const float *dy, const float *wb
 int acg_conv2d_bwd_data_add_supported(const acg_conv_desc *d);
 int acg_conv2d_bwd_data_add(const acg_conv_desc *d, const float *dy, const float *wb, const float *addend, float *dx,
                             void *ws, size_t ws_bytes, void *stream);
+/* dx = data gradient * (x > 0), x = this convolution's own INPUT when that input is the ReLU output of the layer in front
+ * (ResnetBlock: pad-conv-ReLU-pad-conv, modules.py:211-227): dx is then the gradient w.r.t. that layer's PRE-activation and
+ * its separate activation-backward pass is skipped (torch runs threshold_backward there).  Same support query as _add. */
+int acg_conv2d_bwd_data_relu(const acg_conv_desc *d, const float *dy, const float *wb, const float *x, float *dx,
+                             void *ws, size_t ws_bytes, void *stream);
 /* weight (+bias) gradient: x, dy -> dw in torch OIHW layout (Or x Ir real channels), db[Or] (may be NULL).
  * Deterministic split-K over pixels with a second-stage reduction (no atomics).  accumulate != 0: the result is ADDED to
  * dw / db — pass the parameter's .grad (what autograd's AccumulateGrad does after loss.backward(), model.py:445, 509,
