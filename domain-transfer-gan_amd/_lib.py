@@ -54,7 +54,8 @@ SIGNATURES = {
     "acg_norm_workspace_bytes": (c_size_t, [c_int, c_size_t, c_int]),
     "acg_conv2d_fwd_stats_supported": (c_int, [_P]),
     "acg_conv2d_bwd_data_add_supported": (c_int, [_P]),
-    "acg_conv2d_bwd_data_add": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "acg_conv2d_bwd_data_add": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "acg_mask_apply": (c_int, [_P, _P, _P, c_size_t, _P]),
     "acg_conv2d_bwd_data_relu": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "acg_conv2d_fwd_stats": (c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "acg_norm_stats_from_partials": (c_int, [_P, c_int, c_size_t, c_int, c_int, c_float, c_int, _P, _P, _P]),

@@ -348,7 +348,8 @@ __global__ void reflect_fold_kernel(const float *__restrict__ dxp, float *__rest
 // H-1-p..H-2).  Used when the data-gradient kernel already stored every other pixel straight into dx (Geom.fold_p):
 // 2p rows x W plus 2p columns x (H - 2p) pixels per image instead of all H x W.
 __global__ void reflect_fold_frame_kernel(const float *__restrict__ dxp, float *__restrict__ dx, int N, int H, int W, int C,
-                                          int p, const float *__restrict__ addend, const float *__restrict__ relu_src)
+                                          int p, const float *__restrict__ addend, const float *__restrict__ relu_src,
+                                          const unsigned *__restrict__ addend_mask)
 {
     const int C4 = C / 4;
     const int nrow = 2 * p * W, ncol = 2 * p * (H - 2 * p); // frame pixels per image: dirty rows, then dirty columns
@@ -387,7 +388,16 @@ __global__ void reflect_fold_frame_kernel(const float *__restrict__ dxp, float *
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[q] = mv[q] > 0.f ? acc[q] : 0.f;
         }
-        if (addend != nullptr) acc += *(const f32x4 *)(addend + o);
+        if (addend != nullptr) {
+            f32x4 av = *(const f32x4 *)(addend + o);
+            if (addend_mask != nullptr) {
+                const long long f = o >> 2;
+                const unsigned nb = (addend_mask[f >> 3] >> (4 * (int)(f & 7))) & 15u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) av[q] = (nb >> q) & 1u ? av[q] : 0.f;
+            }
+            acc += av;
+        }
         *(f32x4 *)(dx + o) = acc;
     }
 }
@@ -648,7 +658,7 @@ static bool dgrad_frame_ok(const acg_conv_desc *d, const Geom &g)
 
 static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb, const float *bias, float *dst,
                        int act, void *ws, size_t ws_bytes, hipStream_t st, const float *addend = nullptr,
-                       const float *relu_src = nullptr)
+                       const float *relu_src = nullptr, const unsigned *addend_mask = nullptr)
 {
     Geom g; Taps t;
     g.Hin = d->Ho; g.Win = d->Wo; g.Cin = d->Co;
@@ -684,14 +694,14 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
         const bool frame = refl && dgrad_frame_ok(d, g);
         ACG_REQUIRE((addend == nullptr && relu_src == nullptr) || frame,
                     "dgrad: the fused addend / ReLU mask need the frame path (query acg_conv2d_bwd_data_add_supported)");
-        if (frame) { g.fold_p = p; g.fold_H = d->Hi; g.fold_W = d->Wi; g.out2 = dst; g.addend = addend; g.relu_src = relu_src; }
+        if (frame) { g.fold_p = p; g.fold_H = d->Hi; g.fold_W = d->Wi; g.out2 = dst; g.addend = addend; g.relu_src = relu_src; g.addend_mask = addend_mask; }
         int rc = thin_in_valu_dgrad(d) ? thin_out_launch(src, wb, bias, out, g, t, st) : acg_igemm_launch(src, wb, bias, out, g, t, st);
         if (rc != ACG_OK) return rc;
         if (frame) {
             const long long total = (long long)d->N * (2 * p * d->Wi + 2 * p * (d->Hi - 2 * p)) * (d->Ci / 4);
             const int blocks = acg_cdiv(total, 256) > 4096 ? 4096 : acg_cdiv(total, 256);
             hipLaunchKernelGGL(reflect_fold_frame_kernel, dim3(blocks), dim3(256), 0, st, (const float *)ws, dst, d->N, d->Hi,
-                               d->Wi, d->Ci, p, addend, relu_src);
+                               d->Wi, d->Ci, p, addend, relu_src, addend_mask);
             ACG_CHECK_LAUNCH("reflect_fold_frame_kernel");
         } else if (refl) {
             const long long total = (long long)d->N * d->Hi * d->Wi * (d->Ci / 4);
@@ -806,12 +816,14 @@ extern "C" int acg_conv2d_bwd_data_add_supported(const acg_conv_desc *d)
 }
 
 extern "C" int acg_conv2d_bwd_data_add(const acg_conv_desc *d, const float *dy, const float *wb, const float *addend,
-                                       float *dx, void *ws, size_t ws_bytes, void *stream)
+                                       const unsigned *addend_mask, float *dx, void *ws, size_t ws_bytes, void *stream)
 {
     int rc = check_desc(d, "acg_conv2d_bwd_data_add");
     if (rc) return rc;
     ACG_REQUIRE(addend != nullptr && acg_conv2d_bwd_data_add_supported(d), "acg_conv2d_bwd_data_add: unsupported shape or mode");
-    return dgrad_igemm(d, dy, wb, nullptr, dx, ACG_ACT_NONE, ws, ws_bytes, (hipStream_t)stream, addend);
+    ACG_REQUIRE(addend_mask == nullptr || ((long long)d->Hi * d->Wi * (d->Ci / 4)) % 8 == 0,
+                "acg_conv2d_bwd_data_add: the sign bitmask layout needs Hi*Wi*Ci/4 %% 8 == 0");
+    return dgrad_igemm(d, dy, wb, nullptr, dx, ACG_ACT_NONE, ws, ws_bytes, (hipStream_t)stream, addend, nullptr, addend_mask);
 }
 
 extern "C" int acg_conv2d_bwd_data_relu(const acg_conv_desc *d, const float *dy, const float *wb, const float *x,

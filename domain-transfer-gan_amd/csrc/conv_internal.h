@@ -40,6 +40,9 @@ struct Geom {
     int fold_p = 0, fold_H = 0, fold_W = 0;
     float *out2 = nullptr;
     const float *addend = nullptr; // fold_p > 0 only: tensor of out2's shape added to the result (residual-path gradient)
+    // optional sign bitmask of the addend (norm.hip layout: bit e%32 of word e/32 for float index e): only elements whose
+    // bit is set are added — the skip gradient dy * (y > 0) of ReLU(x + IN(..)) without materialising it
+    const unsigned *addend_mask = nullptr;
     // fold_p > 0 only: tensor of out2's shape whose SIGN masks the result (value > 0 ? keep : 0) before the addend — the
     // convolution's own input when that input is the ReLU output of the layer in front: dx is then already the gradient
     // w.r.t. that layer's pre-activation and its separate activation-backward pass (3 tensor streams) disappears

@@ -401,7 +401,16 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
                 for (int q = 0; q < 4; ++q) v[q] = mv[q] > 0.f ? v[q] : 0.f;
             }
             const float *ap = add_ptr[row];
-            if (ap != nullptr) v += *(const f32x4 *)(ap + n0 + c4 * 4);
+            if (ap != nullptr) {
+                f32x4 av = *(const f32x4 *)(ap + n0 + c4 * 4);
+                if (g.addend_mask != nullptr) {
+                    const long long f = ((ap - g.addend) + n0 + c4 * 4) >> 2;   // float4 index of these 4 elements
+                    const unsigned nb = (g.addend_mask[f >> 3] >> (4 * (int)(f & 7))) & 15u;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) av[q] = (nb >> q) & 1u ? av[q] : 0.f;
+                }
+                v += av;
+            }
             *(f32x4 *)(dst + n0 + c4 * 4) = v;
         }
     }

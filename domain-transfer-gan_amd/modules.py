@@ -216,9 +216,9 @@ class InstanceNorm(nn.Module, _Cached):
         dev = self.scale.device
         return torch.ones(C, device=dev), torch.zeros(C, device=dev)
 
-    def forward_act(self, x, act=ACT_NONE, res=None):
+    def forward_act(self, x, act=ACT_NONE, res=None, lazy_dres=False):
         g, b = self._gb()
-        return ops.NormAct.apply(x, self.scale, self.shift, res, "in", act, self.eps, g, b, None, None, 0.0)
+        return ops.NormAct.apply(x, self.scale, self.shift, res, "in", act, self.eps, g, b, None, None, 0.0, lazy_dres)
 
     def forward(self, input):
         return ops.ToNCHW.apply(self.forward_act(ops.ToNHWC.apply(input)), self.num_features)
@@ -337,7 +337,9 @@ def run_sequence(mods, x, C, z=None, res=None):
                     raise NotImplementedError("residual after CondInstanceNorm")
                 x = norm.forward_act(x, z, act)
             elif isinstance(norm, InstanceNorm):
-                x = norm.forward_act(x, ACT_RELU if fuse_res else act, res if fuse_res else None)
+                # skip_routed: `res` is the identity output of the block's first convolution, i.e. its gradient goes to that
+                # convolution's data-gradient epilogue and nowhere else -> it may stay un-materialised (ops.NormAct lazy_dres)
+                x = norm.forward_act(x, ACT_RELU if fuse_res else act, res if fuse_res else None, fuse_res and skip_routed)
             else:
                 if fuse_res:
                     raise NotImplementedError("residual after BatchNorm")

@@ -253,6 +253,20 @@ def _grads_done(*params):
                 h(p)
 
 
+# Skip gradient of ReLU(res + norm(x)) handed from NormAct.backward to the data-gradient epilogue of the convolution whose
+# identity output `res` is: instead of writing dres = dy * (y > 0) (one tensor stream) NormAct returns dy itself and leaves
+# the sign bitmask here, keyed by dy's address; Conv2dFn.backward picks it up with its `dskip`.
+_SKIP_MASKS = {}
+LAZY_DRES = os.environ.get("ACGAN_NO_LAZY_DRES") is None   # A/B switch
+
+
+def take_skip_mask(dskip):
+    m = _SKIP_MASKS.pop(dskip.data_ptr(), None)
+    if m is not None and m[1].shape == dskip.shape:
+        return m[0]
+    return None
+
+
 class ReluLink(object):
     """Hand-off between the two convolutions of a pad-conv-ReLU-pad-conv chain (ResnetBlock, modules.py:211-227): the
     SECOND convolution's data-gradient epilogue can mask its result with the sign of its own input (= the first one's ReLU
@@ -332,9 +346,15 @@ class Conv2dFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             nb = _lib.query("acg_conv2d_bwd_data_workspace_bytes", ctypes.byref(d))
             ws = workspace(nb) if nb else None
-            if dskip is not None and _lib.query("acg_conv2d_bwd_data_add_supported", ctypes.byref(d)):
-                _lib.call("acg_conv2d_bwd_data_add", ctypes.byref(d), _ptr(g), _ptr(pk.wb), _ptr(dskip.contiguous()), _ptr(dx),
+            smask = None
+            if dskip is not None:
+                dskip = dskip.contiguous()
+                smask = take_skip_mask(dskip)   # the skip gradient is dskip * sign-bitmask (NormAct lazy_dres)
+            if dskip is not None and _lib.query("acg_conv2d_bwd_data_add_supported", ctypes.byref(d)) and \
+                    (smask is None or (d.Hi * d.Wi * (d.Ci // 4)) % 8 == 0):
+                _lib.call("acg_conv2d_bwd_data_add", ctypes.byref(d), _ptr(g), _ptr(pk.wb), _ptr(dskip), _ptr(smask), _ptr(dx),
                           _ptr(ws), nb, st)
+                smask = None
             elif (dskip is None and ctx.link_in is not None and RELU_LINK
                   and _lib.query("acg_conv2d_bwd_data_add_supported", ctypes.byref(d))):
                 _lib.call("acg_conv2d_bwd_data_relu", ctypes.byref(d), _ptr(g), _ptr(pk.wb), _ptr(x), _ptr(dx), _ptr(ws), nb, st)
@@ -342,6 +362,10 @@ class Conv2dFn(torch.autograd.Function):
             else:
                 _lib.call("acg_conv2d_bwd_data", ctypes.byref(d), _ptr(g), _ptr(pk.wb), _ptr(dx), _ptr(ws), nb, st)
                 if dskip is not None:
+                    if smask is not None:   # not fusable here: materialise the masked skip gradient
+                        m = torch.empty_like(dskip)
+                        _lib.call("acg_mask_apply", _ptr(dskip), _ptr(smask), _ptr(m), dskip.numel(), st)
+                        dskip = m
                     dx = dx + dskip
         if ctx.needs_input_grad[1]:
             direct = _direct_grad(ctx.wparam, ctx.bparam)
@@ -434,7 +458,7 @@ class NormAct(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, res, kind, act, eps, gamma_p, beta_p, run_mean, run_var, momentum):
+    def forward(ctx, x, gamma, beta, res, kind, act, eps, gamma_p, beta_p, run_mean, run_var, momentum, lazy_dres=False):
         x = x.contiguous()
         _check(x)
         C = x.shape[-1]
@@ -480,6 +504,8 @@ class NormAct(torch.autograd.Function):
                   G, P, C, act, st)
         ctx.cfg = (kind, act, G, P, C, unbiased, gstride, res is not None, gamma.shape)
         ctx.gparam, ctx.bparam = (gamma, beta) if kind != "cin" else (None, None)
+        # lazy_dres: the caller guarantees that the gradient w.r.t. `res` goes (only) to a Conv2dFn's skip input
+        ctx.lazy_dres = bool(lazy_dres and LAZY_DRES and mask is not None)
         ctx.save_for_backward(x, y if (need_y and mask is None) else None, mean, rstd, gp, bp, mask)
         return y
 
@@ -489,7 +515,7 @@ class NormAct(torch.autograd.Function):
         kind, act, G, P, C, unbiased, gstride, has_res, gshape = ctx.cfg
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dres = torch.empty_like(x) if has_res else None
+        dres = torch.empty_like(x) if (has_res and not ctx.lazy_dres) else None
         direct = _direct_grad(ctx.gparam, ctx.bparam) if (kind != "cin" and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]) else None
         if direct is not None:      # shared affine parameters: add into their .grad (first gshape[0] = real channels)
             dgamma, dbeta = direct
@@ -511,7 +537,12 @@ class NormAct(torch.autograd.Function):
             dg, db = dgamma, dbeta
         if has_res and act == ACT_NONE:
             dres = dy
-        return dx, dg, db, dres, None, None, None, None, None, None, None, None
+        elif ctx.lazy_dres:
+            if len(_SKIP_MASKS) > 64:   # entries nobody collected (a skip whose convolution needed no input gradient)
+                _SKIP_MASKS.clear()
+            _SKIP_MASKS[dy.data_ptr()] = (mask, dy)
+            dres = dy
+        return dx, dg, db, dres, None, None, None, None, None, None, None, None, None
 
 
 class SyncBatchNormAct(torch.autograd.Function):

@@ -110,8 +110,10 @@ int acg_conv2d_bwd_data(const acg_conv_desc *d, const float *dy, const float *wb
  * ResnetBlock's skip connection (modules.py:185-188, 232-235) joins the gradient of the block's first convolution without
  * a separate element-wise pass.  Supported (query first) where the reflect data gradient takes its frame path. */
 int acg_conv2d_bwd_data_add_supported(const acg_conv_desc *d);
-int acg_conv2d_bwd_data_add(const acg_conv_desc *d, const float *dy, const float *wb, const float *addend, float *dx,
-                            void *ws, size_t ws_bytes, void *stream);
+int acg_conv2d_bwd_data_add(const acg_conv_desc *d, const float *dy, const float *wb, const float *addend,
+                            const unsigned *addend_sign_mask, float *dx, void *ws, size_t ws_bytes, void *stream);
+/* addend_sign_mask (may be NULL): acg_norm_apply's sign bitmask of the block output; only elements whose bit is set are
+ * added, i.e. the skip gradient dy * (y > 0) is formed here from dy itself and never written to memory. */
 /* dx = data gradient * (x > 0), x = this convolution's own INPUT when that input is the ReLU output of the layer in front
  * (ResnetBlock: pad-conv-ReLU-pad-conv, modules.py:211-227): dx is then the gradient w.r.t. that layer's PRE-activation and
  * its separate activation-backward pass is skipped (torch runs threshold_backward there).  Same support query as _add. */
@@ -177,6 +179,10 @@ int acg_norm_bwd_sums(const float *dy, const float *y, const float *x, const flo
 int acg_norm_bwd_apply(const float *dy, const float *y, const float *x, const float *mean, const float *rstd,
                        const float *gamma, int gstride, const float *sums, float *dx, float *dres, int G, size_t P,
                        size_t Ptot, int C, int act, int unbiased, void *stream);
+
+/* out = x where the sign-bitmask bit (acg_norm_apply layout) is set, else 0 — the materialised form of a masked skip
+ * gradient, for the paths that cannot fuse it (n % 4 == 0) */
+int acg_mask_apply(const float *x, const unsigned *sign_mask, float *out, size_t n, void *stream);
 
 /* ---- elementwise ---- */
 int acg_act_bwd(const float *dy, const float *y, float *dx, size_t n, int act, void *stream); /* dx = dy*act'(y) */

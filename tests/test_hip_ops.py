@@ -320,6 +320,8 @@ def test_resnet_block_128_fused_paths(prec):
             _lib.call = real
         fused = "acg_conv2d_bwd_data_add" in calls and "acg_conv2d_fwd_stats" in calls
         assert fused == (prec == "bf16x3"), sorted(set(calls))
+        # bf16x3 also: the first convolution's ReLU is undone in the second one's data-gradient epilogue (no act_bwd pass)
+        assert ("acg_conv2d_bwd_data_relu" in calls and "acg_act_bwd" not in calls) == (prec == "bf16x3"), sorted(set(calls))
         X, W1, B1, W2, B2, S, Sh = (leaf(a) for a in (x, w1, b1, w2, b2, sc, sh))
         h = oops.relu(oops.conv2d(X, W1, B1, stride=1, pad=1, pad_mode="reflect"))
         yo = oops.relu(oops.add(X, oops.instance_norm(oops.conv2d(h, W2, B2, stride=1, pad=1, pad_mode="reflect"), S, Sh)))
@@ -328,6 +330,41 @@ def test_resnet_block_128_fused_paths(prec):
         assert rel(n(xt.grad), X.g) < 2e-4
         assert rel(n(cb[1].weight.grad), W1.g) < 2e-4
         assert rel(n(cb[4].weight.grad), W2.g) < 2e-4
+
+
+@pytest.mark.parametrize("switch", ["RELU_LINK", "LAZY_DRES", "NORM_SIGN_MASK", "DIRECT_GRAD"])
+def test_backward_fusions_are_bit_identical_to_the_separate_passes(switch):
+    """Each fused route of a ResnetBlock's backward — ReLU mask in the data-gradient epilogue, the skip gradient formed from
+    dy and the sign bitmask inside the first convolution's epilogue, the bitmask itself, parameter gradients added straight
+    into .grad — computes the same values in the same order as the separate pass it replaces: bit-identical results."""
+    from hip_util import t, n
+    from dtgan_amd import modules as M, ops
+    from dtgan_amd.model import FlatNet
+    N, C, H, W = 2, 128, 16, 32
+    rs = np.random.RandomState(9)
+    x, r = rs.normal(0.1, 1.0, (N, C, H, W)).astype(np.float32), rs.normal(0, 1, (N, C, H, W)).astype(np.float32)
+    torch.manual_seed(3)
+    blks = [M.ResnetBlock(C, "reflect", M.InstanceNorm, False, True).cuda() for _ in range(2)]
+    net = torch.nn.Sequential(*blks)
+    with torch.no_grad():
+        for b in blks:
+            b.conv_block[5].scale.normal_(1.0, 0.3); b.conv_block[5].shift.normal_(0, 0.3)
+    flat = FlatNet(net)   # parameters / .grad as views of flat buffers, as inside the model
+    res = {}
+    for on in (True, False):
+        setattr(ops, switch, on)
+        try:
+            flat.zero_grad()
+            xt = t(x, grad=True)
+            h = ops.ToNHWC.apply(xt * 1.0)
+            for b in blks:
+                h = b.forward_nhwc(h)
+            ops.ToNCHW.apply(h, C).backward(t(r))
+            res[on] = [n(xt.grad), n(flat.gv)]
+        finally:
+            setattr(ops, switch, True)
+    assert np.array_equal(res[True][0], res[False][0]) and np.array_equal(res[True][1], res[False][1])
+    assert np.abs(res[True][1]).max() > 0
 
 
 def test_residual_norm_relu_fusion():
