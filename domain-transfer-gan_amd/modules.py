@@ -208,6 +208,7 @@ class InstanceNorm(nn.Module, _Cached):
         if self.affine:
             self.scale.data.normal_(mean=0., std=0.02)
             self.shift.data.zero_()
+        self._acg_cache = None
 
     def _gb(self):
         C = cpad(self.num_features)

@@ -20,7 +20,7 @@ import torch.nn as nn
 from . import ops
 from .modules import (ResnetBlock, CondInstanceNorm, TwoInputSequential, CINResnetBlock, InstanceNorm2d,  # noqa: F401
                       Conv2d, ConvTranspose2d, BatchNorm2d, BatchNorm1d, Linear, Sequential, run_sequence,
-                      run_dense, as_latent)
+                      run_dense, as_latent, mark_dirty)
 
 
 ###############################################################################
@@ -29,6 +29,8 @@ from .modules import (ResnetBlock, CondInstanceNorm, TwoInputSequential, CINResn
 def weights_init(m):
     """networks.py:13-21"""
     classname = m.__class__.__name__
+    if getattr(m, "_acg_cache", None) is not None:
+        m._acg_cache = None   # `.data` writes below do not bump tensor versions: drop the layer's packed copies by hand
     if classname.find('Conv') != -1:
         m.weight.data.normal_(0.0, 0.02)
         if hasattr(m.bias, 'data'):
