@@ -34,6 +34,7 @@ SIGNATURES = {
     "acg_last_kernel": (ctypes.c_char_p, []),
     "acg_set_conv_impl": (c_int, [c_int]),
     "acg_set_conv_precision": (c_int, [c_int]),
+    "acg_minmax_scale_nhwc_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "acg_nchw_to_nhwc16": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "acg_nhwc16_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "acg_concat_channels": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_size_t, _P]),

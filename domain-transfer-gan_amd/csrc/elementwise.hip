@@ -96,6 +96,50 @@ extern "C" int acg_nhwc16_to_nchw(const float *src, float *dst, int N, int C, in
     return ACG_OK;
 }
 
+// ---- data path (dataloader.py:17-35): raw fields (N,H,W,Craw) -> first C channels, NaN -> 0, per-sample / per-channel
+// min-max to [-1, 1] (a constant plane -> 0), NCHW.  One workgroup per (sample, channel) plane: min/max over the plane
+// (wave shuffles + LDS), then the scaled plane.  Strided reads (channel c of NHWC rows): this runs once per data set.
+__global__ __launch_bounds__(256) void minmax_scale_kernel(const float *__restrict__ raw, float *__restrict__ out, int C,
+                                                           int Craw, long long HW)
+{
+    __shared__ float smn[4], smx[4];
+    const int n = blockIdx.x / C, c = blockIdx.x % C;
+    const float *src = raw + (long long)n * HW * Craw + c;
+    float mn = INFINITY, mx = -INFINITY;
+    for (long long i = threadIdx.x; i < HW; i += 256) {
+        float v = src[i * Craw];
+        v = (v != v) ? 0.f : v;            // np.nan_to_num: NaN -> 0 (+-inf -> +-FLT_MAX below)
+        v = fminf(fmaxf(v, -3.4028234664e38f), 3.4028234664e38f);
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, o));
+        mx = fmaxf(mx, __shfl_xor(mx, o));
+    }
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+    mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    const float inv = mx > mn ? 2.f / (mx - mn) : 0.f;
+    float *dst = out + ((long long)n * C + c) * HW;
+    for (long long i = threadIdx.x; i < HW; i += 256) {
+        float v = src[i * Craw];
+        v = (v != v) ? 0.f : v;
+        v = fminf(fmaxf(v, -3.4028234664e38f), 3.4028234664e38f);
+        dst[i] = mx > mn ? -1.f + (v - mn) * inv : 0.f;
+    }
+}
+extern "C" int acg_minmax_scale_nhwc_to_nchw(const float *raw, float *out, int N, int H, int W, int Craw, int C, void *stream)
+{
+    ACG_REQUIRE(raw != nullptr && out != nullptr && N > 0 && H > 0 && W > 0 && C > 0 && C <= Craw,
+                "acg_minmax_scale_nhwc_to_nchw: bad arguments (N=%d H=%d W=%d Craw=%d C=%d)", N, H, W, Craw, C);
+    hipLaunchKernelGGL(minmax_scale_kernel, dim3((unsigned)(N * C)), dim3(256), 0, (hipStream_t)stream, raw, out, C, Craw,
+                       (long long)H * W);
+    ACG_CHECK_LAUNCH("minmax_scale_kernel");
+    return ACG_OK;
+}
+
 __global__ void concat_kernel(const float *__restrict__ a, int Ca, int Cap, const float *__restrict__ b, int Cb, int Cbp,
                               float *__restrict__ d, int Cdp, long long npix)
 {

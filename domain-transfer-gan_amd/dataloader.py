@@ -43,6 +43,82 @@ def prepare(arr, grid_size=None):
     return np.ascontiguousarray(np.transpose(arr, (0, 3, 1, 2))).astype('float32')
 
 
+def prepare_on_device(arr, device="cuda", chunk=256):
+    """`prepare` without the resize, with the arithmetic on the GPU (acg_minmax_scale_nhwc_to_nchw): the raw array is
+    streamed through a pinned staging buffer in chunks of `chunk` samples, the normalised NCHW result stays on the device.
+    fp32 throughout (the host path scales in fp64 and rounds once: results agree to ~1e-6)."""
+    from . import _lib, ops
+    arr = np.asarray(arr)
+    if arr.ndim == 3:
+        arr = arr[..., None]
+    N, H, W, Craw = arr.shape
+    C = min(3, Craw)
+    out = torch.empty((N, C, H, W), device=device, dtype=torch.float32)
+    stage = torch.empty((min(chunk, N), H, W, Craw), dtype=torch.float32).pin_memory()
+    dev = torch.empty_like(stage, device=device)
+    for i in range(0, N, chunk):
+        k = min(chunk, N - i)
+        stage[:k].copy_(torch.from_numpy(np.ascontiguousarray(arr[i:i + k], dtype=np.float32)))
+        dev[:k].copy_(stage[:k], non_blocking=True)
+        _lib.call("acg_minmax_scale_nhwc_to_nchw", ops._ptr(dev), ops._ptr(out[i:i + k]), k, H, W, Craw, C, ops._stream())
+        torch.cuda.current_stream().synchronize()      # the staging buffer is reused by the next chunk
+    return out
+
+
+class DevicePrefetcher(object):
+    """Wraps an Aligned/UnalignedIterator: batch k+1 travels host -> device through pinned buffers on a side stream while
+    step k computes (the reference uploads synchronously right before the step, train.py:198-201).  Yields dicts of
+    DEVICE tensors; iteration semantics (lengths, StopIteration, reset) are the wrapped iterator's."""
+
+    def __init__(self, it, device="cuda"):
+        self.it, self.device = it, torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.pinned = {}
+        self.nxt = None
+
+    def __len__(self):
+        return len(self.it)
+
+    def _stage(self):
+        try:
+            batch = next(self.it)
+        except StopIteration:
+            self.nxt = None
+            return
+        out = {}
+        with torch.cuda.stream(self.stream):
+            for k, v in batch.items():
+                if not torch.is_tensor(v):      # bookkeeping entries travel as they are
+                    out[k] = v
+                    continue
+                buf = self.pinned.get((k, tuple(v.shape)))
+                if buf is None:
+                    buf = self.pinned[(k, tuple(v.shape))] = torch.empty(v.shape, dtype=v.dtype).pin_memory()
+                buf.copy_(v)
+                out[k] = buf.to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        self.nxt = (out, ev)
+
+    def __iter__(self):
+        self._stage()
+        return self
+
+    def __next__(self):
+        if self.nxt is None:
+            raise StopIteration
+        out, ev = self.nxt
+        torch.cuda.current_stream().wait_event(ev)
+        for v in out.values():
+            if torch.is_tensor(v):
+                v.record_stream(torch.cuda.current_stream())
+        self.stream.synchronize()       # the pinned buffers are about to be refilled
+        self._stage()
+        return out
+
+    next = __next__
+
+
 def split_train_dev(trainA, trainB, shuffle=True):
     """dataloader.py:42-57: fixed-seed shuffle (python RNG state restored), first DEV_SIZE samples become the dev set"""
     if shuffle:

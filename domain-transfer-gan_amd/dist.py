@@ -52,8 +52,8 @@ def init_from_env(backend=None):
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     if (ws <= 1 and not _FORCE) or is_on():
         return rank(), world_size()
-    if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend is None:   # ACGAN_DP_BACKEND=gloo: tests that put several ranks on one GPU (RCCL wants one GPU per rank)
+        backend = os.environ.get("ACGAN_DP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     td.init_process_group(backend=backend)

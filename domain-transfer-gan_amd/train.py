@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import dist as D, ops
-from .dataloader import AlignedIterator, UnalignedIterator, load_numpy_data, synthetic_data
+from .dataloader import AlignedIterator, DevicePrefetcher, UnalignedIterator, load_numpy_data, synthetic_data
 from .evaluate import eval_mse_A, eval_ubo_B, one_to_three_channels
 from .model import AugmentedCycleGAN, StochCycleGAN
 from .options import TrainOptions, create_sub_dirs
@@ -181,17 +181,39 @@ class Trainer(object):
             visualize_cycle(o, dA, m.generate_cycle(dA, dB, dz), epoch, it, train=False)
         visualize_multi(o, dA, m, epoch, it)
 
+    def _train_batches(self):
+        """this rank's shard of every training batch; on the GPU the next batch is uploaded through pinned memory on a
+        side stream while the current step computes (dataloader.DevicePrefetcher)"""
+        class Sharded(object):          # host-side shard BEFORE the upload: a rank moves only its own rows
+            def __init__(s, it):
+                s.it = it
+
+            def __len__(s):
+                return len(s.it)
+
+            def __iter__(s):
+                iter(s.it)
+                return s
+
+            def __next__(s):
+                d = next(s.it)
+                full = d['A'].size(0)
+                return {'A': self._shard(d['A']), 'B': self._shard(d['B']), 'n': (full, d['B'].size(0))}
+        src = Sharded(self.train_it)
+        return DevicePrefetcher(src) if self.gpu else src
+
     def train_epoch(self, epoch):
         o, m = self.opt, self.model
         seen = 0
-        for data in self.train_it:
+        for data in self._train_batches():
             real_A, real_B = data['A'], data['B']
-            if real_A.size(0) != real_B.size(0):
+            nA, nB = data['n']
+            if nA != nB:
                 continue
-            prior_z_B = real_A.new_empty((real_A.size(0), o.nlatent, 1, 1)).normal_(0, 1)  # train.py:193
+            prior_z_B = torch.empty((nA, o.nlatent, 1, 1)).normal_(0, 1)                 # on the host, train.py:193
             self.total_steps += o.batchSize
             seen += o.batchSize
-            real_A, real_B, prior_z_B = (_cuda(self._shard(t), self.gpu) for t in (real_A, real_B, prior_z_B))
+            prior_z_B = _cuda(self._shard(prior_z_B), self.gpu)
             out = m.train_instance(real_A, real_B, prior_z_B)
             sup_losses = None
             if self.sup_it is not None:

@@ -70,6 +70,10 @@ int acg_set_conv_impl(int impl);
  * Packed weights must be re-packed (acg_pack_conv_weight) after a switch. */
 int acg_set_conv_precision(int prec);
 
+/* ---- data path (dataloader.py:17-35): raw[N,H,W,Craw] -> first C channels, NaN -> 0, per-sample / per-channel min-max
+ *      scaling to [-1, 1] (constant planes -> 0), written NCHW.  Once per data set, on the device. ---- */
+int acg_minmax_scale_nhwc_to_nchw(const float *raw, float *out_nchw, int N, int H, int W, int Craw, int C, void *stream);
+
 /* ---- layout at the API edge (reference tensors are NCHW: dataloader.py:26, model.py:404) ---- */
 int acg_nchw_to_nhwc16(const float *src, float *dst, int N, int C, int H, int W, int Cp, void *stream);
 int acg_nhwc16_to_nchw(const float *src, float *dst, int N, int C, int H, int W, int Cp, void *stream);

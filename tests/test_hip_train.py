@@ -44,3 +44,60 @@ def test_train_driver_end_to_end(tmp_path):
     train_model(args + ["--continue_train", "--epoch_count", "2"])
     log2 = open(os.path.join(d, "results.txt")).read()
     assert "continue_train: loaded" in log2 and log2.count("End of epoch 2 / 2") == 2
+
+
+def test_two_rank_training_driver_with_syncbn(tmp_path):
+    """train.py under data parallelism: 2 ranks (gloo, sharing this box's GPU), --sync_bn, PNG dumps and the per-epoch
+    evaluation on rank 0 only.  Those rank-0-only forwards run BatchNorm in train mode (the reference never calls eval());
+    with SyncBN they must NOT post collectives the other rank never joins (they use local statistics outside a training
+    step) — otherwise this run hangs or pairs a statistics all-reduce with the next step's gradient all-reduce."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["--name", "dp", "--checkpoints_dir", str(tmp_path), "--synthetic", "16", "--grid_size", "64", "--batchSize", "4",
+            "--ngf", "8", "--nef", "8", "--ndf", "8", "--nlatent", "4", "--niter", "1", "--niter_decay", "1", "--print_freq", "4",
+            "--display_freq", "8", "--save_epoch_freq", "1", "--eval_steps", "2", "--num_multi", "2", "--seed", "1", "--sync_bn"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", WORLD_SIZE="2", ACGAN_DP_BACKEND="gloo",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
+    procs = [subprocess.Popen([sys.executable, "-c", "import dtgan_amd; from dtgan_amd.train import train_model; import sys; "
+                               "train_model(sys.argv[1:])"] + args, env=dict(env, RANK=str(r), LOCAL_RANK="0"), cwd=root,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=420)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("2-rank train.py hung (a rank-0-only forward posted a collective?)")
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    d = os.path.join(str(tmp_path), "dp")
+    log = open(os.path.join(d, "results.txt")).read()
+    assert "2 ranks" in log and "End of epoch 2 / 2" in log
+    assert re.search(r"^\[2\] DEV_MSE_A: ", log, re.M) and re.search(r"^\[2\] DEV_BPP_B: ", log, re.M)
+    for f in ("vis_latest/cycle.png", "vis_latest/multi.png", "latest", "best_A"):
+        assert os.path.exists(os.path.join(d, f)), f
+
+
+def test_device_side_data_path(tmp_path):
+    """dataloader.prepare_on_device (min-max normalisation on the GPU, acg_minmax_scale_nhwc_to_nchw) equals the host
+    pipeline that the reference-derived fixture pins; DevicePrefetcher yields the wrapped iterator's batches."""
+    import torch
+    from golden_util import load
+    from dtgan_amd import dataloader as DL
+    arr, _ = load("data_pipeline")
+    for k in ("trainA", "trainB", "testB"):
+        host = DL.prepare(arr["raw/" + k])
+        dev = DL.prepare_on_device(arr["raw/" + k], chunk=64).cpu().numpy()
+        assert dev.shape == host.shape and np.max(np.abs(dev - host)) < 2e-6, k
+    A = np.arange(40, dtype=np.float32).reshape(10, 1, 2, 2)
+    np.random.seed(3)
+    ref = [(b["A"].clone(), b["B"].clone()) for b in DL.UnalignedIterator(A, -A, batch_size=4)]
+    np.random.seed(3)
+    pf = DL.DevicePrefetcher(DL.UnalignedIterator(A, -A, batch_size=4))
+    for epoch in range(2):
+        got = [(b["A"], b["B"]) for b in pf]
+        assert len(got) == 3 and all(g[0].is_cuda for g in got)
+        if epoch == 0:
+            for (ga, gb), (ra, rb) in zip(got, ref):
+                assert torch.equal(ga.cpu(), ra) and torch.equal(gb.cpu(), rb)
