@@ -157,7 +157,7 @@ def cpu_baseline(a):
     return {"value": round(nb / dt, 4), "unit": "images/s", "cores": cores, "cpu": _cpu_model(), "kind": "port",
             "sample": "%d timed steps (after 1 warm-up step) of batch %d of the same %dx%dx%d %d-resblock full Augmented "
                       "CycleGAN step, fp32, %.1f s per step" % (timed, nb, a.size, a.size, a.nc, a.blocks, dt),
-            "note": "plain-C loops, cache-blocked but not register-blocked: SURVEY.md §6 measured the reference's own "
+            "note": "plain-C loops (cache-blocked rows, register-blocked forward strips, no FMA contraction), not a tuned library: SURVEY.md §6 measured the reference's own "
                     "torch-CPU (MKL-DNN) path at 0.45 images/s on 8 threads for the 256x256x3 3-resblock StochCycleGAN step "
                     "(593 GFLOP/pair = 267 GFLOP/s); the 9-resblock full step is 1289 GFLOP/pair, i.e. about 0.2 images/s "
                     "for the real reference on 8 cores.  This port is a baseline, slower than that library path; the GPU/CPU "

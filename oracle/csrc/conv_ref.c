@@ -33,8 +33,11 @@
 
 #define CB 4 /* output (fwd) / input (dgrad) channels that share one streamed row */
 
+#define OWB 16 /* output pixels of a row kept in registers per channel (2 AVX2 vectors x CB channels = 8 accumulators) */
+
 /* forward: xp[N,Ci,Hp,Wp] (pre-padded), w[Co,Ci,K,K], b[Co] or NULL -> y[N,Co,Ho,Wo]
- * y[n,co,oh,ow] = bias, then += terms in (ci, kh, kw) lexicographic order. */
+ * y[n,co,oh,ow] = bias, then += terms in (ci, kh, kw) lexicographic order.  Stride 1: a strip of OWB output pixels x CB
+ * channels lives in registers across the whole (ci, kh, kw) loop (same per-element order, fewer loads/stores). */
 void conv_fwd(const REAL *xp, const REAL *w, const REAL *b, REAL *y,
               int N, int Ci, int Hp, int Wp, int Co, int K, int s, int Ho, int Wo)
 {
@@ -45,10 +48,40 @@ void conv_fwd(const REAL *xp, const REAL *w, const REAL *b, REAL *y,
             for (int oh = 0; oh < Ho; ++oh) {
                 const int co0 = cb * CB, nco = (Co - co0 < CB) ? Co - co0 : CB;
                 REAL *yr[CB];
+                for (int c = 0; c < nco; ++c) yr[c] = y + IDX4(n, co0 + c, oh, 0, Co, Ho, Wo);
+                int ow0 = 0;
+                if (s == 1 && nco == CB) {
+                    const size_t wstep = (size_t)Ci * K * K;     /* weights of consecutive output channels */
+                    for (; ow0 + OWB <= Wo; ow0 += OWB) {
+                        REAL acc[CB][OWB];
+                        for (int c = 0; c < CB; ++c) {
+                            const REAL bias = b ? b[co0 + c] : (REAL)0;
+                            for (int v = 0; v < OWB; ++v) acc[c][v] = bias;
+                        }
+                        for (int ci = 0; ci < Ci; ++ci)
+                            for (int kh = 0; kh < K; ++kh) {
+                                const REAL *restrict xrow = xp + IDX4(n, ci, oh + kh, ow0, Ci, Hp, Wp);
+                                const REAL *restrict wr = w + IDX4(co0, ci, kh, 0, Ci, K, K);
+                                for (int kw = 0; kw < K; ++kw) {
+                                    const REAL w0 = wr[kw], w1 = wr[wstep + kw], w2 = wr[2 * wstep + kw], w3 = wr[3 * wstep + kw];
+                                    for (int v = 0; v < OWB; ++v) {
+                                        const REAL xv = xrow[kw + v];
+                                        acc[0][v] += w0 * xv;
+                                        acc[1][v] += w1 * xv;
+                                        acc[2][v] += w2 * xv;
+                                        acc[3][v] += w3 * xv;
+                                    }
+                                }
+                            }
+                        for (int c = 0; c < CB; ++c)
+                            for (int v = 0; v < OWB; ++v) yr[c][ow0 + v] = acc[c][v];
+                    }
+                }
+                if (ow0 == Wo) continue;
+                /* remainder of the row (and every stride-2 / ragged-channel case): the row itself is the accumulator */
                 for (int c = 0; c < nco; ++c) {
-                    yr[c] = y + IDX4(n, co0 + c, oh, 0, Co, Ho, Wo);
                     const REAL bias = b ? b[co0 + c] : (REAL)0;
-                    for (int ow = 0; ow < Wo; ++ow) yr[c][ow] = bias;
+                    for (int ow = ow0; ow < Wo; ++ow) yr[c][ow] = bias;
                 }
                 for (int ci = 0; ci < Ci; ++ci)
                     for (int kh = 0; kh < K; ++kh) {
@@ -59,9 +92,9 @@ void conv_fwd(const REAL *xp, const REAL *w, const REAL *b, REAL *y,
                                 const REAL wv = w[IDX4(co0 + c, ci, kh, kw, Ci, K, K)];
                                 REAL *restrict yc = yr[c];
                                 if (s == 1)
-                                    for (int ow = 0; ow < Wo; ++ow) yc[ow] += wv * xr[ow];
+                                    for (int ow = ow0; ow < Wo; ++ow) yc[ow] += wv * xr[ow];
                                 else
-                                    for (int ow = 0; ow < Wo; ++ow) yc[ow] += wv * xr[ow * s];
+                                    for (int ow = ow0; ow < Wo; ++ow) yc[ow] += wv * xr[ow * s];
                             }
                         }
                     }
