@@ -66,14 +66,14 @@ class Conv2d(nn.Conv2d, _Cached):
     def packed(self):
         return self._cached(lambda: ops.PackedConv(self.weight, self.bias, cpad(self.in_channels), cpad(self.out_channels)))
 
-    def forward_nhwc(self, x, act=ACT_NONE, reflect_pad=0, want_stats=False, want_identity=False, link_out=None,
-                     link_in=None):
+    def forward_nhwc(self, x, act=ACT_NONE, reflect_pad=0, want_stats=None, want_identity=False, link_out=None,
+                     link_in=None, skip_grad=None):
         if reflect_pad:
             pad, mode = reflect_pad, PAD_REFLECT
         else:
             pad, mode = self.padding[0], PAD_ZERO
         return ops.Conv2dFn.apply(x, self.weight, self.bias, self.packed(), self.stride[0], pad, mode, act, want_stats,
-                                  want_identity, link_out, link_in)
+                                  want_identity, link_out, link_in, skip_grad)
 
     def forward(self, input):
         return ops.ToNCHW.apply(self.forward_nhwc(ops.ToNHWC.apply(input)), self.out_channels)
@@ -217,9 +217,9 @@ class InstanceNorm(nn.Module, _Cached):
         dev = self.scale.device
         return torch.ones(C, device=dev), torch.zeros(C, device=dev)
 
-    def forward_act(self, x, act=ACT_NONE, res=None, lazy_dres=False):
+    def forward_act(self, x, act=ACT_NONE, res=None, lazy_dres=None, stats=None):
         g, b = self._gb()
-        return ops.NormAct.apply(x, self.scale, self.shift, res, "in", act, self.eps, g, b, None, None, 0.0, lazy_dres)
+        return ops.NormAct.apply(x, self.scale, self.shift, res, "in", act, self.eps, g, b, None, None, 0.0, lazy_dres, stats)
 
     def forward(self, input):
         return ops.ToNCHW.apply(self.forward_act(ops.ToNHWC.apply(input)), self.num_features)
@@ -241,11 +241,11 @@ class CondInstanceNorm(TwoInputModule):
         self.shift_conv = nn.Sequential(Conv2d(z_dim, x_dim, kernel_size=1, padding=0, bias=True), nn.ReLU(True))
         self.scale_conv = nn.Sequential(Conv2d(z_dim, x_dim, kernel_size=1, padding=0, bias=True), nn.ReLU(True))
 
-    def forward_act(self, x, z, act=ACT_NONE):
+    def forward_act(self, x, z, act=ACT_NONE, stats=None):
         Cp = x.shape[-1]
         sh = ops.LinearFn.apply(z, self.shift_conv[0].weight, self.shift_conv[0].bias, ACT_RELU, Cp)
         sc = ops.LinearFn.apply(z, self.scale_conv[0].weight, self.scale_conv[0].bias, ACT_RELU, Cp)
-        return ops.NormAct.apply(x, sc, sh, None, "cin", act, self.eps, None, None, None, None, 0.0)
+        return ops.NormAct.apply(x, sc, sh, None, "cin", act, self.eps, None, None, None, None, 0.0, None, stats)
 
     def forward(self, input, noise):
         y = self.forward_act(ops.ToNHWC.apply(input), as_latent(noise))
@@ -276,6 +276,7 @@ def run_sequence(mods, x, C, z=None, res=None):
     reflect = 0
     skip_routed = False
     relu_link = None   # set by a conv+ReLU whose output goes straight into the next convolution (ops.ReluLink)
+    skip_grad = None   # ops.SkipGrad slot shared by the block's first convolution and its last norm
     while i < n:
         m = mods[i]
         if isinstance(m, nn.ReflectionPad2d):
@@ -286,7 +287,7 @@ def run_sequence(mods, x, C, z=None, res=None):
             x = m.forward_nhwc(x, z)
             i += 1
             continue
-        conv, norm = None, None
+        conv, norm, stats = None, None, None
         if isinstance(m, MergeModule):
             conv, norm = m.module1, m.module2
             i += 1
@@ -322,8 +323,10 @@ def run_sequence(mods, x, C, z=None, res=None):
                 k = i + 1 if (i < n and isinstance(mods[i], nn.ReflectionPad2d)) else i
                 if k < n and isinstance(mods[k], Conv2d):
                     link_out = relu_link = ops.ReluLink()
-            x = conv.forward_nhwc(x, cact, reflect, isinstance(norm, (InstanceNorm, CondInstanceNorm)), skip_here,
-                                  link_out, link_in)
+            stats = ops.ConvStats() if isinstance(norm, (InstanceNorm, CondInstanceNorm)) else None
+            if skip_here:
+                skip_grad = ops.SkipGrad()
+            x = conv.forward_nhwc(x, cact, reflect, stats, skip_here, link_out, link_in, skip_grad if skip_here else None)
             if skip_here:  # the skip connection continues from the conv's identity output: its gradient is added
                 x, res = x  # inside that conv's data-gradient epilogue
                 skip_routed = True
@@ -336,11 +339,12 @@ def run_sequence(mods, x, C, z=None, res=None):
             if isinstance(norm, CondInstanceNorm):
                 if fuse_res:
                     raise NotImplementedError("residual after CondInstanceNorm")
-                x = norm.forward_act(x, z, act)
+                x = norm.forward_act(x, z, act, stats.part if stats is not None else None)
             elif isinstance(norm, InstanceNorm):
                 # skip_routed: `res` is the identity output of the block's first convolution, i.e. its gradient goes to that
                 # convolution's data-gradient epilogue and nowhere else -> it may stay un-materialised (ops.NormAct lazy_dres)
-                x = norm.forward_act(x, ACT_RELU if fuse_res else act, res if fuse_res else None, fuse_res and skip_routed)
+                x = norm.forward_act(x, ACT_RELU if fuse_res else act, res if fuse_res else None,
+                                     skip_grad if (fuse_res and skip_routed) else None, stats.part if stats is not None else None)
             else:
                 if fuse_res:
                     raise NotImplementedError("residual after BatchNorm")

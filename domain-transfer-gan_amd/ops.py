@@ -206,19 +206,34 @@ def conv_desc(N, Hi, Wi, Ci, Co, K, stride, pad, pad_mode, Cir=0, Cor=0):
     return ConvDesc(N, Hi, Wi, Ci, Ho, Wo, Co, K, stride, pad, pad_mode, Cir, Cor)
 
 
-# Hand-off of the per-tile statistics a convolution epilogue produced (acg_conv2d_fwd_stats) to the InstanceNorm /
-# CondInstanceNorm that consumes its output next: (data_ptr of the conv output, partials tensor, rows per chunk).
-_CONV_STATS = None
 STATS_ROWS = 128
 CONV_STATS_ENABLED = os.environ.get("ACGAN_NO_CONV_STATS") is None  # A/B switch
 
 
-def take_conv_stats(x):
-    global _CONV_STATS
-    st, _CONV_STATS = _CONV_STATS, None
-    if st is not None and st[0] == x.data_ptr():
-        return st[1]
-    return None
+class ConvStats(object):
+    """Slot the caller hands to a convolution AND to the (Cond)InstanceNorm behind it (modules.run_sequence): where the
+    kernel supports it the convolution's epilogue emits the norm's per-tile statistics (acg_conv2d_fwd_stats) and leaves
+    them here: `part` [N][Ho*Wo/STATS_ROWS][2][Co] (mean, M2 per 128-pixel tile), else None."""
+
+    def __init__(self):
+        self.part = None
+
+
+class SkipGrad(object):
+    """Slot shared by a residual block's first convolution (whose identity output feeds the skip connection) and the
+    block's last norm: the norm's backward returns dy itself as the gradient of the skip input and leaves the sign bitmask
+    of the block output here; the convolution's data-gradient epilogue adds dy where the bit is set — the skip gradient
+    dy * (y > 0) is never written to memory."""
+
+    def __init__(self):
+        self.mask = self.dy = None
+
+    def take(self, dskip):
+        mask, dy = self.mask, self.dy
+        self.mask = self.dy = None
+        if mask is not None and dy is not None and dy.data_ptr() == dskip.data_ptr() and dy.shape == dskip.shape:
+            return mask
+        return None
 
 
 # Parameter gradients straight into .grad: a model.FlatNet marks its parameters `_acg_direct_grad`; their .grad tensors are
@@ -253,18 +268,7 @@ def _grads_done(*params):
                 h(p)
 
 
-# Skip gradient of ReLU(res + norm(x)) handed from NormAct.backward to the data-gradient epilogue of the convolution whose
-# identity output `res` is: instead of writing dres = dy * (y > 0) (one tensor stream) NormAct returns dy itself and leaves
-# the sign bitmask here, keyed by dy's address; Conv2dFn.backward picks it up with its `dskip`.
-_SKIP_MASKS = {}
-LAZY_DRES = os.environ.get("ACGAN_NO_LAZY_DRES") is None   # A/B switch
-
-
-def take_skip_mask(dskip):
-    m = _SKIP_MASKS.pop(dskip.data_ptr(), None)
-    if m is not None and m[1].shape == dskip.shape:
-        return m[0]
-    return None
+LAZY_DRES = os.environ.get("ACGAN_NO_LAZY_DRES") is None   # A/B switch (SkipGrad)
 
 
 class ReluLink(object):
@@ -282,15 +286,16 @@ RELU_LINK = os.environ.get("ACGAN_NO_RELU_LINK") is None   # A/B switch
 
 
 class Conv2dFn(torch.autograd.Function):
-    """nn.Conv2d (+ preceding ReflectionPad2d) + bias + fused activation.  want_stats: the caller runs an
-    (Cond)InstanceNorm on the output next — where the kernel supports it the epilogue emits that norm's per-tile
-    partial statistics, saving the norm one read of the tensor.  want_identity: also return x itself as a second
+    """nn.Conv2d (+ preceding ReflectionPad2d) + bias + fused activation.  want_stats (a ConvStats slot or None): the
+    caller runs an (Cond)InstanceNorm on the output next — where the kernel supports it the epilogue emits that norm's
+    per-tile partial statistics, saving the norm one read of the tensor.  want_identity: also return x itself as a second
     output; a ResnetBlock feeds that alias to its skip connection, so the skip gradient arrives HERE and is added
-    inside the data-gradient epilogue (acg_conv2d_bwd_data_add) instead of by a separate autograd accumulation."""
+    inside the data-gradient epilogue (acg_conv2d_bwd_data_add) instead of by a separate autograd accumulation;
+    skip_grad (a SkipGrad slot or None) lets that gradient arrive un-materialised.  link_out / link_in: ReluLink."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, packed, stride, pad, pad_mode, act, want_stats=False, want_identity=False,
-                link_out=None, link_in=None):
+    def forward(ctx, x, weight, bias, packed, stride, pad, pad_mode, act, want_stats=None, want_identity=False,
+                link_out=None, link_in=None, skip_grad=None):
         x = x.contiguous()
         _check(x)
         N, Hi, Wi, Ci = x.shape
@@ -304,13 +309,12 @@ class Conv2dFn(torch.autograd.Function):
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        global _CONV_STATS
-        _CONV_STATS = None
-        if want_stats and CONV_STATS_ENABLED and act == ACT_NONE and _lib.query("acg_conv2d_fwd_stats_supported", ctypes.byref(d)):
+        if want_stats is not None and CONV_STATS_ENABLED and act == ACT_NONE and \
+                _lib.query("acg_conv2d_fwd_stats_supported", ctypes.byref(d)):
             part = torch.empty((N, (d.Ho * d.Wo) // STATS_ROWS, 2, packed.Co), device=x.device, dtype=torch.float32)
             _lib.call("acg_conv2d_fwd_stats", ctypes.byref(d), _ptr(x), _ptr(packed.wf),
                       _ptr(packed.bias if bias is not None else None), _ptr(y), _ptr(part), _stream())
-            _CONV_STATS = (y.data_ptr(), part)
+            want_stats.part = part
         else:
             _lib.call("acg_conv2d_fwd", ctypes.byref(d), _ptr(x), _ptr(packed.wf), _ptr(packed.bias if bias is not None else None),
                       _ptr(y), act, _stream())
@@ -322,6 +326,7 @@ class Conv2dFn(torch.autograd.Function):
         ctx.d, ctx.packed, ctx.act, ctx.has_bias = d, packed, act, bias is not None
         ctx.wparam, ctx.bparam = weight, bias
         ctx.link_out, ctx.link_in = (link_out if act == ACT_RELU else None), link_in
+        ctx.skip_grad = skip_grad
         ctx.save_for_backward(x, y if act != ACT_NONE else None)
         if want_identity:
             return y, x.view_as(x)
@@ -349,7 +354,8 @@ class Conv2dFn(torch.autograd.Function):
             smask = None
             if dskip is not None:
                 dskip = dskip.contiguous()
-                smask = take_skip_mask(dskip)   # the skip gradient is dskip * sign-bitmask (NormAct lazy_dres)
+                if ctx.skip_grad is not None:   # the skip gradient is dskip * sign-bitmask (NormAct lazy_dres)
+                    smask = ctx.skip_grad.take(dskip)
             if dskip is not None and _lib.query("acg_conv2d_bwd_data_add_supported", ctypes.byref(d)) and \
                     (smask is None or (d.Hi * d.Wi * (d.Ci // 4)) % 8 == 0):
                 _lib.call("acg_conv2d_bwd_data_add", ctypes.byref(d), _ptr(g), _ptr(pk.wb), _ptr(dskip), _ptr(smask), _ptr(dx),
@@ -381,7 +387,7 @@ class Conv2dFn(torch.autograd.Function):
             if direct is not None:
                 dw = db = None
                 _grads_done(ctx.wparam, ctx.bparam)
-        return dx, dw, db, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None
 
 
 class ConvTranspose2dFn(torch.autograd.Function):
@@ -458,7 +464,10 @@ class NormAct(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, res, kind, act, eps, gamma_p, beta_p, run_mean, run_var, momentum, lazy_dres=False):
+    def forward(ctx, x, gamma, beta, res, kind, act, eps, gamma_p, beta_p, run_mean, run_var, momentum, lazy_dres=None,
+                stats=None):
+        """lazy_dres: a SkipGrad slot (the caller guarantees that the gradient w.r.t. `res` goes only to the Conv2dFn holding
+        the same slot) or None.  stats: per-tile (mean, M2) partials a convolution epilogue produced (ConvStats.part)."""
         x = x.contiguous()
         _check(x)
         C = x.shape[-1]
@@ -482,7 +491,7 @@ class NormAct(torch.autograd.Function):
         if kind == "bn_eval":  # running statistics (real length) -> padded mean / rstd
             _lib.call("acg_bn_eval_stats", _ptr(run_mean), _ptr(run_var), run_mean.numel(), C, eps, _ptr(mean), _ptr(rstd), st)
         else:
-            part = take_conv_stats(x) if kind in ("in", "cin") else None
+            part = stats if kind in ("in", "cin") else None
             if part is not None:  # the producing convolution already reduced 128-pixel tiles: merge only
                 _lib.call("acg_norm_stats_from_partials", _ptr(part), G, P, C, STATS_ROWS, eps, unbiased, _ptr(mean),
                           _ptr(rstd), st)
@@ -504,8 +513,7 @@ class NormAct(torch.autograd.Function):
                   G, P, C, act, st)
         ctx.cfg = (kind, act, G, P, C, unbiased, gstride, res is not None, gamma.shape)
         ctx.gparam, ctx.bparam = (gamma, beta) if kind != "cin" else (None, None)
-        # lazy_dres: the caller guarantees that the gradient w.r.t. `res` goes (only) to a Conv2dFn's skip input
-        ctx.lazy_dres = bool(lazy_dres and LAZY_DRES and mask is not None)
+        ctx.lazy_dres = lazy_dres if (lazy_dres is not None and LAZY_DRES and mask is not None) else None
         ctx.save_for_backward(x, y if (need_y and mask is None) else None, mean, rstd, gp, bp, mask)
         return y
 
@@ -515,7 +523,7 @@ class NormAct(torch.autograd.Function):
         kind, act, G, P, C, unbiased, gstride, has_res, gshape = ctx.cfg
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dres = torch.empty_like(x) if (has_res and not ctx.lazy_dres) else None
+        dres = torch.empty_like(x) if (has_res and ctx.lazy_dres is None) else None
         direct = _direct_grad(ctx.gparam, ctx.bparam) if (kind != "cin" and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]) else None
         if direct is not None:      # shared affine parameters: add into their .grad (first gshape[0] = real channels)
             dgamma, dbeta = direct
@@ -537,12 +545,10 @@ class NormAct(torch.autograd.Function):
             dg, db = dgamma, dbeta
         if has_res and act == ACT_NONE:
             dres = dy
-        elif ctx.lazy_dres:
-            if len(_SKIP_MASKS) > 64:   # entries nobody collected (a skip whose convolution needed no input gradient)
-                _SKIP_MASKS.clear()
-            _SKIP_MASKS[dy.data_ptr()] = (mask, dy)
+        elif ctx.lazy_dres is not None:
+            ctx.lazy_dres.mask, ctx.lazy_dres.dy = mask, dy
             dres = dy
-        return dx, dg, db, dres, None, None, None, None, None, None, None, None, None
+        return dx, dg, db, dres, None, None, None, None, None, None, None, None, None, None
 
 
 class SyncBatchNormAct(torch.autograd.Function):
