@@ -227,6 +227,50 @@ class _Base(object):
         vals = torch.stack(sums + [t.detach().reshape(()).float() for t in local] + mm).tolist()
         return OrderedDict(zip(names, vals))
 
+    # ---- forward-only helpers shared by both models (model.py:210-280, 606-733): compositions of the two generators.
+    # Subclass hooks: _z (noise transform), _cycle_code (the latent the B -> A -> B cycle is closed with).
+    def _draw_prior(self, like):
+        return like.new_empty((like.size(0), self.opt.nlatent, 1, 1)).normal_(0, 1)
+
+    def predict_A(self, real_B):
+        return self.netG_B_A.forward(real_B)
+
+    def predict_B(self, real_A, z_B):
+        return self.netG_A_B.forward(real_A, self._z(z_B))
+
+    def generate_cycle(self, real_A, real_B, prior_z_B):
+        fake_B, fake_A = self.predict_B(real_A, prior_z_B), self.predict_A(real_B)
+        rec_A = self.predict_A(fake_B)
+        rec_B = self.netG_A_B.forward(fake_A, self._cycle_code(fake_A, real_B, prior_z_B))
+        return OrderedDict([('real_A', real_A.data), ('fake_B', fake_B.data), ('rec_A', rec_A.data),
+                            ('real_B', real_B.data), ('fake_A', fake_A.data), ('rec_B', rec_B.data)])
+
+    def generate_multi(self, real_A, multi_prior_z_B):
+        """each A against multi_prior_z_B.size(0) / |A| consecutive codes (train.py:66)"""
+        return self.predict_B(_each_n_times(real_A, multi_prior_z_B.size(0) // real_A.size(0)), multi_prior_z_B)
+
+    def generate_cycle_B_multi(self, real_B, multi_prior_z_B):
+        fake_A = self.predict_A(real_B)
+        return fake_A, self.netG_A_B.forward(_each_n_times(fake_A, multi_prior_z_B.size(0) // real_B.size(0)), multi_prior_z_B)
+
+    def generate_noisy_cycle(self, real_B, std):
+        """B -> A, perturb A by N(0, std/127.5) (clamped to the image range), -> B"""
+        fake_A = self.predict_A(real_B)
+        perturb = lambda: torch.clamp(fake_A + torch.empty_like(fake_A).normal_(0, std / 127.5), -1, 1)
+        if self._noise_before_code:     # order of the random draws as in the reference (model.py:626-645 vs 257-266)
+            noisy, code = perturb(), self._cycle_code(fake_A, real_B, None)
+        else:
+            code, noisy = self._cycle_code(fake_A, real_B, None), perturb()
+        return self.netG_A_B.forward(noisy, code)
+
+    def generate_multi_cycle(self, real_B, steps):
+        images, B = [real_B.data], real_B
+        for _ in range(steps):
+            A = self.predict_A(B)
+            B = self.netG_A_B.forward(A, self._z(self._draw_prior(real_B)))
+            images += [A.data, B.data]
+        return images
+
     # ---- north-star aliases (SURVEY D1) -----------------------------------------------------
     def set_input(self, data, prior_z_B=None):
         self._input = (data['A'], data['B'], prior_z_B)
@@ -261,6 +305,11 @@ def _in_train_step():
         yield
     finally:
         modules.IN_TRAIN_STEP = prev
+
+
+def _each_n_times(x, n):
+    """(N, ...) -> (N*n, ...): every sample n times in a row"""
+    return x.repeat_interleave(n, dim=0)
 
 
 def _n_blocks(opt):
@@ -367,54 +416,15 @@ class StochCycleGAN(_Base):
             return losses, visuals, gnorms
         return losses, visuals
 
-    # ---- forward-only helpers (model.py:210-280) -------------------------------------------
+    # ---- hooks of the shared forward-only helpers (_Base; model.py:210-280) -------------------
+    _noise_before_code = False
+
     def _z(self, z):
-        return z.mul(0.).add(1.) if self.ignore_noise else z
+        return z.mul(0.).add(1.) if self.ignore_noise else z                                     # model.py:128-129
 
-    def generate_cycle(self, real_A, real_B, prior_z_B):
-        z = self._z(prior_z_B)
-        fake_B = self.netG_A_B.forward(real_A, z)
-        fake_A = self.netG_B_A.forward(real_B)
-        rec_A = self.netG_B_A.forward(fake_B)
-        rec_B = self.netG_A_B.forward(fake_A, z)
-        return OrderedDict([('real_A', real_A.data), ('fake_B', fake_B.data), ('rec_A', rec_A.data),
-                            ('real_B', real_B.data), ('fake_A', fake_A.data), ('rec_B', rec_B.data)])
-
-    def generate_multi_cycle(self, real_B, steps):
-        images = [real_B.data]
-        B = real_B
-        for i in range(steps):
-            A = self.netG_B_A.forward(B)
-            z_B = self._z(real_B.new_empty((real_B.size(0), self.opt.nlatent, 1, 1)).normal_(0, 1))
-            B = self.netG_A_B.forward(A, z_B)
-            images.extend([A.data, B.data])
-        return images
-
-    def generate_cycle_B_multi(self, real_B, multi_prior_z_B):
-        fake_A = self.netG_B_A.forward(real_B)
-        size = real_B.size()
-        num = multi_prior_z_B.size(0) // real_B.size(0)
-        multi_fake_A = fake_A.unsqueeze(1).repeat(1, num, 1, 1, 1).view(size[0] * num, size[1], size[2], size[3])
-        return fake_A, self.netG_A_B.forward(multi_fake_A, multi_prior_z_B)
-
-    def generate_noisy_cycle(self, real_B, std):
-        fake_A = self.netG_B_A.forward(real_B)
-        z_B = self._z(real_B.new_empty((real_B.size(0), self.opt.nlatent, 1, 1)).normal_(0, 1))
-        noisy = torch.clamp(fake_A + torch.empty_like(fake_A).normal_(0, std / 127.5), -1, 1)
-        return self.netG_A_B.forward(noisy, z_B)
-
-    def predict_A(self, real_B):
-        return self.netG_B_A.forward(real_B)
-
-    def predict_B(self, real_A, z_B):
-        return self.netG_A_B.forward(real_A, self._z(z_B))
-
-    def generate_multi(self, real_A, multi_prior_z_B):
-        multi_prior_z_B = self._z(multi_prior_z_B)
-        size = real_A.size()
-        num = multi_prior_z_B.size(0) // real_A.size(0)
-        multi_real_A = real_A.unsqueeze(1).repeat(1, num, 1, 1, 1).view(size[0] * num, size[1], size[2], size[3])
-        return self.netG_A_B.forward(multi_real_A, multi_prior_z_B)
+    def _cycle_code(self, fake_A, real_B, prior_z_B):
+        """the code the B -> A -> B cycle is closed with: no encoder here, the given prior"""
+        return self._z(prior_z_B) if prior_z_B is not None else self._z(self._draw_prior(real_B))
 
     def _optimizers(self):
         return OrderedDict([('optimizer_D', self.optimizer_D), ('optimizer_G', self.optimizer_G)])
@@ -676,7 +686,12 @@ class AugmentedCycleGAN(_Base):
             vals[k] = math.sqrt(max(vals[k], 0.0))
         return vals                                                                             # model.py:596-604
 
-    # ---- forward-only helpers (model.py:606-733) -------------------------------------------
+    # ---- hooks of the shared forward-only helpers (_Base) + the encoder-specific ones (model.py:606-733) ----
+    _noise_before_code = True
+
+    def _z(self, z):
+        return z
+
     def _enc_public(self, a, b):
         x = torch.cat((a, b), 1) if self.opt.enc_A_B else b
         return self.netE_B.forward(x)
@@ -686,68 +701,29 @@ class AugmentedCycleGAN(_Base):
             return gauss_reparametrize(mu, logvar)
         return mu.reshape(mu.size(0), mu.size(1), 1, 1)
 
-    def generate_cycle(self, real_A, real_B, prior_z_B):
-        fake_B = self.netG_A_B.forward(real_A, prior_z_B)
-        fake_A = self.netG_B_A.forward(real_B)
-        rec_A = self.netG_B_A.forward(fake_B)
-        mu, logvar = self._enc_public(fake_A, real_B)
-        rec_B = self.netG_A_B.forward(fake_A, self._post_z(mu, logvar))
-        return OrderedDict([('real_A', real_A.data), ('fake_B', fake_B.data), ('rec_A', rec_A.data),
-                            ('real_B', real_B.data), ('fake_A', fake_A.data), ('rec_B', rec_B.data)])
-
-    def generate_noisy_cycle(self, real_B, std):
-        fake_A = self.netG_B_A.forward(real_B)
-        noisy = torch.clamp(fake_A + torch.empty_like(fake_A).normal_(0, std / 127.5), -1, 1)
-        mu, logvar = self._enc_public(fake_A, real_B)
-        return self.netG_A_B.forward(noisy, self._post_z(mu, logvar))
-
-    def predict_A(self, real_B):
-        return self.netG_B_A.forward(real_B)
-
-    def predict_B(self, real_A, z_B):
-        return self.netG_A_B.forward(real_A, z_B)
+    def _cycle_code(self, fake_A, real_B, prior_z_B):
+        """the code the B -> A -> B cycle is closed with: the encoder's posterior for (fake_A, real_B)"""
+        return self._post_z(*self._enc_public(fake_A, real_B))
 
     def predict_enc_params(self, real_A, real_B):
+        """model.py:653-662"""
         mu, logvar = self._enc_public(real_A, real_B)
-        if self.opt.stoch_enc:
-            return mu, logvar
-        return (mu,)
+        return (mu, logvar) if self.opt.stoch_enc else (mu,)
 
     def generate_multi_cycle(self, real_B, steps, from_prior=True):
-        images = [real_B.data]
-        B = real_B
-        for i in range(steps):
-            A = self.netG_B_A.forward(B)
-            if from_prior:
-                z_B = real_B.new_empty((real_B.size(0), self.opt.nlatent, 1, 1)).normal_(0, 1)
-            else:
-                z_B = self._post_z(*self._enc_public(A, B))
-            B = self.netG_A_B.forward(A, z_B)
-            images.extend([A.data, B.data])
+        """model.py:664-685: alternate B -> A -> B `steps` times, re-drawing (or re-encoding) the code every round"""
+        images, B = [real_B.data], real_B
+        for _ in range(steps):
+            A = self.predict_A(B)
+            code = self._draw_prior(real_B) if from_prior else self._cycle_code(A, B, None)
+            B = self.netG_A_B.forward(A, code)
+            images += [A.data, B.data]
         return images
 
-    def generate_multi(self, real_A, multi_prior_z_B):
-        size = real_A.size()
-        num = multi_prior_z_B.size(0) // real_A.size(0)
-        multi_real_A = real_A.unsqueeze(1).repeat(1, num, 1, 1, 1).view(size[0] * num, size[1], size[2], size[3])
-        return self.netG_A_B.forward(multi_real_A, multi_prior_z_B)
-
-    def generate_cycle_B_multi(self, real_B, multi_prior_z_B):
-        fake_A = self.netG_B_A.forward(real_B)
-        size = real_B.size()
-        num = multi_prior_z_B.size(0) // real_B.size(0)
-        multi_fake_A = fake_A.unsqueeze(1).repeat(1, num, 1, 1, 1).view(size[0] * num, size[1], size[2], size[3])
-        return fake_A, self.netG_A_B.forward(multi_fake_A, multi_prior_z_B)
-
     def inference_multi(self, real_A, real_B):
-        size = real_A.size()
-        num = real_B.size(0)
-        multi_real_A = real_A.unsqueeze(1).repeat(1, num, 1, 1, 1).view(size[0] * num, size[1], size[2], size[3])
-        fake_A = self.netG_B_A.forward(real_B) if self.opt.enc_A_B else real_B
-        mu, logvar = self._enc_public(fake_A, real_B)
-        post_z_B = self._post_z(mu, logvar)
-        multi_post_z_B = post_z_B.data.repeat(size[0], 1, 1, 1)
-        return self.netG_A_B.forward(multi_real_A, multi_post_z_B)
+        """model.py:710-733: every A against the posterior code of every B — (|A| * |B|) images, A-major"""
+        codes = self._cycle_code(self.predict_A(real_B) if self.opt.enc_A_B else real_B, real_B, None)
+        return self.netG_A_B.forward(_each_n_times(real_A, real_B.size(0)), codes.data.repeat(real_A.size(0), 1, 1, 1))
 
     def _optimizers(self):
         return OrderedDict([('optimizer_D_A', self.optimizer_D_A), ('optimizer_G_A', self.optimizer_G_A),
