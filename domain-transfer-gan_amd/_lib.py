@@ -24,8 +24,21 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(k, c_int) for k in ("N", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "K", "stride", "pad", "pad_mode", "Cir", "Cor")]
 
 
+class LatentMlpParams(ctypes.Structure):
+    """acg_latent_mlp_params (include/acgan_hip.h)."""
+    _fields_ = [("w", c_void_p * 4), ("b", c_void_p * 4), ("gamma", c_void_p * 3), ("beta", c_void_p * 3),
+                ("run_mean", c_void_p * 3), ("run_var", c_void_p * 3)]
+
+
+class LatentMlpGrads(ctypes.Structure):
+    """acg_latent_mlp_grads (include/acgan_hip.h)."""
+    _fields_ = [("dw", c_void_p * 4), ("db", c_void_p * 4), ("dgamma", c_void_p * 3), ("dbeta", c_void_p * 3)]
+
+
 _P = c_void_p
 _D = ctypes.POINTER(ConvDesc)
+_MP = ctypes.POINTER(LatentMlpParams)
+_MG = ctypes.POINTER(LatentMlpGrads)
 
 # name -> (restype, argtypes); every symbol the header declares
 SIGNATURES = {
@@ -70,6 +83,9 @@ SIGNATURES = {
     "acg_act_bwd": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
     "acg_linear_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "acg_linear_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "acg_latent_mlp_supported": (c_int, [c_int, c_int, c_int]),
+    "acg_latent_mlp_fwd": (c_int, [_MP, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P]),
+    "acg_latent_mlp_bwd": (c_int, [_MP, _MG, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
     "acg_spatial_mean_fwd": (c_int, [_P, _P, c_int, c_size_t, c_int, _P]),
     "acg_spatial_mean_bwd": (c_int, [_P, _P, c_int, c_size_t, c_int, _P]),
     "acg_reduce_workspace_bytes": (c_size_t, [c_size_t]),

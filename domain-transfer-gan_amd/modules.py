@@ -27,6 +27,11 @@ def ops_dist_on():
     return dist.exchange_on()
 
 
+def sync_bn_active():
+    """True where a train-mode BatchNorm forward would exchange its statistics with the other ranks"""
+    return SYNC_BN and IN_TRAIN_STEP and ops_dist_on()
+
+
 def mark_dirty(net):
     """Parameters of `net` changed outside torch's version counter (fused Adam kernel):
     drop the cached packed weights / padded vectors of all its layers."""
@@ -105,7 +110,7 @@ class _BatchNormMixin(_Cached):
         if not self.training:  # eval mode: normalise with the running buffers (model.eval(), train.py:258)
             return ops.NormAct.apply(x, self.weight, self.bias, None, "bn_eval", act, self.eps, g, b,
                                      self.running_mean.contiguous(), self.running_var.contiguous(), 0.0)
-        if SYNC_BN and IN_TRAIN_STEP and ops_dist_on():  # statistics over every rank's shard
+        if sync_bn_active():  # statistics over every rank's shard
             y = ops.SyncBatchNormAct.apply(x, self.weight, self.bias, act, self.eps, g, b, self.running_mean,
                                            self.running_var, self.momentum)
             with torch.no_grad():

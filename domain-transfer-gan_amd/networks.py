@@ -17,7 +17,7 @@ import functools
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import modules, ops
 from .modules import (ResnetBlock, CondInstanceNorm, TwoInputSequential, CINResnetBlock, InstanceNorm2d,  # noqa: F401
                       Conv2d, ConvTranspose2d, BatchNorm2d, BatchNorm1d, Linear, Sequential, run_sequence,
                       run_dense, as_latent, mark_dirty)
@@ -245,7 +245,35 @@ class DiscriminatorLatent(nn.Module):
 
     def forward_dense(self, z):
         """z: (N, >=nlatent) -> (N, 4) with column 0 valid"""
-        return run_dense(list(self.model._modules.values()), z)
+        mods = list(self.model._modules.values())
+        fused = self._fused_args(mods, z)
+        if fused is not None:
+            return fused
+        return run_dense(mods, z)
+
+    def _fused_args(self, mods, z):
+        """the whole chain as one launch per direction (ops.LatentMLPFn) when it is the standard train-mode chain, the batch
+        fits one workgroup's LDS and BatchNorm statistics are local to this rank; None otherwise (layer by layer)"""
+        if len(mods) != 10 or not self.training or modules.sync_bn_active():
+            return None
+        lins, bns = mods[0:10:3], mods[1:9:3]
+        if not (all(isinstance(m, Linear) for m in lins) and all(isinstance(m, BatchNorm1d) for m in bns)
+                and all(modules._act_of(m) == modules.ACT_LRELU for m in mods[2:9:3])):
+            return None
+        H = lins[0].out_features
+        if any(b.num_features != H or b.eps != bns[0].eps or b.momentum != bns[0].momentum or not b.affine
+               or not b.track_running_stats or b.momentum is None for b in bns):
+            return None
+        if not ops.latent_mlp_supported(z.shape[0], lins[0].in_features, H):
+            return None
+        out = ops.LatentMLPFn.apply(z, bns[0].eps, bns[0].momentum,
+                                    [b.running_mean for b in bns] + [b.running_var for b in bns],
+                                    *([m.weight for m in lins] + [m.bias for m in lins] + [b.weight for b in bns]
+                                      + [b.bias for b in bns]))
+        with torch.no_grad():
+            for b in bns:
+                b.num_batches_tracked += 1
+        return out
 
     def forward(self, input):
         if input.dim() == 4:

@@ -654,6 +654,82 @@ class LinearFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+LATENT_MLP = os.environ.get("ACGAN_NO_LATENT_MLP") is None   # A/B switch
+
+
+def latent_mlp_supported(N, I, H):
+    return LATENT_MLP and bool(_lib.query("acg_latent_mlp_supported", N, I, H))
+
+
+class LatentMLPFn(torch.autograd.Function):
+    """DiscriminatorLatent's whole dense chain (networks.py:396-433) as one launch per direction: three Linear /
+    BatchNorm1d(train) / LeakyReLU(0.2) stages and the Linear head.  `params` = 4 weights, 4 biases, 3 BN weights, 3 BN
+    biases (autograd inputs); `buffers` = 3 running means + 3 running variances, updated in place.  -> (N, 4), column 0
+    valid (the layout LinearFn gives the head)."""
+
+    NPARAM = 14
+
+    @staticmethod
+    def forward(ctx, z, eps, momentum, buffers, *params):
+        z = z.contiguous()
+        _check(z, *params)
+        _check(*buffers)
+        N, ldz = z.shape
+        H, I = params[0].shape
+        for l in range(4):
+            want = ((H if l < 3 else 1), (I if l == 0 else H))
+            if tuple(params[l].shape) != want or params[4 + l].numel() != want[0] or not params[l].is_contiguous():
+                raise _lib.AcgError("latent mlp: layer %d has shape %s, expected %s" % (l, tuple(params[l].shape), want))
+        if I > ldz:
+            raise _lib.AcgError("latent mlp: input has %d columns, the first layer expects %d" % (ldz, I))
+        pp = _lib.LatentMlpParams()
+        for l in range(4):
+            pp.w[l], pp.b[l] = params[l].data_ptr(), params[4 + l].data_ptr()
+        for l in range(3):
+            pp.gamma[l], pp.beta[l] = params[8 + l].data_ptr(), params[11 + l].data_ptr()
+            pp.run_mean[l], pp.run_var[l] = buffers[l].data_ptr(), buffers[3 + l].data_ptr()
+        a_save = torch.empty((3, N, H), device=z.device, dtype=torch.float32)
+        stats = torch.empty((3, 2, H), device=z.device, dtype=torch.float32)
+        out = torch.empty((N, 4), device=z.device, dtype=torch.float32)
+        _lib.call("acg_latent_mlp_fwd", ctypes.byref(pp), _ptr(z), ldz, N, I, H, float(eps), float(momentum), _ptr(a_save),
+                  _ptr(stats), _ptr(out), _stream())
+        ctx.cfg = (N, ldz, I, H)
+        ctx.params = params
+        ctx.save_for_backward(z, a_save, stats, *[p.detach() for p in params])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, a_save, stats = ctx.saved_tensors[:3]
+        ws = ctx.saved_tensors[3:]
+        N, ldz, I, H = ctx.cfg
+        dout = dout.contiguous()
+        pp, gg = _lib.LatentMlpParams(), _lib.LatentMlpGrads()
+        for l in range(4):
+            pp.w[l], pp.b[l] = ws[l].data_ptr(), ws[4 + l].data_ptr()
+        for l in range(3):
+            pp.gamma[l], pp.beta[l] = ws[8 + l].data_ptr(), ws[11 + l].data_ptr()
+        want = [ctx.needs_input_grad[4 + i] for i in range(LatentMLPFn.NPARAM)]
+        direct = _direct_grad(*ctx.params) if all(want) else None
+        if direct is not None:
+            grads = direct
+        else:
+            grads = [torch.empty_like(ws[i]) if want[i] else None for i in range(LatentMLPFn.NPARAM)]
+        for l in range(4):
+            gg.dw[l] = grads[l].data_ptr() if grads[l] is not None else None
+            gg.db[l] = grads[4 + l].data_ptr() if grads[4 + l] is not None else None
+        for l in range(3):
+            gg.dgamma[l] = grads[8 + l].data_ptr() if grads[8 + l] is not None else None
+            gg.dbeta[l] = grads[11 + l].data_ptr() if grads[11 + l] is not None else None
+        dz = torch.zeros_like(z) if ctx.needs_input_grad[0] else None
+        _lib.call("acg_latent_mlp_bwd", ctypes.byref(pp), ctypes.byref(gg), _ptr(z), ldz, N, I, H, _ptr(a_save), _ptr(stats),
+                  _ptr(dout), _ptr(dz), 1 if direct is not None else 0, _stream())
+        if direct is not None:
+            _grads_done(*ctx.params)
+            grads = [None] * LatentMLPFn.NPARAM
+        return (dz, None, None, None) + tuple(grads)
+
+
 class SpatialMean(torch.autograd.Function):
     """(N,H,W,Cp) -> (N,Cp): mean over H*W (identity at 1x1; LatentEncoder extension)."""
 

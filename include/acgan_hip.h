@@ -200,6 +200,26 @@ int acg_linear_fwd(const float *x, const float *w, const float *b, float *y, int
 int acg_linear_bwd(const float *dy, const float *y, const float *x, const float *w, float *dx, float *dw, float *db,
                    int N, int I, int ldx, int O, int Op, int act, void *stream);
 
+/* ---- DiscriminatorLatent (networks.py:396-433) fused: Linear(I->H) BatchNorm1d LeakyReLU(0.2), two more H->H stages, then
+ *      Linear(H->1), BatchNorm in train mode (batch statistics; running buffers updated when non-NULL).  One launch per
+ *      direction; the batch must fit one workgroup's LDS (acg_latent_mlp_supported), else use acg_linear_* + acg_norm_*.
+ *      w[l] are torch nn.Linear weights [out][in]; z is [N][ldz] with I valid columns; out is [N][4] (column 0 = the
+ *      prediction).  a_save [3][N][H] and stats_save [3][2][H] carry the pre-norm activations and (mean, rstd) to the
+ *      backward pass.  Gradient pointers may be NULL; accumulate != 0 adds to them (parameter .grad). ---- */
+typedef struct {
+    const float *w[4], *b[4], *gamma[3], *beta[3];
+    float *run_mean[3], *run_var[3];
+} acg_latent_mlp_params;
+typedef struct {
+    float *dw[4], *db[4], *dgamma[3], *dbeta[3];
+} acg_latent_mlp_grads;
+int acg_latent_mlp_supported(int N, int I, int H);
+int acg_latent_mlp_fwd(const acg_latent_mlp_params *params, const float *z, int ldz, int N, int I, int H, float eps,
+                       float momentum, float *a_save, float *stats_save, float *out, void *stream);
+int acg_latent_mlp_bwd(const acg_latent_mlp_params *params, const acg_latent_mlp_grads *grads, const float *z, int ldz, int N,
+                       int I, int H, const float *a_save, const float *stats_save, const float *dout, float *dz, int accumulate,
+                       void *stream);
+
 /* ---- spatial mean over H*W of a C16 map -> [N][Cp] (LatentEncoder extension for S != 64,
  *      identity at the reference's 1x1 map — networks.py:482) ---- */
 int acg_spatial_mean_fwd(const float *x, float *y, int N, size_t P, int Cp, void *stream);

@@ -367,6 +367,58 @@ def test_backward_fusions_are_bit_identical_to_the_separate_passes(switch):
     assert np.abs(res[True][1]).max() > 0
 
 
+@pytest.mark.parametrize("N,nlatent,ndf,flat", [(4, 16, 64, False), (32, 16, 64, True), (96, 16, 64, True), (7, 8, 32, False),
+                                                (1024, 16, 64, False)])
+def test_fused_latent_discriminator_equals_the_layer_chain(N, nlatent, ndf, flat):
+    """DiscriminatorLatent (networks.py:396-433) as one launch per direction against the Linear / BatchNorm1d / LeakyReLU
+    launches it replaces: output, input gradient, every parameter gradient (as autograd tensors and added into a FlatNet's
+    .grad), running statistics and num_batches_tracked.  fp32 sums in a different order: 2e-5.  N=1024 does not fit one
+    workgroup's LDS and must take the layer chain by itself."""
+    from hip_util import t, n, rel
+    from dtgan_amd import networks, ops
+    from dtgan_amd.model import FlatNet
+    rs = np.random.RandomState(N)
+    z, r = rs.normal(0, 1, (N, nlatent)).astype(np.float32), rs.normal(0, 1, (N, 1)).astype(np.float32)
+    torch.manual_seed(5)
+    net = networks.DiscriminatorLatent(nlatent, ndf).cuda()
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            p.normal_(1.0 if p.dim() == 1 and "weight" in k else 0.0, 0.4)
+    fn = FlatNet(net) if flat else None
+    state0 = {k: v.clone() for k, v in net.state_dict().items()}
+    res, used = {}, {}
+    for fused in (True, False):
+        ops.LATENT_MLP = fused
+        try:
+            net.load_state_dict(state0)
+            networks.mark_dirty(net)
+            net.zero_grad() if fn is None else fn.zero_grad()
+            zt = t(z, grad=True)
+            calls = []
+            orig = ops._lib.call
+            ops._lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+            try:
+                for _ in range(2):      # twice: gradients accumulate, running buffers move twice
+                    y = net(zt)
+                    y.backward(t(r))
+            finally:
+                ops._lib.call = orig
+            used[fused] = set(calls)
+            grads = n(fn.gv) if fn is not None else np.concatenate([n(p.grad).ravel() for p in net.parameters()])
+            res[fused] = [n(y), n(zt.grad), grads] + [n(v.float()) for k, v in net.state_dict().items() if "running" in k or "num_batches" in k]
+        finally:
+            ops.LATENT_MLP = True
+    fits = N * ndf * 12 + 8 * ndf <= 159 * 1024
+    assert ("acg_latent_mlp_fwd" in used[True]) == fits and ("acg_latent_mlp_bwd" in used[True]) == fits
+    assert "acg_latent_mlp_fwd" not in used[False]
+    if fits:
+        assert "acg_linear_fwd" not in used[True] and "acg_norm_bwd" not in used[True]
+    assert tuple(res[True][0].shape) == (N, 1)
+    for a, b in zip(res[True], res[False]):
+        assert a.shape == b.shape and rel(a, b) < 2e-5, rel(a, b)
+    assert np.abs(res[True][2]).max() > 0
+
+
 def test_residual_norm_relu_fusion():
     """ResnetBlock tail: y = ReLU(x + IN(conv(...))) with the add + ReLU fused into the norm pass"""
     from hip_util import t, n, rel
