@@ -388,30 +388,57 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
             o[g.Cout] = redf[c] + redf[BN + c];
         }
     }
+    if (g.addend == nullptr && g.relu_src == nullptr) {
 #pragma unroll 4
-    for (int k = 0; k < BM * (BN / 4) / 256; ++k) { // 16 float4 per thread, consecutive lanes on consecutive channels
-        const int idx = tid + 256 * k, row = idx / (BN / 4), c4 = idx - row * (BN / 4);
-        float *dst = out_ptr[row];
-        if (dst != nullptr && n0 + c4 * 4 < g.Cout) {
-            f32x4 v = *(const f32x4 *)&tile[row * TS + c4 * 4];
-            const float *mp = msk_ptr[row];
-            if (mp != nullptr) {
-                const f32x4 mv = *(const f32x4 *)(mp + n0 + c4 * 4);
+        for (int k = 0; k < BM * (BN / 4) / 256; ++k) { // 16 float4 per thread, consecutive lanes on consecutive channels
+            const int idx = tid + 256 * k, row = idx / (BN / 4), c4 = idx - row * (BN / 4);
+            float *dst = out_ptr[row];
+            if (dst != nullptr && n0 + c4 * 4 < g.Cout) *(f32x4 *)(dst + n0 + c4 * 4) = *(const f32x4 *)&tile[row * TS + c4 * 4];
+        }
+        return;
+    }
+    // Data-gradient epilogues with side inputs (ReLU source, skip gradient and its sign bitmask): four rows at a time, every
+    // side load issued before the first is used.  Rows without a side input (fold targets, the frame) read a dummy address
+    // instead of branching: with the loads inside per-row branches the compiler drained the queue (vmcnt(0)) three times
+    // per row, 48 dependent round trips per thread.
+    const float *dummy = in;
+    const unsigned *amask = g.addend_mask != nullptr ? g.addend_mask : (const unsigned *)in;
+    constexpr int EB = 4;
+#pragma unroll 1
+    for (int kb = 0; kb < BM * (BN / 4) / 256; kb += EB) {
+        float *dst[EB];
+        const float *mp[EB], *ap[EB];
+        f32x4 v[EB], mv[EB], av[EB];
+        unsigned nb[EB];
+        int col[EB];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = mv[q] > 0.f ? v[q] : 0.f;
-            }
-            const float *ap = add_ptr[row];
-            if (ap != nullptr) {
-                f32x4 av = *(const f32x4 *)(ap + n0 + c4 * 4);
-                if (g.addend_mask != nullptr) {
-                    const long long f = ((ap - g.addend) + n0 + c4 * 4) >> 2;   // float4 index of these 4 elements
-                    const unsigned nb = (g.addend_mask[f >> 3] >> (4 * (int)(f & 7))) & 15u;
+        for (int u = 0; u < EB; ++u) {
+            const int idx = tid + 256 * (kb + u), row = idx / (BN / 4), c4 = idx - row * (BN / 4);
+            col[u] = n0 + c4 * 4;
+            dst[u] = out_ptr[row];
+            mp[u] = msk_ptr[row];
+            ap[u] = add_ptr[row];
+            v[u] = *(const f32x4 *)&tile[row * TS + c4 * 4];
+        }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) av[q] = (nb >> q) & 1u ? av[q] : 0.f;
-                }
-                v += av;
+        for (int u = 0; u < EB; ++u) {
+            mv[u] = *(const f32x4 *)((mp[u] != nullptr ? mp[u] : dummy) + col[u]);
+            av[u] = *(const f32x4 *)((ap[u] != nullptr ? ap[u] : dummy) + col[u]);
+            const long long f = ap[u] != nullptr ? ((ap[u] - g.addend) + col[u]) >> 2 : 0;   // float4 index of these 4 elements
+            nb[u] = (amask[f >> 3] >> (4 * (int)(f & 7))) & 15u;
+        }
+#pragma unroll
+        for (int u = 0; u < EB; ++u) {
+            if (mp[u] != nullptr) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[u][q] = mv[u][q] > 0.f ? v[u][q] : 0.f;
             }
-            *(f32x4 *)(dst + n0 + c4 * 4) = v;
+            if (ap[u] != nullptr) {
+                if (g.addend_mask == nullptr) nb[u] = 15u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[u][q] += (nb[u] >> q) & 1u ? av[u][q] : 0.f;
+            }
+            if (dst[u] != nullptr && col[u] < g.Cout) *(f32x4 *)(dst[u] + col[u]) = v[u];
         }
     }
 }
