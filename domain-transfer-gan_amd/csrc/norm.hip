@@ -181,11 +181,12 @@ __device__ __forceinline__ unsigned norm_mask_nibble(const unsigned *__restrict_
 // y == nullptr: the activation mask is recomputed from x (pre = xhat*gamma + beta) instead of read — valid when no
 // residual was added before the activation; saves one tensor stream per pass.
 // mask != nullptr: the sign bits norm_apply_kernel<.., MASK> stored replace y
+template <int ACT, int MSRC> // activation mask: MSRC 0 = read y, 1 = recompute from x (y == nullptr), 2 = sign bitmask
 __global__ __launch_bounds__(256) void norm_bwd_partial(const float *__restrict__ dy, const float *__restrict__ y,
                                                         const float *__restrict__ x, const float *__restrict__ mean,
                                                         const float *__restrict__ rstd, const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, int gstride, long long P, int C,
-                                                        int nchunks, int act, float *__restrict__ part,
+                                                        int nchunks, float *__restrict__ part,
                                                         const unsigned *__restrict__ mask)
 {
     __shared__ float sa[256 * 4], sb[256 * 4];
@@ -202,30 +203,53 @@ __global__ __launch_bounds__(256) void norm_bwd_partial(const float *__restrict_
         const f32x4 mu = *(const f32x4 *)(mean + g * C + c4 * 4);
         const f32x4 rs = *(const f32x4 *)(rstd + g * C + c4 * 4);
         f32x4 ga = {0.f, 0.f, 0.f, 0.f}, be = ga;
-        const bool recompute = act != ACG_ACT_NONE && y == nullptr && mask == nullptr;
-        if (recompute) {
+        if (ACT != ACG_ACT_NONE && MSRC == 1) {
             ga = *(const f32x4 *)(gamma + g * gstride + c4 * 4);
             be = *(const f32x4 *)(beta + g * gstride + c4 * 4);
         }
-#pragma unroll 4
-        for (long long r = r0 + rl; r < r1; r += rows_par) {
-            const long long o = base + r * C + c4 * 4;
-            f32x4 gy = *(const f32x4 *)(dy + o);
-            const f32x4 xv = *(const f32x4 *)(x + o);
-            if (act != ACG_ACT_NONE) {
-                f32x4 yy;
-                if (mask != nullptr) {
-                    const unsigned nb = norm_mask_nibble(mask, o >> 2);
+        // EW_UNROLL rows per trip, every load issued before the first use (with the activation and its mask source as run-time
+        // branches the loop was not unrolled and drained its two loads every row); rows are still summed in ascending order
+        auto masked = [&](f32x4 gy, const f32x4 &xv, const f32x4 &yv) {
+            if (ACT != ACG_ACT_NONE) {
+                const f32x4 yy = MSRC == 1 ? (xv - mu) * rs * ga + be : yv; // same expression as norm_apply_kernel (sign is all we need)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) yy[k] = (nb >> k) & 1u ? 1.f : -1.f;
-                } else if (recompute) yy = (xv - mu) * rs * ga + be;   // same expression as norm_apply_kernel (sign is all we need)
-                else yy = *(const f32x4 *)(y + o);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) gy[k] *= acg_act_grad_from_y(yy[k], act);
+                for (int k = 0; k < 4; ++k) gy[k] *= acg_act_grad_from_y(yy[k], ACT);
             }
-            const f32x4 xh = (xv - mu) * rs;
+            return gy;
+        };
+        auto side = [&](long long o) {
+            f32x4 yv = {0.f, 0.f, 0.f, 0.f};
+            if (ACT != ACG_ACT_NONE && MSRC == 0) yv = *(const f32x4 *)(y + o);
+            if (ACT != ACG_ACT_NONE && MSRC == 2) {
+                const unsigned nb = norm_mask_nibble(mask, o >> 2);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) yv[k] = (nb >> k) & 1u ? 1.f : -1.f;
+            }
+            return yv;
+        };
+        long long r = r0 + rl;
+        for (; r + (long long)rows_par * (EW_UNROLL - 1) < r1; r += (long long)rows_par * EW_UNROLL) {
+            f32x4 gv[EW_UNROLL], xv[EW_UNROLL], yv[EW_UNROLL];
+#pragma unroll
+            for (int u = 0; u < EW_UNROLL; ++u) {
+                const long long o = base + (r + (long long)u * rows_par) * C + c4 * 4;
+                gv[u] = *(const f32x4 *)(dy + o);
+                xv[u] = *(const f32x4 *)(x + o);
+                yv[u] = side(o);
+            }
+#pragma unroll
+            for (int u = 0; u < EW_UNROLL; ++u) {
+                const f32x4 gy = masked(gv[u], xv[u], yv[u]);
+                s1 += gy;
+                s2 += gy * ((xv[u] - mu) * rs);
+            }
+        }
+        for (; r < r1; r += rows_par) {
+            const long long o = base + r * C + c4 * 4;
+            const f32x4 xv = *(const f32x4 *)(x + o);
+            const f32x4 gy = masked(*(const f32x4 *)(dy + o), xv, side(o));
             s1 += gy;
-            s2 += gy * xh;
+            s2 += gy * ((xv - mu) * rs);
         }
     }
     *(f32x4 *)&sa[threadIdx.x * 4] = s1;
@@ -396,6 +420,22 @@ static void launch_norm_apply(dim3 grid, hipStream_t st, const float *x, const f
 #undef M
 }
 
+static void launch_norm_bwd_partial(dim3 grid, hipStream_t st, const float *dy, const float *y, const float *x, const float *mean,
+                                    const float *rstd, const float *gamma, const float *beta, int gstride, long long P, int C,
+                                    int nch, int act, float *part, const unsigned *mask)
+{
+#define L(A, R) hipLaunchKernelGGL((norm_bwd_partial<A, R>), grid, dim3(256), 0, st, dy, y, x, mean, rstd, gamma, beta, gstride, P, C, nch, part, mask)
+#define M(A)                                                                         \
+    do {                                                                             \
+        if (mask) L(A, 2);                                                           \
+        else if (y == nullptr) L(A, 1);                                              \
+        else L(A, 0);                                                                \
+    } while (0)
+    NORM_ACT_SWITCH(act, M)
+#undef M
+#undef L
+}
+
 static void launch_norm_bwd_apply(dim3 grid, hipStream_t st, const float *dy, const float *y, const float *x,
                                   const float *mean, const float *rstd, const float *gamma, const float *beta, int gstride,
                                   const float *sums, float *dx, float *dres, long long P, int C, int act, float invP,
@@ -524,8 +564,8 @@ extern "C" int acg_norm_bwd_sums(const float *dy, const float *y, const float *x
     hipStream_t st = (hipStream_t)stream;
     const int nch = nchunks_of(P);
     ACG_REQUIRE(act == ACG_ACT_NONE || y != nullptr, "acg_norm_bwd_sums: y required");
-    hipLaunchKernelGGL(norm_bwd_partial, dim3(nch, G), dim3(256), 0, st, dy, y, x, mean, rstd, (const float *)nullptr,
-                       (const float *)nullptr, 0, (long long)P, C, nch, act, (float *)ws, (const unsigned *)nullptr);
+    launch_norm_bwd_partial(dim3(nch, G), st, dy, y, x, mean, rstd, (const float *)nullptr, (const float *)nullptr, 0,
+                            (long long)P, C, nch, act, (float *)ws, (const unsigned *)nullptr);
     hipLaunchKernelGGL(norm_bwd_final, dim3(G * acg_cdiv(C, FIN_CH)), dim3(256), 0, st, (const float *)ws, G, C, nch, sums,
                        (float *)nullptr, (float *)nullptr);
     ACG_CHECK_LAUNCH("norm_bwd_sums");
@@ -571,8 +611,7 @@ extern "C" int acg_norm_bwd(const float *dy, const float *y, const unsigned *mas
     ACG_REQUIRE(act == ACG_ACT_NONE || y != nullptr || mask != nullptr || beta != nullptr,
                 "acg_norm_bwd: y, the sign bitmask or beta required for the activation mask");
     ACG_REQUIRE(mask == nullptr || ((long long)P * (C / 4)) % 8 == 0, "acg_norm_bwd: bitmask layout needs P*C/4 %% 8 == 0");
-    hipLaunchKernelGGL(norm_bwd_partial, dim3(nch, G), dim3(256), 0, st, dy, y, x, mean, rstd, gamma, beta, gstride,
-                       (long long)P, C, nch, act, part, mask);
+    launch_norm_bwd_partial(dim3(nch, G), st, dy, y, x, mean, rstd, gamma, beta, gstride, (long long)P, C, nch, act, part, mask);
     hipLaunchKernelGGL(norm_bwd_final, dim3(G * acg_cdiv(C, FIN_CH)), dim3(256), 0, st, (const float *)part, G, C,
                        nch, sums, gstride ? dgamma : (float *)nullptr, gstride ? dbeta : (float *)nullptr);
     if (gstride == 0 && nparam > 0 && (dgamma != nullptr || dbeta != nullptr))
