@@ -30,7 +30,7 @@ def mean_counter(path, counter, needle, grid):
 
 def main():
     needle, out = sys.argv[1], sys.argv[2]
-    grid = int(sys.argv[3]) if len(sys.argv) > 3 else 4096 * 256
+    grid = int(sys.argv[3]) if len(sys.argv) > 3 else 4096 * 512   # 4096 tiles x 512 threads (wave-specialised kernel)
     f, nf = mean_counter(newest(ROOT + "/gpurun_out/pmc_fetch/**/*counter_collection.csv"), "FETCH_SIZE", needle, grid)
     w, nw = mean_counter(newest(ROOT + "/gpurun_out/pmc_write/**/*counter_collection.csv"), "WRITE_SIZE", needle, grid)
     N, H, C, K = 32, 128, 128, 3
