@@ -127,40 +127,61 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
             a_bx[j] = gx * g.is;
             a_row[j] = REFLECT ? n * g.Hin : (n * g.Hin + a_by[j]) * g.Win + a_bx[j];
         }
+        // The weight tile goes global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no VGPR round trip, no ds_write): lane
+        // L of a wave lands on the 16-byte slot (slot0 + L) of the wave's 1 KB piece of a plane, so it fetches the column the
+        // XOR permutation of that plane puts there.  Measured against register staging (two loads and two ds_write_b128
+        // per chunk): -2 % on the resblock forward.
+        typedef __attribute__((address_space(3))) void lds_void;
         unsigned b_voff[BL];
         int b_lds[BL];
 #pragma unroll
         for (int i = 0; i < BL; ++i) {
             const int idx = pt + 256 * i;
-            const int plane = idx / BN, col = idx - plane * BN; // 8 consecutive lanes store 8 columns of ONE plane
+            const int plane = idx / BN, slot = idx - plane * BN, col = slot ^ (2 * plane);
             b_voff[i] = (unsigned)((((plane >> 1) * g.ncols_pad + n0 + col) * 16 + (plane & 1) * 8) * 2);
-            b_lds[i] = lds_at(plane, col, BPL);
+            b_lds[i] = __builtin_amdgcn_readfirstlane((plane * BPL + (slot & ~63) * 8) * 2);   // byte offset of the wave's piece
         }
-        f32x8 ra[ROWP ? 3 : AL]; // ROWP: up to 3 of the <= 160*4 patch units per thread
-        u32x4 rb[BL], rbl[BL];
-        // ROWP geometry: the tile's 128 consecutive output pixels form SEGMENTS, one per grid row it touches (the first
-        // starts at column x0, the others at 0); segment s occupies image rows [row0(s), row0(s) + len(s) + K-1)
-        const long long grow0 = m0 / g.GW;                     // global grid row (image * GH + gy) of the first pixel
-        const int x0 = (int)(m0 - grow0 * g.GW);
-        const int first = g.GW - x0 < BM ? g.GW - x0 : BM;     // pixels in segment 0
-        const int RW = g.GW + kdim - 1;
-        const int nseg = first >= BM ? 1 : 1 + (BM - first + g.GW - 1) / g.GW;
-        const int npu = ROWP ? (BM + nseg * (kdim - 1)) * 4 : 0;
-        const long long grows = g.Mtot / g.GW;                 // grid rows in the whole tensor
-        auto load_b = [&](int tw, int c0) {
-            const unsigned soff = (unsigned)(((tw * (g.Cin >> 4) + (c0 >> 4)) * g.ncols_pad) * 16) * 2u;
+        int bt = 0, bc0 = 0; // tap and first input channel of the next B stage
+        auto dma_b = [&](int buf) { // 2 * BL pieces per thread: hi and lo image of stage (bt, bc0) into B buffer `buf`
+            char *Bb = (char *)(lds + L::b_off(buf));
+            const unsigned soff = (unsigned)((((taps.pk[bt] >> 16) * (g.Cin >> 4) + (bc0 >> 4)) * g.ncols_pad) * 16) * 2u;
 #pragma unroll
             for (int i = 0; i < BL; ++i) {
-                rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[i], soff, 0);
-                rbl[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[i], soff + w_lo_bytes, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(Bb + b_lds[i]), 16, b_voff[i], soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(Bb + B_IMG * 2 + b_lds[i]), 16, b_voff[i], soff + w_lo_bytes, 0, 0);
             }
+            if (++bt == taps.n) { bt = 0; bc0 += KC; }
         };
-        // ROWP: the patch unit (pixel pp, 8-channel group uu) a thread gathers does not depend on the kernel row except
-        // through iy = gy + dy: segment, image, reflected column and validity are fixed per thread, so only the row term is
-        // left inside the loop (the 64-bit divisions of the segment arithmetic used to run once per kernel row and unit)
-        int rp_gy[3], rp_nb[3], rp_ix[3];
-        bool rp_ok[3];
+        static_assert(BL == 2, "the vmcnt immediates below count 2 * BL = 4 DMA pieces per stage");
+        f32x8 ra[ROWP ? 3 : AL]; // ROWP: up to 3 of the <= 160*4 patch units per thread
+        auto store_a = [&](int j, int a_at, __bf16 *As) {
+            const float v[8] = {ra[j][0], ra[j][1], ra[j][2], ra[j][3], ra[j][4], ra[j][5], ra[j][6], ra[j][7]};
+            acg_u32x4 hi, lo;
+            acg_split8(v, hi, lo);
+            *(acg_u32x4 *)&As[a_at] = hi;
+            *(acg_u32x4 *)&As[AIMG + a_at] = lo;
+        };
+        auto load_a = [&](int j, unsigned off, bool ok) {
+            const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off, ok), 0, 0);
+            const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off + 16u, ok), 0, 0);
+            const f32x4 flo = __builtin_bit_cast(f32x4, lo), fhi = __builtin_bit_cast(f32x4, hi);
+            ra[j] = (f32x8){flo[0], flo[1], flo[2], flo[3], fhi[0], fhi[1], fhi[2], fhi[3]};
+        };
         if constexpr (ROWP) {
+            // The tile's 128 consecutive output pixels form SEGMENTS, one per grid row it touches (the first starts at column
+            // x0, the others at 0); segment s occupies image rows [row0(s), row0(s) + len(s) + K-1).
+            const long long grow0 = m0 / g.GW;                     // global grid row (image * GH + gy) of the first pixel
+            const int x0 = (int)(m0 - grow0 * g.GW);
+            const int first = g.GW - x0 < BM ? g.GW - x0 : BM;     // pixels in segment 0
+            const int RW = g.GW + kdim - 1;
+            const int nseg = first >= BM ? 1 : 1 + (BM - first + g.GW - 1) / g.GW;
+            const int npu = (BM + nseg * (kdim - 1)) * 4;
+            const long long grows = g.Mtot / g.GW;                 // grid rows in the whole tensor
+            // the patch unit (pixel pp, 8-channel group uu) a thread gathers does not depend on the kernel row except through
+            // iy = gy + dy: segment, image, reflected column and validity are fixed per thread, so only the row term is left
+            // inside the loop (the 64-bit divisions of the segment arithmetic used to run once per kernel row and unit)
+            int rp_gy[3], rp_nb[3], rp_ix[3];
+            bool rp_ok[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int q = pt + 256 * j;
@@ -186,33 +207,52 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
                 rp_ix[j] = ix;
                 rp_ok[j] = ok;
             }
-        }
-        int st_t = 0, st_c0 = 0, st_k = 0; // tap, first input channel and position in the kernel row of the NEXT stage to load
-        auto load_stage = [&]() {
-            const int c0 = st_c0;
-            const int pk = taps.pk[st_t];
-            const int ty = (pk << 24) >> 24, tx = (pk << 16) >> 24, tw = pk >> 16;
-            if constexpr (ROWP) {
-                if (st_k == 0) { // first tap of a kernel row: gather the R x (GW+K-1) patch of this row, from dx = dxmin
+            int ar_t = 0, ar_c0 = 0; // first tap and first input channel of the next kernel row to gather
+            auto load_a_row = [&]() { // the R x (GW+K-1) patch of one kernel row, from dx = dxmin
+                const int ty = (taps.pk[ar_t] << 24) >> 24;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int uu = (pt + 256 * j) & 3;
+                    int iy = rp_gy[j] + ty;
+                    bool ok = rp_ok[j];
+                    if (REFLECT) {
+                        iy = iy < 0 ? -iy : iy;
+                        iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
+                    } else {
+                        ok = ok && (unsigned)iy < (unsigned)g.Hin;
+                    }
+                    load_a(j, (unsigned)(((rp_nb[j] + iy) * g.Win + rp_ix[j]) * g.Cin + ar_c0 + 8 * uu) * 4u, ok);
+                }
+                ar_t += kdim;
+                if (ar_t >= taps.n) { ar_t = 0; ar_c0 += KC; }
+            };
+            const int rows = S / kdim;
+            load_a_row();
+            int pk_k = 0, row = 0; // position of stage s in its kernel row, and that row (its A buffer: row & 1)
+            for (int s = 0; s < S; ++s) {
+                dma_b(s & 1);
+                if (pk_k == 0) { // first stage of a kernel row: its patch (loaded a row ago, older than the DMA pieces just issued)
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
-                        const int uu = (pt + 256 * j) & 3;
-                        int iy = rp_gy[j] + ty;
-                        bool ok = rp_ok[j];
-                        if (REFLECT) {
-                            iy = iy < 0 ? -iy : iy;
-                            iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
-                        } else {
-                            ok = ok && (unsigned)iy < (unsigned)g.Hin;
-                        }
-                        const unsigned off = (unsigned)(((rp_nb[j] + iy) * g.Win + rp_ix[j]) * g.Cin + c0 + 8 * uu) * 4u;
-                        const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off, ok), 0, 0);
-                        const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off + 16u, ok), 0, 0);
-                        const f32x4 flo = __builtin_bit_cast(f32x4, lo), fhi = __builtin_bit_cast(f32x4, hi);
-                        ra[j] = (f32x8){flo[0], flo[1], flo[2], flo[3], fhi[0], fhi[1], fhi[2], fhi[3]};
+                        const int q = pt + 256 * j;
+                        if (q < npu) store_a(j, rp_at(q & 3, q >> 2), lds + L::a_off(row & 1));
                     }
                 }
-            } else {
+                if (pk_k == kdim - 1 && row + 1 < rows) {
+                    load_a_row();
+                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); // this stage's B pieces have landed; the next patch stays in flight
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if (++pk_k == kdim) { pk_k = 0; ++row; }
+                __syncthreads(); // B buffer s&1 (and the A buffer of its kernel row) is full; the consumers have drained the other
+            }
+        } else {
+            int st_t = 0, st_c0 = 0; // tap and first input channel of the next A stage to load
+            auto load_a_stage = [&]() {
+                const int pk = taps.pk[st_t];
+                const int ty = (pk << 24) >> 24, tx = (pk << 16) >> 24;
 #pragma unroll
                 for (int j = 0; j < AL; ++j) {
                     int pix;
@@ -229,57 +269,25 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
                         ok = ok && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
                         pix = a_row[j] + ty * g.Win + tx;
                     }
-                    const unsigned off = (unsigned)(pix * g.Cin + c0 + 8 * u) * 4u;
-                    const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off, ok), 0, 0);
-                    const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off + 16u, ok), 0, 0);
-                    const f32x4 flo = __builtin_bit_cast(f32x4, lo), fhi = __builtin_bit_cast(f32x4, hi);
-                    ra[j] = (f32x8){flo[0], flo[1], flo[2], flo[3], fhi[0], fhi[1], fhi[2], fhi[3]};
+                    load_a(j, (unsigned)(pix * g.Cin + st_c0 + 8 * u) * 4u, ok);
                 }
-            }
-            load_b(tw, c0);
-            if (++st_t == taps.n) { st_t = 0; st_c0 += KC; }
-            if (ROWP && ++st_k == kdim) st_k = 0;
-        };
-        load_stage();
-        int pk_k = 0, pk_buf = 0; // ROWP: position of stage s in its kernel row, and that row's A buffer
-        for (int s = 0; s < S; ++s) {
-            // A buffer: per kernel row in ROWP, per stage otherwise; B buffer: per stage
-            const bool a_new = !ROWP || pk_k == 0;
-            __bf16 *As = lds + L::a_off(ROWP ? pk_buf : s & 1), *Bs = lds + L::b_off(s & 1);
-            if (a_new) {
-                if constexpr (ROWP) {
+                if (++st_t == taps.n) { st_t = 0; st_c0 += KC; }
+            };
+            static_assert(AL == 2, "the vmcnt immediates below count 2 * AL = 4 A loads per stage");
+            load_a_stage();
+            for (int s = 0; s < S; ++s) {
+                dma_b(s & 1);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); // this stage's A tile (older than the DMA pieces)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const int q = pt + 256 * j;
-                        if (q < npu) {
-                            const int a_at = rp_at(q & 3, q >> 2);
-                            const float v[8] = {ra[j][0], ra[j][1], ra[j][2], ra[j][3], ra[j][4], ra[j][5], ra[j][6], ra[j][7]};
-                            acg_u32x4 hi, lo;
-                            acg_split8(v, hi, lo);
-                            *(acg_u32x4 *)&As[a_at] = hi;
-                            *(acg_u32x4 *)&As[AIMG + a_at] = lo;
-                        }
-                    }
+                for (int j = 0; j < AL; ++j) store_a(j, lds_at(u, rrow + RPP * j, APL), lds + L::a_off(s & 1));
+                if (s + 1 < S) {
+                    load_a_stage();
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); // the B pieces have landed; the next A tile stays in flight
                 } else {
-#pragma unroll
-                    for (int j = 0; j < AL; ++j) {
-                        const int a_at = lds_at(u, rrow + RPP * j, APL);
-                        const float v[8] = {ra[j][0], ra[j][1], ra[j][2], ra[j][3], ra[j][4], ra[j][5], ra[j][6], ra[j][7]};
-                        acg_u32x4 hi, lo;
-                        acg_split8(v, hi, lo);
-                        *(acg_u32x4 *)&As[a_at] = hi;
-                        *(acg_u32x4 *)&As[AIMG + a_at] = lo;
-                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
+                __syncthreads(); // buffers s&1 are full; the consumers have drained the others
             }
-#pragma unroll
-            for (int i = 0; i < BL; ++i) {
-                *(u32x4 *)&Bs[b_lds[i]] = rb[i];
-                *(u32x4 *)&Bs[B_IMG + b_lds[i]] = rbl[i];
-            }
-            if (s + 1 < S) load_stage();
-            if (ROWP && ++pk_k == kdim) { pk_k = 0; pk_buf ^= 1; }
-            __syncthreads(); // B buffer s&1 (and the A buffer of its kernel row) is full; the consumers have drained the other
         }
         return;
     }
