@@ -316,24 +316,33 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
             }
         }
     }
-    // ROWP: the taps of a kernel row step through the patch columns by kstep (+1 forward, -1 data gradient); kept in
-    // scalar counters (a per-stage scalar load of the tap behind the barrier stalled the wave on its latency)
+    // Fragment addresses: a per-lane byte offset fixed for the whole tile plus a wave-uniform stage offset (buffer, and
+    // in ROWP the tap's column: the taps of a kernel row step through the patch columns by kstep, +1 forward, -1 data
+    // gradient) kept in scalar counters — five v_add per stage (the index arithmetic written out per fragment cost 18
+    // VALU instructions per stage beside the MFMAs; a per-stage scalar load of the tap behind the barrier stalled the
+    // wave on its latency).  The four B fragments of a lane are 16 columns = 256 B apart (the XOR permutation only
+    // touches the low column bits).
+    int a_base[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_base[i] = 2 * (ROWP ? rp_at(pl, arow[i]) : lds_at(pl, wm * TM + i * 16 + lr, APL));
+    const int b_base = 2 * lds_at(pl, wn * TN + lr, BPL);
+    const char *ldsb = (const char *)lds;
     int kk = 0, abuf = 0, kx = ROWP ? (kstep > 0 ? 0 : kdim - 1) : 0;
     for (int s = 0; s < S; ++s) {
         __syncthreads();
-        const __bf16 *As = lds + L::a_off(ROWP ? abuf : s & 1), *Bs = lds + L::b_off(s & 1);
+        const int so_a = 2 * (L::a_off(ROWP ? abuf : s & 1) + (ROWP ? kx * 8 : 0)), so_b = 2 * L::b_off(s & 1);
         bf16x8 a[4], al[4], b[4], bl[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int at = ROWP ? rp_at(pl, arow[i] + kx) : lds_at(pl, wm * TM + i * 16 + lr, APL);
-            a[i] = *(const bf16x8 *)&As[at];
-            al[i] = *(const bf16x8 *)&As[AIMG + at];
+            const char *pa = ldsb + (a_base[i] + so_a);
+            a[i] = *(const bf16x8 *)pa;
+            al[i] = *(const bf16x8 *)(pa + 2 * AIMG);
         }
+        const char *pb = ldsb + (b_base + so_b);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int bt = lds_at(pl, wn * TN + j * 16 + lr, BPL);
-            b[j] = *(const bf16x8 *)&Bs[bt];
-            bl[j] = *(const bf16x8 *)&Bs[B_IMG + bt];
+            b[j] = *(const bf16x8 *)(pb + j * 256);
+            bl[j] = *(const bf16x8 *)(pb + 2 * B_IMG + j * 256);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
