@@ -12,6 +12,7 @@
 #include "common.h"
 #include "conv_internal.h"
 #include <cstdlib>
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
@@ -327,18 +328,14 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
     for (int i = 0; i < 4; ++i) a_base[i] = 2 * (ROWP ? rp_at(pl, arow[i]) : lds_at(pl, wm * TM + i * 16 + lr, APL));
     const int b_base = 2 * lds_at(pl, wn * TN + lr, BPL);
     const char *ldsb = (const char *)lds;
-    int kk = 0, abuf = 0, kx = ROWP ? (kstep > 0 ? 0 : kdim - 1) : 0;
-    for (int s = 0; s < S; ++s) {
-        __syncthreads();
-        const int so_a = 2 * (L::a_off(ROWP ? abuf : s & 1) + (ROWP ? kx * 8 : 0)), so_b = 2 * L::b_off(s & 1);
+    auto stage = [&](const char *pa_off, const char *pb) { // one K stage: 16 fragment reads, 48 MFMAs
         bf16x8 a[4], al[4], b[4], bl[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const char *pa = ldsb + (a_base[i] + so_a);
+            const char *pa = pa_off + a_base[i];
             a[i] = *(const bf16x8 *)pa;
             al[i] = *(const bf16x8 *)(pa + 2 * AIMG);
         }
-        const char *pb = ldsb + (b_base + so_b);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             b[j] = *(const bf16x8 *)(pb + j * 256);
@@ -352,9 +349,41 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             }
-        if constexpr (ROWP) {
-            kx += kstep;
-            if (++kk == kdim) { kk = 0; abuf ^= 1; kx = kstep > 0 ? 0 : kdim - 1; }
+    };
+    const char *pb0 = ldsb + b_base + 2 * L::b_off(0), *pb1 = ldsb + b_base + 2 * L::b_off(1);
+    bool done = false;
+    if constexpr (ROWP) {
+        if (kdim == 3 && S % 6 == 0) {
+            // 3 x 3 layers: six stages (two kernel rows) per trip, so buffer, tap column and B buffer of every stage are
+            // compile-time constants that ride in the ds_read offset field: no vector and hardly any scalar bookkeeping is
+            // left beside the MFMAs
+            auto run = [&](auto ks) {
+                constexpr int KS = decltype(ks)::value;
+                for (int it = 0; it < S / 6; ++it) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        __syncthreads();
+                        constexpr int dummy = 0;
+                        (void)dummy;
+                        const int kx = KS > 0 ? k % 3 : 2 - k % 3;
+                        stage(ldsb + 2 * (L::a_off(k / 3) + kx * 8), (k & 1) ? pb1 : pb0);
+                    }
+                }
+            };
+            if (kstep > 0) run(std::integral_constant<int, 1>{});
+            else run(std::integral_constant<int, -1>{});
+            done = true;
+        }
+    }
+    if (!done) {
+        int kk = 0, abuf = 0, kx = ROWP ? (kstep > 0 ? 0 : kdim - 1) : 0;
+        for (int s = 0; s < S; ++s) {
+            __syncthreads();
+            stage(ldsb + 2 * (L::a_off(ROWP ? abuf : s & 1) + (ROWP ? kx * 8 : 0)), (s & 1) ? pb1 : pb0);
+            if constexpr (ROWP) {
+                kx += kstep;
+                if (++kk == kdim) { kk = 0; abuf ^= 1; kx = kstep > 0 ? 0 : kdim - 1; }
+            }
         }
     }
     __builtin_amdgcn_s_setprio(0);
