@@ -142,10 +142,14 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
             b_voff[i] = (unsigned)((((plane >> 1) * g.ncols_pad + n0 + col) * 16 + (plane & 1) * 8) * 2);
             b_lds[i] = __builtin_amdgcn_readfirstlane((plane * BPL + (slot & ~63) * 8) * 2);   // byte offset of the wave's piece
         }
+        // the tap list lives in one VGPR (lane t = tap t) and is read with v_readlane: indexing the kernel argument with a
+        // run-time tap number is a scalar memory load per stage (neutral in the step: the producers have that slack)
+        const int tap_v = taps.pk[lane < taps.n ? lane : 0];
+        auto tap_pk = [&](int t) { return __builtin_amdgcn_readlane(tap_v, t); };
         int bt = 0, bc0 = 0; // tap and first input channel of the next B stage
         auto dma_b = [&](int buf) { // 2 * BL pieces per thread: hi and lo image of stage (bt, bc0) into B buffer `buf`
             char *Bb = (char *)(lds + L::b_off(buf));
-            const unsigned soff = (unsigned)((((taps.pk[bt] >> 16) * (g.Cin >> 4) + (bc0 >> 4)) * g.ncols_pad) * 16) * 2u;
+            const unsigned soff = (unsigned)((((tap_pk(bt) >> 16) * (g.Cin >> 4) + (bc0 >> 4)) * g.ncols_pad) * 16) * 2u;
 #pragma unroll
             for (int i = 0; i < BL; ++i) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(Bb + b_lds[i]), 16, b_voff[i], soff, 0, 0);
@@ -210,7 +214,7 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
             }
             int ar_t = 0, ar_c0 = 0; // first tap and first input channel of the next kernel row to gather
             auto load_a_row = [&]() { // the R x (GW+K-1) patch of one kernel row, from dx = dxmin
-                const int ty = (taps.pk[ar_t] << 24) >> 24;
+                const int ty = (tap_pk(ar_t) << 24) >> 24;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     const int uu = (pt + 256 * j) & 3;
@@ -252,7 +256,7 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
         } else {
             int st_t = 0, st_c0 = 0; // tap and first input channel of the next A stage to load
             auto load_a_stage = [&]() {
-                const int pk = taps.pk[st_t];
+                const int pk = tap_pk(st_t);
                 const int ty = (pk << 24) >> 24, tx = (pk << 16) >> 24;
 #pragma unroll
                 for (int j = 0; j < AL; ++j) {
