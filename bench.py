@@ -251,7 +251,7 @@ def main():
     # rocprofv3 --pmc passes; counters cannot be read inside the timed run), committed per kernel under profiles/
     traffic, traffic_src = None, None
     for cand in ({"f32": ["r01_c_resblock_conv_traffic_f32.json"],
-                  "bf16x3": ["r02_w_resblock_conv_traffic_bf16x3.json", "r02_p_resblock_conv_traffic_bf16x3.json", "r02_resblock_conv_traffic_bf16x3.json", "r01_f_resblock_conv_traffic_bf16x3.json"]}.get(a.precision, [])):
+                  "bf16x3": ["r02_z_resblock_conv_traffic_bf16x3.json", "r02_p_resblock_conv_traffic_bf16x3.json", "r02_resblock_conv_traffic_bf16x3.json", "r01_f_resblock_conv_traffic_bf16x3.json"]}.get(a.precision, [])):
         tj = os.path.join(ROOT, "profiles", cand)
         if os.path.exists(tj) and (N, S, nc) == (32, 256, 3):
             traffic, traffic_src = json.load(open(tj)).get("hbm_bytes_per_launch"), "profiles/" + cand
