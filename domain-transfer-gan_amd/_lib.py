@@ -35,6 +35,12 @@ class LatentMlpGrads(ctypes.Structure):
     _fields_ = [("dw", c_void_p * 4), ("db", c_void_p * 4), ("dgamma", c_void_p * 3), ("dbeta", c_void_p * 3)]
 
 
+class AdamGroup(ctypes.Structure):
+    """acg_adam_group (include/acgan_hip.h)."""
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_size_t), ("sumsq", c_void_p)]
+
+
+ADAM_MAX_GROUPS = 8
 _P = c_void_p
 _D = ctypes.POINTER(ConvDesc)
 _MP = ctypes.POINTER(LatentMlpParams)
@@ -95,6 +101,9 @@ SIGNATURES = {
     "acg_l1_bwd": (c_int, [_P, _P, c_size_t, c_int, c_int, _P, _P, _P, _P]),
     "acg_mean_fwd": (c_int, [_P, c_size_t, c_int, c_int, _P, _P, c_size_t, _P]),
     "acg_sumsq": (c_int, [_P, c_size_t, _P, _P, c_size_t, _P]),
+    "acg_clip_adam_multi_workspace_bytes": (c_size_t, [c_int]),
+    "acg_clip_adam_multi": (c_int, [ctypes.POINTER(AdamGroup), c_int, c_float, c_float, c_float, c_float, c_float, c_int, _P,
+                                    c_size_t, _P]),
     "acg_adam_step": (c_int, [_P, _P, _P, _P, c_size_t, _P, c_float, c_float, c_float, c_float, c_float, c_int,
                               c_int, _P]),
 }

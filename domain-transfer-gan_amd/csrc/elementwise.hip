@@ -462,6 +462,106 @@ __global__ void adam_kernel(float *__restrict__ p, float *__restrict__ g, float 
         if (scale_grads) g[i] = gi;
     }
 }
+// ---------------------------------------------------------------- the same for all networks of an optimiser phase
+// (multi-tensor: one partial-sums launch, one final launch, one Adam launch for up to ACG_ADAM_MAX_GROUPS flat buffers;
+// every group keeps the block count, the per-thread order of sums and the arithmetic of acg_sumsq + acg_adam_step, so the
+// results are bit-identical to calling those per network)
+struct AdamGroups {
+    acg_adam_group gr[ACG_ADAM_MAX_GROUPS];
+    int nb[ACG_ADAM_MAX_GROUPS], first[ACG_ADAM_MAX_GROUPS + 1]; // blocks of group i: [first[i], first[i] + nb[i])
+    int n;
+};
+__device__ __forceinline__ int adam_group_of(const AdamGroups &G, int block)
+{
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < ACG_ADAM_MAX_GROUPS; ++i) gi += (i < G.n && block >= G.first[i]) ? 1 : 0;
+    return gi;
+}
+__global__ __launch_bounds__(256) void sumsq_multi_partial_kernel(AdamGroups G, float *__restrict__ part)
+{
+    __shared__ float red[256];
+    const int gi = adam_group_of(G, blockIdx.x), lb = blockIdx.x - G.first[gi], nb = G.nb[gi];
+    const float *__restrict__ a = G.gr[gi].g;
+    const long long total = (long long)G.gr[gi].n;
+    float s = 0.f;
+    for (long long i = lb * 256LL + threadIdx.x; i < total; i += nb * 256LL) { const float v = a[i]; s += v * v; }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[gi * RED_BLOCKS + lb] = red[0];
+}
+__global__ __launch_bounds__(256) void sumsq_multi_final_kernel(AdamGroups G, const float *__restrict__ part)
+{
+    __shared__ float red[256];
+    const int gi = blockIdx.x;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < G.nb[gi]; i += 256) s += part[gi * RED_BLOCKS + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) G.gr[gi].sumsq[0] = red[0] * 1.f;
+}
+__global__ void adam_multi_kernel(AdamGroups G, float max_norm, float step_size, float beta1, float beta2, float inv_bc2_sqrt,
+                                  float eps)
+{
+    const int gi = adam_group_of(G, blockIdx.x), lb = blockIdx.x - G.first[gi], nb = G.nb[gi];
+    const acg_adam_group q = G.gr[gi];
+    float coef = max_norm / (sqrtf(q.sumsq[0]) + 1e-6f);
+    coef = coef < 1.f ? coef : 1.f;
+    for (long long i = lb * 256LL + threadIdx.x; i < (long long)q.n; i += nb * 256LL) {
+        const float gi_ = q.g[i] * coef;
+        const float mi = beta1 * q.m[i] + (1.f - beta1) * gi_;
+        const float vi = beta2 * q.v[i] + (1.f - beta2) * gi_ * gi_;
+        q.m[i] = mi;
+        q.v[i] = vi;
+        q.p[i] -= step_size * mi / (sqrtf(vi) * inv_bc2_sqrt + eps);
+        q.g[i] = gi_;
+    }
+}
+extern "C" size_t acg_clip_adam_multi_workspace_bytes(int ngroups)
+{
+    return (size_t)(ngroups > 0 ? ngroups : 0) * RED_BLOCKS * sizeof(float);
+}
+extern "C" int acg_clip_adam_multi(const acg_adam_group *groups, int ngroups, float max_norm, float lr, float beta1, float beta2,
+                                   float eps, int step, void *ws, size_t ws_bytes, void *stream)
+{
+    ACG_REQUIRE(groups != nullptr && ngroups >= 1 && ngroups <= ACG_ADAM_MAX_GROUPS, "acg_clip_adam_multi: 1..%d groups, got %d",
+                ACG_ADAM_MAX_GROUPS, ngroups);
+    ACG_REQUIRE(step >= 1, "acg_clip_adam_multi: step must be >= 1");
+    if (ws == nullptr || ws_bytes < acg_clip_adam_multi_workspace_bytes(ngroups)) {
+        acg_set_error("acg_clip_adam_multi: workspace too small");
+        return ACG_ERR_WORKSPACE;
+    }
+    AdamGroups S, A; // block tables of the sums pass (as acg_sumsq) and of the update pass (as acg_adam_step)
+    S.n = A.n = ngroups;
+    S.first[0] = A.first[0] = 0;
+    for (int i = 0; i < ngroups; ++i) {
+        const acg_adam_group &q = groups[i];
+        ACG_REQUIRE(q.p && q.g && q.m && q.v && q.sumsq && q.n > 0, "acg_clip_adam_multi: group %d has a null pointer or no elements", i);
+        S.gr[i] = A.gr[i] = q;
+        const long long nbl = ((long long)q.n + 2047) / 2048;
+        S.nb[i] = (int)(nbl > RED_BLOCKS ? RED_BLOCKS : (nbl < 1 ? 1 : nbl));
+        A.nb[i] = ew_blocks((long long)q.n);
+        S.first[i + 1] = S.first[i] + S.nb[i];
+        A.first[i + 1] = A.first[i] + A.nb[i];
+    }
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sumsq_multi_partial_kernel, dim3(S.first[ngroups]), dim3(256), 0, st, S, (float *)ws);
+    hipLaunchKernelGGL(sumsq_multi_final_kernel, dim3(ngroups), dim3(256), 0, st, S, (const float *)ws);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(A.first[ngroups]), dim3(256), 0, st, A, max_norm, (float)(lr / bc1), beta1, beta2,
+                       (float)(1.0 / sqrt(bc2)), eps);
+    ACG_CHECK_LAUNCH("acg_clip_adam_multi");
+    return ACG_OK;
+}
+
 extern "C" int acg_adam_step(float *p, float *g, float *m, float *v, size_t n, const float *sumsq, float max_norm,
                              float lr, float beta1, float beta2, float eps, int step, int scale_grads, void *stream)
 {

@@ -146,14 +146,11 @@ class FusedAdam(object):
         """per network: sumsq -> (device) clip coefficient -> Adam.  Returns the sumsq scalars."""
         g = self.param_groups[0]
         self.t += 1
-        out = []
+        ops.clip_adam_multi([(f.p, f.gv, f.m, f.v, f.sumsq) for f in self.flats], max_norm, g['lr'], g['betas'][0],
+                            g['betas'][1], g['eps'], self.t)
         for f in self.flats:
-            ops.sumsq(f.gv, f.sumsq)
-            out.append(f.sumsq)
-        for f in self.flats:
-            ops.adam_step(f.p, f.gv, f.m, f.v, f.sumsq, max_norm, g['lr'], g['betas'][0], g['betas'][1], g['eps'], self.t)
             mark_dirty(f.net)
-        return out
+        return [f.sumsq for f in self.flats]
 
     def state_dict(self):
         state, idx = {}, 0

@@ -834,6 +834,23 @@ def sumsq(flat, out):
     return out
 
 
+def clip_adam_multi(groups, max_norm, lr, beta1, beta2, eps, step):
+    """clip_grad_norm + Adam for all networks of a phase in three launches; groups = [(p, g, m, v, sumsq), ...] flat fp32
+    buffers of each network (sumsq: 1-element tensor that receives the gradient sum of squares)."""
+    n = len(groups)
+    arr = (_lib.AdamGroup * n)()
+    for i, (p, g, m, v, ss) in enumerate(groups):
+        _check(p, g, m, v, ss)
+        if not (p.numel() == g.numel() == m.numel() == v.numel()):
+            raise _lib.AcgError("clip_adam_multi: group %d buffers differ in size" % i)
+        arr[i].p, arr[i].g, arr[i].m, arr[i].v, arr[i].n, arr[i].sumsq = (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                                                           p.numel(), ss.data_ptr())
+    nb = _lib.query("acg_clip_adam_multi_workspace_bytes", n)
+    ws = workspace(nb, slot=1)
+    _lib.call("acg_clip_adam_multi", arr, n, float(max_norm), float(lr), float(beta1), float(beta2), float(eps), int(step),
+              _ptr(ws), nb, _stream())
+
+
 def adam_step(p, g, m, v, sumsq_t, max_norm, lr, beta1, beta2, eps, step, scale_grads=True):
     """clip (coefficient from the device-side sum of squares) + Adam on one flat buffer."""
     _check(p, g, m, v)

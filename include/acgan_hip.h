@@ -249,6 +249,20 @@ int acg_sumsq(const float *g, size_t n, float *out, void *workspace, size_t ws_b
 int acg_adam_step(float *p, float *g, float *m, float *v, size_t n, const float *sumsq, float max_norm, float lr,
                   float beta1, float beta2, float eps, int step, int scale_grads, void *stream);
 
+/* The same for every network of an optimiser phase in three launches (multi-tensor clip + Adam: model.py:447-452 clips and
+ * steps D_A, D_B (and D_z_B); model.py:510-515 G_A_B, G_B_A (and E_B)).  Per group: *sumsq = sum(g^2), then
+ * coef = min(1, max_norm/(sqrt(*sumsq)+1e-6)), g *= coef, Adam on (p, m, v).  Bit-identical to acg_sumsq + acg_adam_step
+ * (scale_grads = 1) per group.  The group array is host memory, read during the call. */
+#define ACG_ADAM_MAX_GROUPS 8
+typedef struct {
+    float *p, *g, *m, *v; /* device: parameters, gradients, first and second moments of one network, n floats each */
+    size_t n;
+    float *sumsq;         /* device: receives the network's gradient sum of squares (1 float) */
+} acg_adam_group;
+size_t acg_clip_adam_multi_workspace_bytes(int ngroups);
+int acg_clip_adam_multi(const acg_adam_group *groups, int ngroups, float max_norm, float lr, float beta1, float beta2, float eps,
+                        int step, void *workspace, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

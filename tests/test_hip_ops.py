@@ -419,6 +419,39 @@ def test_fused_latent_discriminator_equals_the_layer_chain(N, nlatent, ndf, flat
     assert np.abs(res[True][2]).max() > 0
 
 
+def test_multi_tensor_clip_adam_is_bit_identical_to_the_per_network_calls():
+    """acg_clip_adam_multi (one partial-sums, one final, one update launch for all networks of a phase; model.py:447-452,
+    510-515) against acg_sumsq + acg_adam_step per network: same block counts and order of sums -> identical bits, over
+    sizes from below one block to beyond the 1024-block cap, clipped and unclipped, three steps."""
+    from hip_util import n
+    from dtgan_amd import ops
+    torch.manual_seed(2)
+    sizes = [7, 2048 * 3 + 5, 2_500_000, 40_000]
+    scales = [1.0, 30.0, 0.3, 1e-3]         # gradient norms on both sides of max_norm
+    def make():
+        bufs = []
+        g = torch.Generator(device="cuda").manual_seed(4)
+        for sz, sc in zip(sizes, scales):
+            p = torch.randn(sz, device="cuda", generator=g)
+            gr = torch.randn(sz, device="cuda", generator=g) * sc
+            bufs.append([p, gr, torch.zeros(sz, device="cuda"), torch.zeros(sz, device="cuda"), torch.zeros(1, device="cuda")])
+        return bufs
+    A, B = make(), make()
+    for step in (1, 2, 3):
+        for (p, gr, m, v, ss) in A:
+            ops.sumsq(gr, ss)
+        for (p, gr, m, v, ss) in A:
+            ops.adam_step(p, gr, m, v, ss, 50.0, 2e-4, 0.5, 0.999, 1e-8, step)
+        ops.clip_adam_multi([tuple(b) for b in B], 50.0, 2e-4, 0.5, 0.999, 1e-8, step)
+        for a, b in zip(A, B):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y)
+        if step == 1:
+            assert float(A[1][4]) > 50.0 ** 2 > float(A[3][4])      # one network clipped, one not
+    with pytest.raises(Exception):
+        ops.clip_adam_multi([tuple(B[0])] * 9, 50.0, 2e-4, 0.5, 0.999, 1e-8, 1)
+
+
 def test_residual_norm_relu_fusion():
     """ResnetBlock tail: y = ReLU(x + IN(conv(...))) with the add + ReLU fused into the norm pass"""
     from hip_util import t, n, rel
