@@ -101,6 +101,10 @@ SIGNATURES = {
     "acg_l1_bwd": (c_int, [_P, _P, c_size_t, c_int, c_int, _P, _P, _P, _P]),
     "acg_mean_fwd": (c_int, [_P, c_size_t, c_int, c_int, _P, _P, c_size_t, _P]),
     "acg_sumsq": (c_int, [_P, c_size_t, _P, _P, c_size_t, _P]),
+    "acg_comm_unique_id": (c_int, [_P]),
+    "acg_comm_init": (c_int, [ctypes.POINTER(c_void_p), _P, c_int, c_int]),
+    "acg_comm_allreduce_mean": (c_int, [_P, _P, c_size_t, _P]),
+    "acg_comm_destroy": (c_int, [_P]),
     "acg_clip_adam_multi_workspace_bytes": (c_size_t, [c_int]),
     "acg_clip_adam_multi": (c_int, [ctypes.POINTER(AdamGroup), c_int, c_float, c_float, c_float, c_float, c_float, c_int, _P,
                                     c_size_t, _P]),

@@ -47,19 +47,50 @@ def rank():
     return td.get_rank() if is_on() else 0
 
 
+_ACG_COMM = None   # ACGAN_DP_BACKEND=acg_comm: (communicator handle, side stream) of the library's own RCCL wrappers
+
+
 def init_from_env(backend=None):
-    """torchrun-style init (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT / LOCAL_RANK)."""
+    """torchrun-style init (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT / LOCAL_RANK).
+    ACGAN_DP_BACKEND: "nccl" (default on a GPU: torch.distributed over RCCL), "gloo" (tests that put several ranks on one GPU;
+    RCCL wants one GPU per rank) or "acg_comm": the gradient buffers travel through the library's own C entry points
+    (acg_comm_*, include/acgan_hip.h: RCCL ncclAvg on a side stream) and torch.distributed/gloo is only the control plane
+    that ships the communicator id, the initial parameters and SyncBN's statistics."""
+    global _ACG_COMM
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     if (ws <= 1 and not _FORCE) or is_on():
         return rank(), world_size()
-    if backend is None:   # ACGAN_DP_BACKEND=gloo: tests that put several ranks on one GPU (RCCL wants one GPU per rank)
+    if backend is None:
         backend = os.environ.get("ACGAN_DP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-    if backend == "nccl":
+    if backend in ("nccl", "acg_comm"):
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    td.init_process_group(backend=backend)
+    td.init_process_group(backend="gloo" if backend == "acg_comm" else backend)
     if td.get_world_size() > MAX_RANKS:
         raise RuntimeError("the scalar tail of the gradient buffers holds %d ranks (one node); got %d" % (MAX_RANKS, td.get_world_size()))
+    if backend == "acg_comm":
+        import ctypes
+        from . import _lib
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if td.get_rank() == 0:
+            blob = (ctypes.c_char * 128)()
+            _lib.call("acg_comm_unique_id", ctypes.cast(blob, ctypes.c_void_p))
+            ident = torch.frombuffer(bytearray(blob.raw), dtype=torch.uint8).clone()
+        td.broadcast(ident, src=0)
+        raw = (ctypes.c_char * 128).from_buffer_copy(bytes(ident.numpy().tobytes()))
+        comm = ctypes.c_void_p()
+        _lib.call("acg_comm_init", ctypes.byref(comm), ctypes.cast(raw, ctypes.c_void_p), td.get_world_size(), td.get_rank())
+        _ACG_COMM = (comm, torch.cuda.Stream())
     return rank(), world_size()
+
+
+def shutdown():
+    """release the communicator of the acg_comm backend (tests; a training process simply exits)"""
+    global _ACG_COMM
+    if _ACG_COMM is not None:
+        from . import _lib
+        torch.cuda.synchronize()
+        _lib.call("acg_comm_destroy", _ACG_COMM[0])
+        _ACG_COMM = None
 
 
 def _staged():
@@ -72,9 +103,29 @@ class _Done(object):
         return True
 
 
+class _OnEvent(object):
+    """handle of a collective enqueued on the side stream: wait() orders the CURRENT stream behind it"""
+
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+        return True
+
+
 def _allreduce_avg_async(buf):
     """Average `buf` over the ranks in place; returns a handle whose wait() orders the current stream behind it."""
     ws = world_size()
+    if _ACG_COMM is not None and buf.is_cuda:   # the library's RCCL wrapper, on its own stream behind everything enqueued so far
+        import ctypes
+        from . import _lib
+        comm, side = _ACG_COMM
+        side.wait_stream(torch.cuda.current_stream())
+        _lib.call("acg_comm_allreduce_mean", comm, ctypes.c_void_p(buf.data_ptr()), buf.numel(), ctypes.c_void_p(side.cuda_stream))
+        ev = torch.cuda.Event()
+        ev.record(side)
+        return _OnEvent(ev)
     if td.get_backend() == "nccl":   # RCCL averages in the collective itself (ncclAvg): no extra kernel
         return td.all_reduce(buf, op=td.ReduceOp.AVG, async_op=True)
     if buf.is_cuda:                  # gloo + device tensors (tests): blocking, through the host

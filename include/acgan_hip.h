@@ -33,7 +33,8 @@ typedef enum {
     ACG_OK = 0,
     ACG_ERR_INVALID = -1,   /* bad argument / unsupported shape */
     ACG_ERR_WORKSPACE = -2, /* workspace too small */
-    ACG_ERR_LAUNCH = -3     /* hip launch error */
+    ACG_ERR_LAUNCH = -3,    /* hip launch error */
+    ACG_ERR_COMM = -4       /* RCCL unavailable or an RCCL call failed */
 } acg_status;
 
 typedef enum { ACG_ACT_NONE = 0, ACG_ACT_RELU = 1, ACG_ACT_LRELU = 2 /* slope 0.2 */, ACG_ACT_TANH = 3 } acg_act;
@@ -262,6 +263,17 @@ typedef struct {
 size_t acg_clip_adam_multi_workspace_bytes(int ngroups);
 int acg_clip_adam_multi(const acg_adam_group *groups, int ngroups, float max_norm, float lr, float beta1, float beta2, float eps,
                         int step, void *workspace, size_t ws_bytes, void *stream);
+
+/* ---- gradient exchange of the data-parallel step (replaces nn.parallel.data_parallel, networks.py:193-197 etc.): one
+ *      process per GPU; rank 0 makes an id and ships its ACG_COMM_ID_BYTES to the other ranks by any side channel; every
+ *      rank then joins with its current HIP device.  acg_comm_allreduce_mean averages a flat fp32 buffer (a network's
+ *      gradients, model.py:447-449 / 510-512 clip AFTER it) in place across the ranks, enqueued on `stream` (ncclAvg over
+ *      xGMI).  RCCL is bound at run time; the rest of the library does not need it. ---- */
+#define ACG_COMM_ID_BYTES 128
+int acg_comm_unique_id(void *id);
+int acg_comm_init(void **comm, const void *id, int nranks, int rank);
+int acg_comm_allreduce_mean(void *comm, float *buf, size_t n, void *stream);
+int acg_comm_destroy(void *comm);
 
 #ifdef __cplusplus
 }

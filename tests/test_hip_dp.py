@@ -76,3 +76,36 @@ def test_rccl_backend_one_rank_group(tmp_path):
         assert np.allclose(rccl[k], plain[k], rtol=3e-3, atol=1e-6), k
     for k in ("probe_fake_B", "probe_fake_A"):
         assert np.max(np.abs(rccl[k] - plain[k])) < 1e-2 * np.max(np.abs(plain[k])), k
+
+
+def test_acg_comm_backend_one_rank_group(tmp_path):
+    """The same through the library's own exchange entry points (acg_comm_unique_id / _init / _allreduce_mean / _destroy,
+    ACGAN_DP_BACKEND=acg_comm): RCCL bound at run time, the flat gradient buffers averaged on a side stream, gloo as the
+    control plane.  One rank (one GPU here), every collective forced."""
+    plain = _run(tmp_path, 1, 2, 29549)
+    comm = _run(tmp_path, 1, 2, 29550, ACGAN_DIST_FORCE="1", ACGAN_DP_BACKEND="acg_comm", RANK="0")
+    for k in ("s0/losses", "s0/gnorms"):
+        assert np.allclose(comm[k], plain[k], rtol=1e-5, atol=1e-7), k
+    for k in ("s1/losses", "s1/gnorms"):
+        assert np.allclose(comm[k], plain[k], rtol=3e-3, atol=1e-6), k
+
+
+def test_acg_comm_c_abi_one_rank():
+    """the four entry points called directly: id, init on the current device, in-place mean of a buffer, destroy"""
+    import ctypes
+    import torch
+    from dtgan_amd import _lib
+    blob = (ctypes.c_char * 128)()
+    _lib.call("acg_comm_unique_id", ctypes.cast(blob, ctypes.c_void_p))
+    assert any(blob.raw)
+    comm = ctypes.c_void_p()
+    _lib.call("acg_comm_init", ctypes.byref(comm), ctypes.cast(blob, ctypes.c_void_p), 1, 0)
+    x = torch.randn(100_003, device="cuda")
+    ref = x.clone()
+    _lib.call("acg_comm_allreduce_mean", comm, ctypes.c_void_p(x.data_ptr()), x.numel(),
+              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
+    _lib.call("acg_comm_destroy", comm)
+    with pytest.raises(_lib.AcgError):
+        _lib.call("acg_comm_init", ctypes.byref(comm), ctypes.cast(blob, ctypes.c_void_p), 1, 3)
