@@ -1,6 +1,6 @@
 // Probe: the bf16 MFMA rate the chip SUSTAINS on register operands (no LDS, no memory), as a ceiling for the convolution
 // kernels' executed-MFMA rate.  hipcc --offload-arch=gfx950 -O3 tools/probes/mfma_rate.hip -o tools/probes/mfma_rate
-//   ./mfma_rate [waves_per_simd=2] [random=1] [shape=16|32]
+//   ./mfma_rate [waves_per_simd=2] [random=1] [shape=16|32] [dep=0|1: three dependent MFMAs per accumulator, as the kernels issue them]
 // Every wave issues ITER x 16 MFMAs on 16 independent accumulators; operands are random bf16 (or zeros).
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -12,7 +12,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int SHAPE>
-__global__ __launch_bounds__(512) void mfma_loop(const u32x4 *__restrict__ src, float *__restrict__ out, int iters)
+__global__ __launch_bounds__(512) void mfma_loop(const u32x4 *__restrict__ src, float *__restrict__ out, int iters, int dep)
 {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     bf16x8 a[4], b[4];
@@ -28,6 +28,18 @@ __global__ __launch_bounds__(512) void mfma_loop(const u32x4 *__restrict__ src, 
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (dep) { // the convolution kernels' order: three products back to back on the same accumulator
+            for (int it = 0; it < iters / 3; ++it) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(i + 1) & 3], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[(j + 1) & 3], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -66,7 +78,7 @@ __global__ __launch_bounds__(512) void mfma_loop(const u32x4 *__restrict__ src, 
 int main(int argc, char **argv)
 {
     const int wps = argc > 1 ? atoi(argv[1]) : 2, rnd = argc > 2 ? atoi(argv[2]) : 1, shape = argc > 3 ? atoi(argv[3]) : 16;
-    const int iters = 20000;
+    const int iters = 19998, dep = argc > 4 ? atoi(argv[4]) : 0;
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount;
@@ -89,8 +101,8 @@ int main(int argc, char **argv)
     hipEventCreate(&e1);
     for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(e0);
-        if (shape == 16) hipLaunchKernelGGL(mfma_loop<16>, dim3(wgs), dim3(threads), 0, 0, src, out, iters);
-        else hipLaunchKernelGGL(mfma_loop<32>, dim3(wgs), dim3(threads), 0, 0, src, out, iters);
+        if (shape == 16) hipLaunchKernelGGL(mfma_loop<16>, dim3(wgs), dim3(threads), 0, 0, src, out, iters, dep);
+        else hipLaunchKernelGGL(mfma_loop<32>, dim3(wgs), dim3(threads), 0, 0, src, out, iters, dep);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
