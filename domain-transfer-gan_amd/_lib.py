@@ -106,7 +106,7 @@ SIGNATURES = {
     "acg_comm_allreduce_mean": (c_int, [_P, _P, c_size_t, _P]),
     "acg_comm_destroy": (c_int, [_P]),
     "acg_clip_adam_multi_workspace_bytes": (c_size_t, [c_int]),
-    "acg_clip_adam_multi": (c_int, [ctypes.POINTER(AdamGroup), c_int, c_float, c_float, c_float, c_float, c_float, c_int, _P,
+    "acg_clip_adam_multi": (c_int, [ctypes.POINTER(AdamGroup), c_int, c_float, c_float, c_float, c_float, c_float, c_int, _P, _P,
                                     c_size_t, _P]),
     "acg_adam_step": (c_int, [_P, _P, _P, _P, c_size_t, _P, c_float, c_float, c_float, c_float, c_float, c_int,
                               c_int, _P]),

@@ -509,10 +509,15 @@ __global__ __launch_bounds__(256) void sumsq_multi_final_kernel(AdamGroups G, co
     if (threadIdx.x == 0) G.gr[gi].sumsq[0] = red[0] * 1.f;
 }
 __global__ void adam_multi_kernel(AdamGroups G, float max_norm, float step_size, float beta1, float beta2, float inv_bc2_sqrt,
-                                  float eps)
+                                  float eps, float lr, const int *__restrict__ step_dev)
 {
     const int gi = adam_group_of(G, blockIdx.x), lb = blockIdx.x - G.first[gi], nb = G.nb[gi];
     const acg_adam_group q = G.gr[gi];
+    if (step_dev != nullptr) { // the step number lives on the device (a captured graph replays this launch with fixed arguments)
+        const int step = step_dev[0] + 1;
+        step_size = (float)((double)lr / (1.0 - pow((double)beta1, (double)step)));
+        inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+    }
     float coef = max_norm / (sqrtf(q.sumsq[0]) + 1e-6f);
     coef = coef < 1.f ? coef : 1.f;
     for (long long i = lb * 256LL + threadIdx.x; i < (long long)q.n; i += nb * 256LL) {
@@ -530,11 +535,12 @@ extern "C" size_t acg_clip_adam_multi_workspace_bytes(int ngroups)
     return (size_t)(ngroups > 0 ? ngroups : 0) * RED_BLOCKS * sizeof(float);
 }
 extern "C" int acg_clip_adam_multi(const acg_adam_group *groups, int ngroups, float max_norm, float lr, float beta1, float beta2,
-                                   float eps, int step, void *ws, size_t ws_bytes, void *stream)
+                                   float eps, int step, const int *step_dev, void *ws, size_t ws_bytes, void *stream)
 {
     ACG_REQUIRE(groups != nullptr && ngroups >= 1 && ngroups <= ACG_ADAM_MAX_GROUPS, "acg_clip_adam_multi: 1..%d groups, got %d",
                 ACG_ADAM_MAX_GROUPS, ngroups);
-    ACG_REQUIRE(step >= 1, "acg_clip_adam_multi: step must be >= 1");
+    ACG_REQUIRE(step >= 1 || step_dev != nullptr, "acg_clip_adam_multi: step must be >= 1");
+    if (step < 1) step = 1;
     if (ws == nullptr || ws_bytes < acg_clip_adam_multi_workspace_bytes(ngroups)) {
         acg_set_error("acg_clip_adam_multi: workspace too small");
         return ACG_ERR_WORKSPACE;
@@ -557,7 +563,7 @@ extern "C" int acg_clip_adam_multi(const acg_adam_group *groups, int ngroups, fl
     hipLaunchKernelGGL(sumsq_multi_partial_kernel, dim3(S.first[ngroups]), dim3(256), 0, st, S, (float *)ws);
     hipLaunchKernelGGL(sumsq_multi_final_kernel, dim3(ngroups), dim3(256), 0, st, S, (const float *)ws);
     hipLaunchKernelGGL(adam_multi_kernel, dim3(A.first[ngroups]), dim3(256), 0, st, A, max_norm, (float)(lr / bc1), beta1, beta2,
-                       (float)(1.0 / sqrt(bc2)), eps);
+                       (float)(1.0 / sqrt(bc2)), eps, lr, step_dev);
     ACG_CHECK_LAUNCH("acg_clip_adam_multi");
     return ACG_OK;
 }

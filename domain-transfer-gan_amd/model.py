@@ -137,6 +137,8 @@ class FusedAdam(object):
         self.flats = list(flats)
         self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False)]
         self.t = 0
+        self.t_dev = None      # int32 device copy of t, read by the kernels of a captured step graph (StepGraph)
+        self.dev_step = False  # True only while StepGraph captures: the recorded launches take the step from t_dev
 
     def zero_grad(self):
         for f in self.flats:
@@ -147,7 +149,7 @@ class FusedAdam(object):
         g = self.param_groups[0]
         self.t += 1
         ops.clip_adam_multi([(f.p, f.gv, f.m, f.v, f.sumsq) for f in self.flats], max_norm, g['lr'], g['betas'][0],
-                            g['betas'][1], g['eps'], self.t)
+                            g['betas'][1], g['eps'], self.t, self.t_dev if self.dev_step else None)
         for f in self.flats:
             mark_dirty(f.net)
         return [f.sumsq for f in self.flats]
@@ -176,6 +178,74 @@ class FusedAdam(object):
                     self.t = int(float(st['step']))
                 idx += 1
         self.param_groups[0]['lr'] = sd['param_groups'][0]['lr']
+
+
+class _PendingVals(object):
+    """the step's scalars still on the device (graph capture): names, the stacked tensor and the closure that turns the
+    host-side values into what train_instance returns"""
+
+    def __init__(self, names, dev):
+        self.names, self.dev, self.finish = names, dev, None
+
+    def resolve(self):
+        return self.finish(OrderedDict(zip(self.names, self.dev.tolist())))
+
+
+class StepGraph(object):
+    """train_instance captured into a HIP graph (torch.cuda.CUDAGraph drives hipStreamBeginCapture / hipGraphLaunch; the
+    library's ctypes launches go to the capturing stream like torch's own kernels).  What a replay cannot take from the
+    host is kept on the device: the inputs (static buffers copied into), the Adam step number (FusedAdam.t_dev, read by
+    acg_clip_adam_multi) and the reported scalars (one .tolist() after the replay).  The learning rates are launch
+    arguments: a change re-captures."""
+    WARMUP = 2
+
+    def __init__(self, model):
+        self.model, self.graph, self.key, self.calls = model, None, None, 0
+
+    def _key(self, a, b, z):
+        lrs = tuple(opt.param_groups[0]['lr'] for opt in self.model._optimizers().values())
+        return (tuple(a.shape), tuple(b.shape), tuple(z.shape), lrs, self.model.netG_A_B.training)
+
+    def __call__(self, real_A, real_B, prior_z_B):
+        m = self.model
+        key = self._key(real_A, real_B, prior_z_B)
+        self.calls += 1
+        if self.calls <= self.WARMUP:                 # lazily built state (packed weights, workspaces) settles eagerly
+            with _in_train_step():
+                return m._train_instance(real_A, real_B, prior_z_B)
+        opts = list(m._optimizers().values())
+        if self.graph is None or key != self.key:
+            self.inputs = [real_A.clone(), real_B.clone(), prior_z_B.clone()]
+            for opt in opts:
+                if opt.t_dev is None:
+                    opt.t_dev = torch.zeros(1, dtype=torch.int32, device=real_A.device)
+            self.graph, self.key = torch.cuda.CUDAGraph(), key
+            # every derived tensor the step uses (packed weights, padded vectors) must be rebuilt INSIDE the graph: a cache
+            # that is still valid here — the discriminators', packed in the previous step's G phase — would be baked in as a
+            # pointer to eager memory and as the weights of one particular step
+            for net in m._nets():
+                mark_dirty(net)
+            m._capturing = True
+            for opt in opts:
+                opt.dev_step = True
+            try:
+                with torch.cuda.graph(self.graph), _in_train_step():
+                    self.pending = m._train_instance(*self.inputs)
+            finally:
+                m._capturing = False
+                for opt in opts:                      # the capture ran clip_and_step's host side once without executing it
+                    opt.t -= 1
+                    opt.dev_step = False
+        for dst, src in zip(self.inputs, (real_A, real_B, prior_z_B)):
+            dst.copy_(src)
+        for opt in opts:
+            opt.t_dev.fill_(opt.t)
+        self.graph.replay()
+        for opt in opts:
+            opt.t += 1
+        for net in m._nets():                         # the replay repacked and then updated the weights behind Python's caches
+            mark_dirty(net)
+        return self.pending.resolve()
 
 
 class _Base(object):
@@ -221,8 +291,28 @@ class _Base(object):
             if mm:
                 mm = [per_rank[:, i].min() for i in range(len(mins))] + \
                      [per_rank[:, len(mins) + i].max() for i in range(len(maxs))]
-        vals = torch.stack(sums + [t.detach().reshape(()).float() for t in local] + mm).tolist()
-        return OrderedDict(zip(names, vals))
+        dev = torch.stack(sums + [t.detach().reshape(()).float() for t in local] + mm)
+        if self._capturing:        # StepGraph: the copy to the host happens after the replay
+            return _PendingVals(names, dev)
+        return OrderedDict(zip(names, dev.tolist()))
+
+    _capturing = False
+    _step_graph = None
+
+    def _report(self, vals, finish):
+        """finish(vals) builds what the step returns from the host-side scalars; deferred while a graph is being captured"""
+        if isinstance(vals, _PendingVals):
+            vals.finish = finish
+            return vals
+        return finish(vals)
+
+    def enable_step_graph(self, on=True):
+        """Run train_instance as ONE captured HIP graph per (shapes, learning rates): the whole step — about 3 000 kernel
+        launches — is replayed by a single host call.  Worth it where the step is launch-bound (small images / batches:
+        64 x 64 x 4 runs 28 ms eager against the 33 ms of Python it takes to enqueue); at 256 x 256 x 32 the GPU is the
+        bound either way.  The first calls run eagerly (warm-up), the tensors in the returned `visuals` are overwritten by the
+        next call, and the data-parallel exchange keeps the eager path."""
+        self._step_graph = StepGraph(self) if on else None
 
     # ---- forward-only helpers shared by both models (model.py:210-280, 606-733): compositions of the two generators.
     # Subclass hooks: _z (noise transform), _cycle_code (the latent the B -> A -> B cycle is closed with).
@@ -355,6 +445,8 @@ class StochCycleGAN(_Base):
         self.optimizer_D = FusedAdam([self.f_D_A, self.f_D_B], o.lr / 5., (o.beta1, 0.999))     # model.py:112-114
 
     def train_instance(self, real_A, real_B, prior_z_B):
+        if self._step_graph is not None and not acg_dist.exchange_on():
+            return self._step_graph(real_A, real_B, prior_z_B)
         with _in_train_step():
             return self._train_instance(real_A, real_B, prior_z_B)
 
@@ -404,14 +496,17 @@ class StochCycleGAN(_Base):
         names = ['D_A', 'G_A', 'Cyc_A', 'D_B', 'G_B', 'Cyc_B', 'P_t_A', 'P_f_A', 'P_t_B', 'P_f_B',
                  'gnorm_G_A_B', 'gnorm_G_B_A', 'gnorm_D_B', 'gnorm_D_A']
         vals = self._scalars(ex_G, self.f_G_A_B, names, sums, local=[ss_G_A_B, ss_G_B_A, ss_D_B, ss_D_A])
-        losses = OrderedDict((k, vals[k]) for k in names[:10])                                   # model.py:193-196
         visuals = OrderedDict([('real_A', real_A.detach()), ('fake_B', self._nchw(fake_B, nB)),
                                ('rec_A', self._nchw(rec_A, nA)), ('real_B', real_B.detach()),
                                ('fake_A', self._nchw(fake_A, nA)), ('rec_B', self._nchw(rec_B, nB))])
-        if o.monitor_gnorm:
-            gnorms = OrderedDict((k, math.sqrt(max(vals[k], 0.0))) for k in names[10:])          # model.py:202-205
-            return losses, visuals, gnorms
-        return losses, visuals
+
+        def finish(vals):
+            losses = OrderedDict((k, vals[k]) for k in names[:10])                               # model.py:193-196
+            if o.monitor_gnorm:
+                gnorms = OrderedDict((k, math.sqrt(max(vals[k], 0.0))) for k in names[10:])      # model.py:202-205
+                return losses, visuals, gnorms
+            return losses, visuals
+        return self._report(vals, finish)
 
     # ---- hooks of the shared forward-only helpers (_Base; model.py:210-280) -------------------
     _noise_before_code = False
@@ -527,6 +622,8 @@ class AugmentedCycleGAN(_Base):
         return self.netE_B.forward_nhwc(x)
 
     def train_instance(self, real_A, real_B, prior_z_B):
+        if self._step_graph is not None and not acg_dist.exchange_on():
+            return self._step_graph(real_A, real_B, prior_z_B)
         with _in_train_step():
             return self._train_instance(real_A, real_B, prior_z_B)
 
@@ -619,16 +716,19 @@ class AugmentedCycleGAN(_Base):
                  'mu_min', 'logvar_min', 'mu_max', 'logvar_max']
         vals = self._scalars(ex_G, self.f_G_A_B, names, sums, mins, maxs,
                              local=[ss_G_A_B, ss_G_B_A, ss_E, ss_D_B, ss_D_z, ss_D_A])
-        losses = OrderedDict((k, vals[k]) for k in names[:13])                                  # model.py:518-523
         visuals = OrderedDict([('real_A', real_A.detach()), ('fake_B', self._nchw(fake_B, nB)),
                                ('rec_A', self._nchw(rec_A, nA)), ('real_B', real_B.detach()),
                                ('fake_A', self._nchw(fake_A, nA)), ('rec_B', self._nchw(rec_B, nB))])
-        if o.monitor_gnorm:
-            gnorms = OrderedDict((k, math.sqrt(max(vals[k], 0.0))) for k in names[13:19])       # model.py:527-533
-            for k in ('mu_min', 'mu_max', 'logvar_min', 'logvar_max'):
-                gnorms[k] = vals[k]
-            return losses, visuals, gnorms
-        return losses, visuals
+
+        def finish(vals):
+            losses = OrderedDict((k, vals[k]) for k in names[:13])                              # model.py:518-523
+            if o.monitor_gnorm:
+                gnorms = OrderedDict((k, math.sqrt(max(vals[k], 0.0))) for k in names[13:19])   # model.py:527-533
+                for k in ('mu_min', 'mu_max', 'logvar_min', 'logvar_max'):
+                    gnorms[k] = vals[k]
+                return losses, visuals, gnorms
+            return losses, visuals
+        return self._report(vals, finish)
 
     def supervised_train_instance(self, real_A, real_B, prior_z_B):
         """model.py:541-604 (paired step; off by default, --supervised)"""

@@ -834,9 +834,10 @@ def sumsq(flat, out):
     return out
 
 
-def clip_adam_multi(groups, max_norm, lr, beta1, beta2, eps, step):
+def clip_adam_multi(groups, max_norm, lr, beta1, beta2, eps, step, step_dev=None):
     """clip_grad_norm + Adam for all networks of a phase in three launches; groups = [(p, g, m, v, sumsq), ...] flat fp32
-    buffers of each network (sumsq: 1-element tensor that receives the gradient sum of squares)."""
+    buffers of each network (sumsq: 1-element tensor that receives the gradient sum of squares).  step_dev: int32 device
+    tensor holding the number of COMPLETED steps (graph capture: the kernel reads it instead of `step`)."""
     n = len(groups)
     arr = (_lib.AdamGroup * n)()
     for i, (p, g, m, v, ss) in enumerate(groups):
@@ -848,7 +849,7 @@ def clip_adam_multi(groups, max_norm, lr, beta1, beta2, eps, step):
     nb = _lib.query("acg_clip_adam_multi_workspace_bytes", n)
     ws = workspace(nb, slot=1)
     _lib.call("acg_clip_adam_multi", arr, n, float(max_norm), float(lr), float(beta1), float(beta2), float(eps), int(step),
-              _ptr(ws), nb, _stream())
+              _ptr(step_dev), _ptr(ws), nb, _stream())
 
 
 def adam_step(p, g, m, v, sumsq_t, max_norm, lr, beta1, beta2, eps, step, scale_grads=True):

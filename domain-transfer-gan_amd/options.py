@@ -76,6 +76,8 @@ _T = [
      "and the parity tests run), f32 (exact products, 2.4x slower), bf16 (rounded operands, outside the parity bar)"),
     ("synthetic", int, 0, "use N synthetic U(-1,1) samples per split instead of --dataroot"),
     ("sync_bn", "flag", False, "data parallel: BatchNorm (E_B, D_z_B) statistics across all ranks"),
+    ("step_graph", "flag", False, "replay the training step as one captured HIP graph (launch-bound sizes: small images / "
+                                  "batches; single GPU)"),
     ("eval_steps", int, 50, "variational-bound steps per epoch (train.py:285 uses 50)"),
 ]
 

@@ -159,6 +159,8 @@ class Trainer(object):
             raise NotImplementedError('Specified model is not implemented.')
         self.log("model [%s] was created (conv arithmetic: %s, %d rank%s)"
                  % (self.model.__class__.__name__, ops.get_precision(), self.ws, "" if self.ws == 1 else "s"))
+        if getattr(o, "step_graph", False) and not getattr(o, "supervised", False):
+            self.model.enable_step_graph()            # ignored while the data-parallel exchange is on (model.train_instance)
         if o.continue_train:
             chk = os.path.join(o.expr_dir, o.which_epoch)
             self.model.load(chk)

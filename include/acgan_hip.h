@@ -253,7 +253,9 @@ int acg_adam_step(float *p, float *g, float *m, float *v, size_t n, const float 
 /* The same for every network of an optimiser phase in three launches (multi-tensor clip + Adam: model.py:447-452 clips and
  * steps D_A, D_B (and D_z_B); model.py:510-515 G_A_B, G_B_A (and E_B)).  Per group: *sumsq = sum(g^2), then
  * coef = min(1, max_norm/(sqrt(*sumsq)+1e-6)), g *= coef, Adam on (p, m, v).  Bit-identical to acg_sumsq + acg_adam_step
- * (scale_grads = 1) per group.  The group array is host memory, read during the call. */
+ * (scale_grads = 1) per group.  The group array is host memory, read during the call.  step_dev (device, may be NULL): when
+ * given, the step number of the bias corrections is *step_dev + 1, read by the kernel — for a launch recorded into a HIP
+ * graph, whose arguments are fixed at capture (`step` is then ignored). */
 #define ACG_ADAM_MAX_GROUPS 8
 typedef struct {
     float *p, *g, *m, *v; /* device: parameters, gradients, first and second moments of one network, n floats each */
@@ -262,7 +264,7 @@ typedef struct {
 } acg_adam_group;
 size_t acg_clip_adam_multi_workspace_bytes(int ngroups);
 int acg_clip_adam_multi(const acg_adam_group *groups, int ngroups, float max_norm, float lr, float beta1, float beta2, float eps,
-                        int step, void *workspace, size_t ws_bytes, void *stream);
+                        int step, const int *step_dev, void *workspace, size_t ws_bytes, void *stream);
 
 /* ---- gradient exchange of the data-parallel step (replaces nn.parallel.data_parallel, networks.py:193-197 etc.): one
  *      process per GPU; rank 0 makes an id and ships its ACG_COMM_ID_BYTES to the other ranks by any side channel; every

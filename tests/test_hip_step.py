@@ -174,3 +174,33 @@ def test_stoch_enc_branch_against_oracle(prec, monkeypatch):
         for k in ("fake_A", "fake_B", "rec_A", "rec_B"):
             assert rel(n(v1[k]), v0[k]) < vt, k
         assert l1["KLD_z_B"] != 0.0
+
+
+@pytest.mark.parametrize("aug", [True, False])
+def test_step_as_one_captured_graph_matches_the_eager_step(aug):
+    """enable_step_graph(): train_instance replayed as one HIP graph (inputs, Adam step number and reported scalars kept on
+    the device) against the eager step on an identically initialised model, over seven steps (two eager warm-up calls, the
+    capture, more replays) with a learning-rate change in between (re-capture).  Not bit-identical: the graph's Adam
+    kernel forms the bias corrections on the device."""
+    meta = dict(opt=dict(input_nc=1, output_nc=1, n_blocks=2), aug=aug, seed=5, flavour="init")
+    ref, gr = build_model(meta), build_model(meta)
+    gr.enable_step_graph()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for step in range(7):
+        if step == 5:
+            ref.update_learning_rate(); gr.update_learning_rate()
+        a = torch.randn(4, 1, 64, 64, device="cuda", generator=g).clamp_(-1, 1)
+        b = torch.randn(4, 1, 64, 64, device="cuda", generator=g).clamp_(-1, 1)
+        z = torch.randn(4, 16, 1, 1, device="cuda", generator=g)
+        lr_, vr, gn_r = ref.train_instance(a, b, z)
+        lg, vg, gn_g = gr.train_instance(a, b, z)
+        assert list(lr_.keys()) == list(lg.keys()) and list(gn_r.keys()) == list(gn_g.keys())
+        for k in lr_:
+            assert abs(lr_[k] - lg[k]) <= 2e-3 * max(1.0, abs(lr_[k])), (step, k, lr_[k], lg[k])
+        for k in gn_r:
+            assert abs(gn_r[k] - gn_g[k]) <= 2e-2 * max(1e-3, abs(gn_r[k])), (step, k, gn_r[k], gn_g[k])
+        assert float((vr["fake_B"] - vg["fake_B"]).abs().max()) < 2e-2
+        assert vg["real_A"].shape == a.shape and torch.equal(vg["real_A"], a)
+    assert gr._step_graph.graph is not None
+    for o_r, o_g in zip(ref._optimizers().values(), gr._optimizers().values()):
+        assert o_r.t == o_g.t == 7
