@@ -447,6 +447,7 @@ __global__ void adam_kernel(float *__restrict__ p, float *__restrict__ g, float 
                             long long n, const float *__restrict__ sumsq, float max_norm, float step_size, float beta1,
                             float beta2, float inv_bc2_sqrt, float eps, int scale_grads)
 {
+#pragma clang fp contract(off) // the same roundings as adam_multi_kernel whatever the compiler would fuse in either
     float coef = 1.f;
     if (sumsq != nullptr) {
         coef = max_norm / (sqrtf(sumsq[0]) + 1e-6f);
@@ -511,6 +512,7 @@ __global__ __launch_bounds__(256) void sumsq_multi_final_kernel(AdamGroups G, co
 __global__ void adam_multi_kernel(AdamGroups G, float max_norm, float step_size, float beta1, float beta2, float inv_bc2_sqrt,
                                   float eps, float lr, const int *__restrict__ step_dev)
 {
+#pragma clang fp contract(off) // bit-identical to adam_kernel (see there)
     const int gi = adam_group_of(G, blockIdx.x), lb = blockIdx.x - G.first[gi], nb = G.nb[gi];
     const acg_adam_group q = G.gr[gi];
     if (step_dev != nullptr) { // the step number lives on the device (a captured graph replays this launch with fixed arguments)

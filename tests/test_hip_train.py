@@ -46,6 +46,20 @@ def test_train_driver_end_to_end(tmp_path):
     assert "continue_train: loaded" in log2 and log2.count("End of epoch 2 / 2") == 2
 
 
+def test_train_driver_with_step_graph(tmp_path):
+    """train.py --step_graph: the unsupervised step replayed as one captured HIP graph between the driver's eager
+    visualisation / evaluation forwards, across a learning-rate change (re-capture)"""
+    from dtgan_amd.train import train_model
+    args = ["--name", "graph", "--checkpoints_dir", str(tmp_path), "--synthetic", "24", "--grid_size", "64", "--batchSize", "4",
+            "--ngf", "8", "--nef", "8", "--ndf", "8", "--nlatent", "4", "--niter", "1", "--niter_decay", "2", "--print_freq", "4",
+            "--display_freq", "12", "--save_epoch_freq", "3", "--eval_steps", "2", "--num_multi", "2", "--seed", "1", "--step_graph"]
+    train_model(args)
+    log = open(os.path.join(str(tmp_path), "graph", "results.txt")).read()
+    vals = [float(v) for v in re.findall(r" D_A: ([-\d.]+(?:e-?\d+)?|nan) ", log)]
+    assert len(vals) >= 9 and all(np.isfinite(vals)) and "End of epoch 3 / 3" in log, log[-1500:]
+    assert all(0.0 < v < 2.0 for v in vals)
+
+
 def test_two_rank_training_driver_with_syncbn(tmp_path):
     """train.py under data parallelism: 2 ranks (gloo, sharing this box's GPU), --sync_bn, PNG dumps and the per-epoch
     evaluation on rank 0 only.  Those rank-0-only forwards run BatchNorm in train mode (the reference never calls eval());
