@@ -66,6 +66,12 @@ SIGNATURES = {
     "acg_conv2d_fwd": (c_int, [_D, _P, _P, _P, _P, c_int, _P]),
     "acg_conv2d_bwd_data_workspace_bytes": (c_size_t, [_D]),
     "acg_conv2d_bwd_data": (c_int, [_D, _P, _P, _P, _P, c_size_t, _P]),
+    "acg_s16_encode": (c_int, [_P, _P, c_size_t, _P]),
+    "acg_s16_decode": (c_int, [_P, _P, c_size_t, _P]),
+    "acg_conv2d_s16_supported": (c_int, [_D]),
+    "acg_conv2d_fwd_s16": (c_int, [_D, _P, _P, _P, _P, c_int, _P, c_int, _P]),
+    "acg_conv2d_bwd_data_s16": (c_int, [_D, _P, _P, _P, _P, c_size_t, _P, _P, _P, c_int, _P]),
+    "acg_conv2d_bwd_weight_s16": (c_int, [_D, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
     "acg_conv2d_bwd_weight_workspace_bytes": (c_size_t, [_D]),
     "acg_conv2d_bwd_weight": (c_int, [_D, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
     "acg_conv_transpose2d_fwd": (c_int, [_D, _P, _P, _P, _P, c_int, _P]),
@@ -113,6 +119,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 110   # include/acgan_hip.h ACG_VERSION this binding was written against
 
 
 class AcgError(RuntimeError):
@@ -131,6 +138,10 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype, fn.argtypes = res, args
+    got = lib.acg_version()
+    if got != ABI_VERSION:   # a stale build would take shifted arguments instead of failing cleanly
+        raise AcgError("%s reports ABI version %d, this binding expects %d — rebuild it (make -C %s)"
+                       % (LIB_PATH, got, ABI_VERSION, os.path.join(_HERE, "csrc")))
     _lib = lib
     return lib
 

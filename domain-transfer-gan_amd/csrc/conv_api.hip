@@ -349,7 +349,7 @@ __global__ void reflect_fold_kernel(const float *__restrict__ dxp, float *__rest
 // 2p rows x W plus 2p columns x (H - 2p) pixels per image instead of all H x W.
 __global__ void reflect_fold_frame_kernel(const float *__restrict__ dxp, float *__restrict__ dx, int N, int H, int W, int C,
                                           int p, const float *__restrict__ addend, const float *__restrict__ relu_src,
-                                          const unsigned *__restrict__ addend_mask)
+                                          const unsigned *__restrict__ addend_mask, int out_s16, int relu_s16)
 {
     const int C4 = C / 4;
     const int nrow = 2 * p * W, ncol = 2 * p * (H - 2 * p); // frame pixels per image: dirty rows, then dirty columns
@@ -383,10 +383,19 @@ __global__ void reflect_fold_frame_kernel(const float *__restrict__ dxp, float *
             for (int b = 0; b < nx; ++b)
                 acc += *(const f32x4 *)(dxp + (((long long)n * Hp + ys[a]) * Wp + xs[b]) * C + c4 * 4);
         const long long o = (((long long)n * H + y) * W + x) * C + c4 * 4;
+        // pre-split (S16) tensors: the 8-channel group of element o starts at byte 4 * (o & ~7); hi halves at +0, lo at +16
+        const long long sb = 4 * (o & ~7LL) + 2 * (o & 7);
         if (relu_src != nullptr) { // same order as the convolution epilogue: mask, then addend
-            const f32x4 mv = *(const f32x4 *)(relu_src + o);
+            if (relu_s16) {
+                const uint2 sv = *(const uint2 *)((const char *)relu_src + sb);
+                const unsigned h[4] = {sv.x & 0xffffu, sv.x >> 16, sv.y & 0xffffu, sv.y >> 16};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = mv[q] > 0.f ? acc[q] : 0.f;
+                for (int q = 0; q < 4; ++q) acc[q] = (h[q] - 1u) < 0x7fffu ? acc[q] : 0.f;
+            } else {
+                const f32x4 mv = *(const f32x4 *)(relu_src + o);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = mv[q] > 0.f ? acc[q] : 0.f;
+            }
         }
         if (addend != nullptr) {
             f32x4 av = *(const f32x4 *)(addend + o);
@@ -398,7 +407,23 @@ __global__ void reflect_fold_frame_kernel(const float *__restrict__ dxp, float *
             }
             acc += av;
         }
-        *(f32x4 *)(dx + o) = acc;
+        if (out_s16) {
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            uint2 hi, lo;
+            unsigned *hp = &hi.x, *lp = &lo.x;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { // the arithmetic of acg_split8
+                const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){acc[2 * q], acc[2 * q + 1]}, bf16x2_t));
+                const float ha = __builtin_bit_cast(float, h << 16), hb = __builtin_bit_cast(float, h & 0xffff0000u);
+                hp[q] = h;
+                lp[q] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){acc[2 * q] - ha, acc[2 * q + 1] - hb}, bf16x2_t));
+            }
+            *(uint2 *)((char *)dx + sb) = hi;
+            *(uint2 *)((char *)dx + sb + 16) = lo;
+        } else {
+            *(f32x4 *)(dx + o) = acc;
+        }
     }
 }
 
@@ -658,7 +683,8 @@ static bool dgrad_frame_ok(const acg_conv_desc *d, const Geom &g)
 
 static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb, const float *bias, float *dst,
                        int act, void *ws, size_t ws_bytes, hipStream_t st, const float *addend = nullptr,
-                       const float *relu_src = nullptr, const unsigned *addend_mask = nullptr)
+                       const float *relu_src = nullptr, const unsigned *addend_mask = nullptr, int in_s16 = 0, int out_s16 = 0,
+                       int relu_s16 = 0)
 {
     Geom g; Taps t;
     g.Hin = d->Ho; g.Win = d->Wo; g.Cin = d->Co;
@@ -695,13 +721,22 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
         ACG_REQUIRE((addend == nullptr && relu_src == nullptr) || frame,
                     "dgrad: the fused addend / ReLU mask need the frame path (query acg_conv2d_bwd_data_add_supported)");
         if (frame) { g.fold_p = p; g.fold_H = d->Hi; g.fold_W = d->Wi; g.out2 = dst; g.addend = addend; g.relu_src = relu_src; g.addend_mask = addend_mask; }
-        int rc = thin_in_valu_dgrad(d) ? thin_out_launch(src, wb, bias, out, g, t, st) : acg_igemm_launch(src, wb, bias, out, g, t, st);
+        int rc;
+        if (in_s16 || out_s16 || relu_s16) { // pre-split operands: the frame path of the pre-split kernel only
+            ACG_REQUIRE(in_s16 && frame && acg_igemm_x3_pre_ok(g, t) && (relu_s16 == 0 || out_s16) && (out_s16 == 0 || addend == nullptr) &&
+                        (relu_src == nullptr || relu_s16 == out_s16),
+                        "dgrad: unsupported pre-split combination (query acg_conv2d_s16_supported)");
+            g.out_s16 = out_s16; g.relu_s16 = relu_s16;
+            rc = acg_igemm_x3_pre_launch(src, wb, bias, out, g, t, g.w_elems, st);
+        } else {
+            rc = thin_in_valu_dgrad(d) ? thin_out_launch(src, wb, bias, out, g, t, st) : acg_igemm_launch(src, wb, bias, out, g, t, st);
+        }
         if (rc != ACG_OK) return rc;
         if (frame) {
             const long long total = (long long)d->N * (2 * p * d->Wi + 2 * p * (d->Hi - 2 * p)) * (d->Ci / 4);
             const int blocks = acg_cdiv(total, 256) > 4096 ? 4096 : acg_cdiv(total, 256);
             hipLaunchKernelGGL(reflect_fold_frame_kernel, dim3(blocks), dim3(256), 0, st, (const float *)ws, dst, d->N, d->Hi,
-                               d->Wi, d->Ci, p, addend, relu_src, addend_mask);
+                               d->Wi, d->Ci, p, addend, relu_src, addend_mask, out_s16, relu_s16);
             ACG_CHECK_LAUNCH("reflect_fold_frame_kernel");
         } else if (refl) {
             const long long total = (long long)d->N * d->Hi * d->Wi * (d->Ci / 4);
@@ -835,6 +870,74 @@ extern "C" int acg_conv2d_bwd_data_relu(const acg_conv_desc *d, const float *dy,
     return dgrad_igemm(d, dy, wb, nullptr, dx, ACG_ACT_NONE, ws, ws_bytes, (hipStream_t)stream, nullptr, x);
 }
 
+// ---- pre-split ("S16") activation storage for the MFMA-bound 3x3 layers (conv_x3_pre.hip) ---------------------------------
+// An S16 tensor has the shape and byte size of its fp32 NHWC twin; per pixel and 8-channel group it holds 16 bytes of bf16
+// hi followed by 16 bytes of bf16 lo (x = hi + lo up to 2^-17 |x|: exactly the operand the bf16x3 convolutions consume).
+// Replaces the per-launch split of `modules.py:205-227`'s activations inside the convolution loaders.
+static bool acg_wgrad_krow_s16_ok(const acg_conv_desc *d) // the conditions under which wgrad_plan sizes the kernel-row split
+{
+    return g_acg_precision == ACG_PREC_BF16X3 && g_acg_conv_impl == ACG_IMPL_MFMA && !thin_in(d) && d->K == 3 && d->stride == 1 &&
+           d->pad == 1 && d->Hi == d->Ho && d->Wi == d->Wo && d->Wo % 32 == 0 && d->Ci % 128 == 0 && d->Co % 128 == 0 &&
+           getenv("ACG_NO_KROW") == nullptr;
+}
+
+static bool s16_dgrad_geom_ok(const acg_conv_desc *d)
+{
+    if (d->stride != 1 || d->pad_mode != ACG_PAD_REFLECT || d->pad <= 0) return false;
+    Geom g; Taps t;
+    g.Hin = d->Ho; g.Win = d->Wo; g.Cin = d->Co; g.Cout = d->Ci; g.reflect = 0; g.act = 0; g.ncols_pad = acg_ncols_pad(d->Ci);
+    g.is = 1; g.thin = (d->stride == 1 && thin_out(d)) ? 1 : 0;
+    const int p = d->pad, K = d->K;
+    g.Hout = d->Hi + 2 * p; g.Wout = d->Wi + 2 * p; g.GH = g.Hout; g.GW = g.Wout; g.os = 1; g.oy0 = 0; g.ox0 = 0;
+    g.Mtot = (long long)d->N * g.GH * g.GW;
+    t.n = 0;
+    for (int kh = 0; kh < K; ++kh)
+        for (int kw = 0; kw < K; ++kw) { t.dy[t.n] = (short)(-kh); t.dx[t.n] = (short)(-kw); t.w[t.n] = (short)(kh * K + kw); t.n++; }
+    return dgrad_frame_ok(d, g) && acg_igemm_x3_pre_ok(g, t);
+}
+
+extern "C" int acg_conv2d_s16_supported(const acg_conv_desc *d)
+{
+    if (d == nullptr || g_acg_precision != ACG_PREC_BF16X3 || g_acg_conv_impl != ACG_IMPL_MFMA) return 0;
+    if (check_desc(d, "acg_conv2d_s16_supported") != ACG_OK || thin_in(d) || thin_out(d)) return 0;
+    Geom g; Taps t;
+    fwd_geom(d, &g, &t, 0);
+    if (!acg_igemm_x3_pre_ok(g, t) || !s16_dgrad_geom_ok(d)) return 0;
+    return acg_wgrad_krow_s16_ok(d) ? 1 : 0;
+}
+
+extern "C" int acg_conv2d_fwd_s16(const acg_conv_desc *d, const void *x, const float *wf, const float *bias, void *y, int act,
+                                  float *stats, int out_s16, void *stream)
+{
+    int rc = check_desc(d, "acg_conv2d_fwd_s16");
+    if (rc) return rc;
+    ACG_REQUIRE(g_acg_precision == ACG_PREC_BF16X3 && g_acg_conv_impl == ACG_IMPL_MFMA, "acg_conv2d_fwd_s16: bf16x3 MFMA mode only");
+    Geom g; Taps t;
+    fwd_geom(d, &g, &t, stats != nullptr ? (int)ACG_ACT_NONE : act);
+    ACG_REQUIRE(stats == nullptr || act == ACG_ACT_NONE, "acg_conv2d_fwd_s16: statistics with an activation");
+    g.out_s16 = out_s16;
+    return acg_igemm_x3_pre_launch(x, wf, bias, (float *)y, g, t, g.w_elems, (hipStream_t)stream, stats);
+}
+
+// dy pre-split; addend (fp32, + optional sign bitmask) only with fp32 output; relu_src (pre-split) only with pre-split output
+extern "C" int acg_conv2d_bwd_data_s16(const acg_conv_desc *d, const void *dy, const float *wb, void *dx, void *ws,
+                                       size_t ws_bytes, const float *addend, const unsigned *addend_mask, const void *relu_src,
+                                       int out_s16, void *stream)
+{
+    int rc = check_desc(d, "acg_conv2d_bwd_data_s16");
+    if (rc) return rc;
+    ACG_REQUIRE(g_acg_precision == ACG_PREC_BF16X3 && g_acg_conv_impl == ACG_IMPL_MFMA && s16_dgrad_geom_ok(d),
+                "acg_conv2d_bwd_data_s16: unsupported shape or mode");
+    ACG_REQUIRE(addend_mask == nullptr || (addend != nullptr && ((long long)d->Hi * d->Wi * (d->Ci / 4)) % 8 == 0),
+                "acg_conv2d_bwd_data_s16: the sign bitmask needs an addend and Hi*Wi*Ci/4 %% 8 == 0");
+    return dgrad_igemm(d, (const float *)dy, wb, nullptr, (float *)dx, ACG_ACT_NONE, ws, ws_bytes, (hipStream_t)stream, addend,
+                       (const float *)relu_src, addend_mask, 1, out_s16, relu_src != nullptr ? 1 : 0);
+}
+
+// x and dy pre-split; dw / db fp32 as in acg_conv2d_bwd_weight (db = column sums of dy, produced by the same launch)
+extern "C" int acg_conv2d_bwd_weight_s16(const acg_conv_desc *d, const void *x, const void *dy, float *dw, float *db, int Or,
+                                         int Ir, void *ws, size_t ws_bytes, int accumulate, void *stream);
+
 // split-K plan shared by the workspace query and the launch
 static bool wgrad_thin(const acg_conv_desc *d) { return thin_in(d); }
 
@@ -918,7 +1021,7 @@ extern "C" size_t acg_conv2d_bwd_weight_workspace_bytes(const acg_conv_desc *d)
 // bias_from: 0 none; 1 db[c] = column sums of g_side (Conv2d bias, Or entries); 2 of x_side (ConvTranspose bias, Ir entries)
 static int wgrad_common(const acg_conv_desc *d, const float *x_side, const float *g_side, float *dw, int Or, int Ir,
                         void *ws, size_t ws_bytes, hipStream_t st, int accumulate, int bias_from = 0, float *db = nullptr,
-                        bool thin_conv = false)
+                        bool thin_conv = false, bool s16 = false)
 {
     ACG_REQUIRE(Or <= d->Co && Ir <= d->Ci, "wgrad: Or=%d Ir=%d exceed padded dims", Or, Ir);
     if (g_acg_conv_impl == ACG_IMPL_DIRECT) {
@@ -942,7 +1045,14 @@ static int wgrad_common(const acg_conv_desc *d, const float *x_side, const float
     }
     g.bias_from = db != nullptr ? bias_from : 0;
     g.bias_part = (float *)((char *)ws + acg_round_up(need, 256));
-    int rc = acg_wgrad_launch(x_side, g_side, (float *)ws, g, t, st);
+    int rc;
+    if (s16) {
+        ACG_REQUIRE(acg_wgrad_krow_s16_ok(d) && g.CiP == d->Ci && g.CoP == d->Co && g.m_per_split % 32 == 0 && g.bias_from != 2,
+                    "wgrad: pre-split operands need the kernel-row geometry (query acg_conv2d_s16_supported)");
+        rc = acg_wgrad_krow_s16_launch(x_side, g_side, (float *)ws, g, st);
+    } else {
+        rc = acg_wgrad_launch(x_side, g_side, (float *)ws, g, t, st);
+    }
     if (rc) return rc;
     const int Cp = bias_from == 1 ? g.CoP : g.CiP, Cr = g.bias_from ? (bias_from == 1 ? Or : Ir) : 0;
     const long long total = (long long)t.n * Ir * Or;
@@ -1025,6 +1135,16 @@ extern "C" int acg_conv2d_bwd_weight(const acg_conv_desc *d, const float *x, con
         rc = colsum_launch(dy, M, d->Co, Or, db, cw, st, accumulate);
     }
     return rc;
+}
+
+extern "C" int acg_conv2d_bwd_weight_s16(const acg_conv_desc *d, const void *x, const void *dy, float *dw, float *db, int Or,
+                                         int Ir, void *ws, size_t ws_bytes, int accumulate, void *stream)
+{
+    int rc = check_desc(d, "acg_conv2d_bwd_weight_s16");
+    if (rc) return rc;
+    ACG_REQUIRE(dw != nullptr && ws != nullptr && ws_bytes >= acg_conv2d_bwd_weight_workspace_bytes(d),
+                "acg_conv2d_bwd_weight_s16: workspace too small");
+    return wgrad_common(d, (const float *)x, (const float *)dy, dw, Or, Ir, ws, ws_bytes, (hipStream_t)stream, accumulate, 1, db, false, true);
 }
 
 extern "C" int acg_conv_transpose2d_fwd(const acg_conv_desc *d, const float *x, const float *wb, const float *bias,

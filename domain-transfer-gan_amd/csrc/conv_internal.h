@@ -47,6 +47,10 @@ struct Geom {
     // convolution's own input when that input is the ReLU output of the layer in front: dx is then already the gradient
     // w.r.t. that layer's pre-activation and its separate activation-backward pass (3 tensor streams) disappears
     const float *relu_src = nullptr;
+    // pre-split ("S16") storage, conv_x3_pre.hip: per pixel and 8-channel group 16 bytes of bf16 hi then 16 bytes of bf16 lo
+    // (x = hi + lo + O(2^-17 |x|); the same 4 bytes per element as fp32).  out_s16: the written tensor (out2 on the frame
+    // path) takes that form; relu_s16: relu_src is stored that way (its sign = the sign of the hi halves).
+    int out_s16 = 0, relu_s16 = 0;
     int thin;             // 1: K flattened over (tap, 4 channels): stage s = taps 8s..8s+7, channels 0..3 of each
     int bk8;              // 8-float k-chunks per packed weight slab (Cin/8; thin: 4*ceil(ntaps/8), single slab)
     long long Mtot;       // N*GH*GW
@@ -77,6 +81,10 @@ extern int g_acg_conv_impl;
 int acg_igemm_x3_ws_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g, const Taps &t,
                            long long n_w_elems, hipStream_t st, float *stats = nullptr);
 bool acg_igemm_uses_ws(const Geom &g);
+// conv_x3_pre.hip: the same tile on a pre-split (S16) gathered tensor, both operands by LDS-DMA
+bool acg_igemm_x3_pre_ok(const Geom &g, const Taps &t);
+int acg_igemm_x3_pre_launch(const void *in, const void *wp, const float *bias, float *out, const Geom &g, const Taps &t,
+                            long long n_w_elems, hipStream_t st, float *stats = nullptr);
 bool acg_conv_patch16_ok(const Geom &g, const Taps &t);
 int acg_conv_patch16_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g, const Taps &t,
                             long long n_w_elems, hipStream_t st);
@@ -87,6 +95,7 @@ int acg_wgrad_bf16_launch(const float *x, const float *dy, float *part, const WG
 // conv_wgrad_tr.hip: one kernel row per workgroup (stride-1 3x3, 128-multiple channels, bf16x3)
 bool acg_wgrad_krow_ok(const WGeom &g, const Taps &t);
 int acg_wgrad_krow_launch(const float *x, const float *dy, float *part, const WGeom &g, hipStream_t st);
+int acg_wgrad_krow_s16_launch(const void *x, const void *dy, float *part, const WGeom &g, hipStream_t st); // pre-split operands
 bool acg_wgrad_krow_s_ok(const WGeom &g, const Taps &t);   // its 32 <-> 64 channel, 128-pixel-run variant
 int acg_wgrad_krow_s_launch(const float *x, const float *dy, float *part, const WGeom &g, hipStream_t st);
 

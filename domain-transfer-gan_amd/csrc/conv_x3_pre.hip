@@ -1,0 +1,469 @@
+// Wave-specialised implicit-GEMM convolution (bf16x3 arithmetic, 128x128 tiles) on PRE-SPLIT activations.
+//
+// conv_x3.hip gathers fp32 activations, splits every value into bf16 hi + lo in registers (20 VALU per 8 values) and
+// stores the halves to LDS with ds_write_b128 — all of it producer-wave work beside the MFMAs.  Here the gathered tensor
+// is stored pre-split ("S16": per pixel and 8-channel group, 16 bytes of hi followed by 16 bytes of lo — the same 4 bytes
+// per element as fp32, written once by the kernel that produces the activation), so BOTH operands travel global -> LDS
+// by LDS-DMA (buffer_load_dwordx4 ... lds): no VGPR staging, no split, no LDS stores; the four producer waves only
+// issue DMA pieces and wait for them.
+//
+// A image ("row patch", as in conv_x3.hip: the K taps of a kernel row read the same input rows shifted by one pixel, so
+// the patch — the tile's row segments with their K-1 halo pixels — is fetched once per kernel row and 32-channel chunk).
+// A DMA piece is 64 lanes x 16 B of CONTIGUOUS LDS, so padding has to be bought with lanes: an image row is 80 bytes =
+// the four 16-byte chunks {hi, lo} x {k-group q, k-group q+2} of one pixel plus one pad chunk (a masked lane), and the
+// k-groups of different parity live in two images a multiple of 256 B apart.  A ds_read_b128 lane group (8 lanes of
+// k-group 2j on rows r..r+3, r+12..r+15 and 8 lanes of k-group 2j+1 on rows r+4..r+11) then reads the SAME in-row offset
+// of 16 consecutive rows of the two images: 16 distinct 16-byte slots of the 256-byte bank row for every tap shift
+// (5 slots per row, 5 odd).  The source side stays line-friendly: the four data lanes of a row read 64 of the 128
+// contiguous bytes a pixel's 32-channel chunk occupies, the other image's piece the other 64.
+#include "common.h"
+#include "conv_internal.h"
+#include <cstdlib>
+#include <type_traits>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int BM = 128, BN = 128, KC = 32, NK8 = KC / 8;
+constexpr int BPL = BN * 8;                 // B plane stride (bf16 elements), planes XOR-permuted as in conv_x3.hip
+constexpr int B_IMG = NK8 * BPL;            // one hi (or lo) B image, elements
+__device__ __forceinline__ int lds_at(int plane, int row, int pl) { return plane * pl + ((row ^ (2 * plane)) * 8); }
+constexpr int PROW = 80;                    // bytes per A image row
+constexpr int PPIECES = 11;                 // 1 KB DMA pieces per parity image: 140 rows
+constexpr int PIMG = PPIECES * 1024;        // bytes per parity image (a multiple of 256)
+constexpr int ABUF = 2 * PIMG;              // one A buffer: parity images 0 and 1
+constexpr int A_BYTES = 2 * ABUF;           // two A buffers (kernel rows alternate)
+constexpr int BBUF = 2 * B_IMG * 2;         // one B buffer: hi image, lo image (bytes)
+constexpr int LDS_BYTES = A_BYTES + 2 * BBUF;
+constexpr int NPW = 6;                      // A pieces per producer wave and kernel row: 22 over 4 waves = 6, 6, 5, 5
+constexpr unsigned NO_PIX = 0xFFFFFFFFu;
+}
+
+template <bool REFLECT, bool STATS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void
+igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
+                  float *__restrict__ out, Geom g, Taps taps, unsigned in_bytes, unsigned w_bytes, unsigned w_lo_bytes,
+                  float *__restrict__ stats, int kdim, int dxmin, int kstep)
+{
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+    // output row of every tile pixel in 16-byte units; bit 31: the row lies in Geom.out2 (the un-padded tensor of a reflect
+    // data gradient: side inputs apply there), NO_PIX past the end
+    __shared__ unsigned pix_off[BM];
+    __shared__ float red[2][2][64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int tiles_n = g.ncols_pad / BN;
+    const int tile_n = swz % tiles_n, tile_m = swz / tiles_n;
+    const int n0 = tile_n * BN;
+    const long long m0 = (long long)tile_m * BM;
+    const int GHW = g.GH * g.GW;
+    const int S = taps.n * (g.Cin / KC);
+
+    if (tid < BM) {
+        const long long m = m0 + tid;
+        unsigned po = NO_PIX;
+        if (m < g.Mtot) {
+            const int n = (int)(m / GHW);
+            const int r = (int)(m - (long long)n * GHW);
+            const int gy = r / g.GW, gx = r - gy * g.GW;
+            po = (unsigned)(((((long long)n * g.Hout + gy) * g.Wout + gx) * g.Cout) >> 2);
+            if (g.fold_p > 0) { // reflect data gradient: pixels nothing is mirrored onto bypass the fold
+                const int p = g.fold_p, iy = gy - p, ix = gx - p;
+                const bool cy = iy >= 0 && iy < g.fold_H && !(iy >= 1 && iy <= p) && !(iy >= g.fold_H - 1 - p && iy <= g.fold_H - 2);
+                const bool cx = ix >= 0 && ix < g.fold_W && !(ix >= 1 && ix <= p) && !(ix >= g.fold_W - 1 - p && ix <= g.fold_W - 2);
+                if (cy && cx) po = (unsigned)(((((long long)n * g.fold_H + iy) * g.fold_W + ix) * g.Cout) >> 2) | 0x80000000u;
+            }
+        }
+        pix_off[tid] = po;
+    }
+
+    typedef __attribute__((address_space(3))) void lds_void;
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producers: DMA issue only
+        const int pt = tid - 256, pw = wave - 4;
+        constexpr int BCH = NK8 * BN, BL = BCH / 256;               // 16-byte chunks of the B tile: 2 per thread
+        const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, in_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, w_bytes, 0x00020000);
+        unsigned b_voff[BL];
+        int b_lds[BL];
+#pragma unroll
+        for (int i = 0; i < BL; ++i) {
+            const int idx = pt + 256 * i;
+            const int plane = idx / BN, slot = idx - plane * BN, col = slot ^ (2 * plane);
+            b_voff[i] = (unsigned)((((plane >> 1) * g.ncols_pad + n0 + col) * 16 + (plane & 1) * 8) * 2);
+            b_lds[i] = __builtin_amdgcn_readfirstlane((plane * BPL + (slot & ~63) * 8) * 2);   // byte offset of the wave's piece
+        }
+        const int tap_v = taps.pk[lane < taps.n ? lane : 0];
+        auto tap_pk = [&](int t) { return __builtin_amdgcn_readlane(tap_v, t); };
+        int bt = 0, bc0 = 0; // tap and first input channel of the next B stage
+        auto dma_b = [&](int buf) { // 2 * BL pieces per thread: hi and lo image of stage (bt, bc0) into B buffer `buf`
+            char *Bb = lds + A_BYTES + buf * BBUF;
+            const unsigned soff = (unsigned)((((tap_pk(bt) >> 16) * (g.Cin >> 4) + (bc0 >> 4)) * g.ncols_pad) * 16) * 2u;
+#pragma unroll
+            for (int i = 0; i < BL; ++i) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(Bb + b_lds[i]), 16, b_voff[i], soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(Bb + B_IMG * 2 + b_lds[i]), 16, b_voff[i], soff + w_lo_bytes, 0, 0);
+            }
+            if (++bt == taps.n) { bt = 0; bc0 += KC; }
+        };
+        static_assert(BL == 2, "the vmcnt immediates below count 2 * BL = 4 B pieces per stage");
+
+        // The tile's 128 consecutive output pixels form SEGMENTS, one per grid row it touches (the first starts at column
+        // x0, the others at 0); segment s occupies image rows [row0(s), row0(s) + len(s) + K-1).  Piece e = pw + 4 j of a
+        // kernel row fills 1 KB of parity image e / 11; its lane L holds chunk L % 5 of image row L / 5.
+        const long long grow0 = m0 / g.GW;                     // global grid row (image * GH + gy) of the first pixel
+        const int x0 = (int)(m0 - grow0 * g.GW);
+        const int first = g.GW - x0 < BM ? g.GW - x0 : BM;     // pixels in segment 0
+        const int RW = g.GW + kdim - 1;
+        const int nseg = first >= BM ? 1 : 1 + (BM - first + g.GW - 1) / g.GW;
+        const int nrows = BM + nseg * (kdim - 1);
+        const long long grows = g.Mtot / g.GW;                 // grid rows in the whole tensor
+        int pa_gy[NPW], pa_nb[NPW], pa_lds[NPW];
+        unsigned pa_col[NPW];
+        bool pa_ok[NPW];
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) {
+            const int e = pw + 4 * j;
+            const int q = e >= PPIECES ? 1 : 0, pc = e - q * PPIECES;
+            const int L = pc * 64 + lane;
+            const int row = L / 5, ch = L - row * 5;
+            int seg = 0, px = row;
+            if (row >= first + kdim - 1) {
+                const int qq = row - (first + kdim - 1);
+                seg = 1 + qq / RW;
+                px = qq - (seg - 1) * RW;
+            }
+            const long long grow = grow0 + seg;
+            const int n_img = (int)(grow / g.GH);
+            int ix = (seg == 0 ? x0 : 0) + px + dxmin;
+            bool ok = e < 2 * PPIECES && ch < 4 && row < nrows && grow < grows;
+            if (REFLECT) {
+                ix = ix < 0 ? -ix : ix;
+                ix = ix >= g.Win ? 2 * (g.Win - 1) - ix : ix;
+            } else {
+                ok = ok && (unsigned)ix < (unsigned)g.Win;
+            }
+            pa_gy[j] = (int)(grow - (long long)n_img * g.GH);
+            pa_nb[j] = n_img * g.Hin;
+            pa_col[j] = (unsigned)(ix * g.Cin * 4 + (q + 2 * (ch >> 1)) * 32 + (ch & 1) * 16);
+            pa_ok[j] = ok;
+            pa_lds[j] = __builtin_amdgcn_readfirstlane(q * PIMG + pc * 1024);
+        }
+        int ar_t = 0, ar_c0 = 0; // first tap and first input channel of the next kernel row to fetch
+        auto dma_a = [&](int buf) { // the patch of one kernel row (all of its taps share dy), from dx = dxmin
+            const int ty = (tap_pk(ar_t) << 24) >> 24;
+            char *Ab = lds + buf * ABUF;
+#pragma unroll
+            for (int j = 0; j < NPW; ++j) {
+                if (pw + 4 * j < 2 * PPIECES) { // wave-uniform: waves 2 and 3 have five pieces
+                    int iy = pa_gy[j] + ty;
+                    bool ok = pa_ok[j];
+                    if (REFLECT) {
+                        iy = iy < 0 ? -iy : iy;
+                        iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
+                    } else {
+                        ok = ok && (unsigned)iy < (unsigned)g.Hin;
+                    }
+                    const unsigned off = (unsigned)((pa_nb[j] + iy) * g.Win) * (unsigned)(g.Cin * 4) + pa_col[j] + (unsigned)(ar_c0 * 4);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void *)(Ab + pa_lds[j]), 16, acg_masked_off(off, ok), 0, 0, 0);
+                }
+            }
+            ar_t += kdim;
+            if (ar_t >= taps.n) { ar_t = 0; ar_c0 += KC; }
+        };
+        // Schedule: iteration s (which ends with barrier s, releasing consumer stage s) issues the B tile of stage s; the A
+        // patch of kernel row r+1 is issued in the SECOND iteration of row r — its buffer was last read in the final stage
+        // of row r-1, which the consumers have left when they pass the barrier before this iteration — and has to have
+        // landed by the end of the first iteration of row r+1.  vmcnt counts in issue order: the second iteration waits for
+        // its B pieces and leaves the (five or six) A pieces behind them in flight, every other iteration drains the queue.
+        const int rows = S / kdim;
+        dma_a(0);
+        int pk_k = 0, row = 0;
+        for (int s = 0; s < S; ++s) {
+            dma_b(s & 1);
+            if (pk_k == 1 && row + 1 < rows) {
+                dma_a((row + 1) & 1);
+                asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (++pk_k == kdim) { pk_k = 0; ++row; }
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    __builtin_amdgcn_s_setprio(2);
+    const int wm = wave >> 1, wn = wave & 1;
+    constexpr int TM = 64, TN = 64;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int pl = lane >> 4, lr = lane & 15;
+    int a_base[4]; // byte offset of this lane's hi chunk in row-tile i at tap column 0 (lo: + 16)
+    {
+        const int x0c = (int)(m0 % g.GW), firstc = g.GW - x0c < BM ? g.GW - x0c : BM, RWc = g.GW + kdim - 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tp = wm * TM + i * 16 + lr;
+            int arow;
+            if (tp < firstc) {
+                arow = tp;
+            } else {
+                const int sg = 1 + (tp - firstc) / g.GW;
+                arow = (firstc + kdim - 1) + (sg - 1) * RWc + (tp - firstc - (sg - 1) * g.GW);
+            }
+            a_base[i] = (pl & 1) * PIMG + arow * PROW + (pl >> 1) * 32;
+        }
+    }
+    const int b_base = 2 * lds_at(pl, wn * TN + lr, BPL);
+    const char *ldsb = (const char *)lds;
+    auto stage = [&](const char *pa_off, const char *pb) { // one K stage: 16 fragment reads, 48 MFMAs
+        bf16x8 a[4], al[4], b[4], bl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const char *pa = pa_off + a_base[i];
+            a[i] = *(const bf16x8 *)pa;
+            al[i] = *(const bf16x8 *)(pa + 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            b[j] = *(const bf16x8 *)(pb + j * 256);
+            bl[j] = *(const bf16x8 *)(pb + 2 * B_IMG + j * 256);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], b[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+    };
+    const char *pb0 = ldsb + A_BYTES + b_base, *pb1 = pb0 + BBUF;
+    bool done = false;
+    if (kdim == 3 && S % 6 == 0) {
+        // 3 x 3 layers: six stages (two kernel rows) per trip, so buffer, tap column and B buffer of every stage are
+        // compile-time constants that ride in the ds_read offset field
+        auto run = [&](auto ks) {
+            constexpr int KS = decltype(ks)::value;
+            for (int it = 0; it < S / 6; ++it) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    __syncthreads();
+                    const int kx = KS > 0 ? k % 3 : 2 - k % 3;
+                    stage(ldsb + (k / 3) * ABUF + kx * PROW, (k & 1) ? pb1 : pb0);
+                }
+            }
+        };
+        if (kstep > 0) run(std::integral_constant<int, 1>{});
+        else run(std::integral_constant<int, -1>{});
+        done = true;
+    }
+    if (!done) {
+        int kk = 0, abuf = 0, kx = kstep > 0 ? 0 : kdim - 1;
+        for (int s = 0; s < S; ++s) {
+            __syncthreads();
+            stage(ldsb + abuf * ABUF + kx * PROW, (s & 1) ? pb1 : pb0);
+            kx += kstep;
+            if (++kk == kdim) { kk = 0; abuf ^= 1; kx = kstep > 0 ? 0 : kdim - 1; }
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    // Epilogue through LDS: the tile (accumulator + bias, activation) is staged in the LDS the main loop no longer needs
+    // and leaves in coalesced rows.
+    constexpr int TS = BN; // row stride (floats)
+    static_assert(BM * TS * 4 <= LDS_BYTES, "the staged tile must fit the LDS buffers");
+    float *tile = (float *)lds;
+    __syncthreads(); // every consumer wave is done with the last LDS buffer (the producers have exited)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int cl = wn * TN + j * 16 + lr;
+        const float bv = (bias != nullptr && n0 + cl < g.Cout) ? bias[n0 + cl] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                tile[(wm * TM + i * 16 + 4 * pl + r) * TS + cl] = acg_apply_act(acc[i][j][r] + bv, STATS ? (int)ACG_ACT_NONE : g.act);
+    }
+    __syncthreads();
+    if constexpr (STATS) {
+        // per-tile (mean, M2) of the 128 output pixels of every channel for the InstanceNorm that follows (conv_x3.hip)
+        float *redf = &red[0][0][0]; // 256 floats
+        const int c = tid & (BN - 1), h = tid >> 7; // tid < 256 here: column c, rows h*64 .. h*64+63
+        float sum = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < BM / 2; ++r) sum += tile[(h * (BM / 2) + r) * TS + c];
+        redf[h * BN + c] = sum;
+        __syncthreads();
+        const float mu = (redf[c] + redf[BN + c]) * (1.f / BM);
+        float sq = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < BM / 2; ++r) {
+            const float dlt = tile[(h * (BM / 2) + r) * TS + c] - mu;
+            sq += dlt * dlt;
+        }
+        __syncthreads();
+        redf[h * BN + c] = sq;
+        __syncthreads();
+        if (h == 0 && n0 + c < g.Cout) {
+            float *o = stats + ((m0 / BM) * 2) * g.Cout + n0 + c; // chunk = image * (GH*GW/128) + tile within the image
+            o[0] = mu;
+            o[g.Cout] = redf[c] + redf[BN + c];
+        }
+    }
+    char *const base0 = (char *)out, *const base1 = (char *)g.out2;
+    if (g.out_s16) {
+        // pre-split output: a thread converts 8 channels of one pixel (hi at +0, lo at +16 of the group's 32 bytes); the
+        // optional ReLU source is pre-split too and only its sign is needed: the sign of the hi halves
+        const char *rsrc = (const char *)g.relu_src;
+#pragma unroll 2
+        for (int k = 0; k < BM * (BN / 8) / 256; ++k) {
+            const int idx = tid + 256 * k, row = idx / (BN / 8), c8 = idx - row * (BN / 8);
+            const unsigned po = pix_off[row];
+            if (po == NO_PIX || n0 + c8 * 8 >= g.Cout) continue;
+            const size_t boff = (size_t)(po & 0x7fffffffu) * 16 + (size_t)(n0 + c8 * 8) * 4;
+            const f32x4 t0 = *(const f32x4 *)&tile[row * TS + c8 * 8], t1 = *(const f32x4 *)&tile[row * TS + c8 * 8 + 4];
+            float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+            if (rsrc != nullptr && (po >> 31)) {
+                const u32x4 sv = *(const u32x4 *)(rsrc + boff);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned a = sv[q] & 0xffffu, b = sv[q] >> 16;
+                    v[2 * q] = (a - 1u) < 0x7fffu ? v[2 * q] : 0.f;         // positive, non-zero bf16
+                    v[2 * q + 1] = (b - 1u) < 0x7fffu ? v[2 * q + 1] : 0.f;
+                }
+            }
+            if (g.fold_p > 0 && !(po >> 31)) { // frame pixel of a reflect data gradient: fp32 into the padded scratch, the
+                *(f32x4 *)(base0 + boff) = t0; // fold kernel sums, masks and splits it
+                *(f32x4 *)(base0 + boff + 16) = t1;
+                continue;
+            }
+            acg_u32x4 hi, lo;
+            acg_split8(v, hi, lo);
+            char *dst = ((po >> 31) ? base1 : base0) + boff;
+            *(acg_u32x4 *)dst = hi;
+            *(acg_u32x4 *)(dst + 16) = lo;
+        }
+        return;
+    }
+    if (g.addend == nullptr && g.relu_src == nullptr) {
+#pragma unroll 4
+        for (int k = 0; k < BM * (BN / 4) / 256; ++k) { // 16 float4 per thread, consecutive lanes on consecutive channels
+            const int idx = tid + 256 * k, row = idx / (BN / 4), c4 = idx - row * (BN / 4);
+            const unsigned po = pix_off[row];
+            if (po != NO_PIX && n0 + c4 * 4 < g.Cout)
+                *(f32x4 *)(((po >> 31) ? base1 : base0) + (size_t)(po & 0x7fffffffu) * 16 + (size_t)(n0 + c4 * 4) * 4) = *(const f32x4 *)&tile[row * TS + c4 * 4];
+        }
+        return;
+    }
+    // Data-gradient epilogue with fp32 side inputs (skip gradient and its sign bitmask; fp32 ReLU source): four rows at a
+    // time, every side load issued before the first is used; rows without a side input read a dummy address instead of
+    // branching (conv_x3.hip)
+    const char *dummy = in;
+    const unsigned *amask = g.addend_mask != nullptr ? g.addend_mask : (const unsigned *)in;
+    constexpr int EB = 4;
+#pragma unroll 1
+    for (int kb = 0; kb < BM * (BN / 4) / 256; kb += EB) {
+        unsigned po[EB], nb[EB];
+        size_t bo[EB];
+        f32x4 v[EB], mv[EB], av[EB];
+        bool side[EB];
+#pragma unroll
+        for (int u = 0; u < EB; ++u) {
+            const int idx = tid + 256 * (kb + u), row = idx / (BN / 4), c4 = idx - row * (BN / 4);
+            po[u] = pix_off[row];
+            side[u] = po[u] != NO_PIX && (po[u] >> 31);
+            bo[u] = (size_t)(po[u] & 0x7fffffffu) * 16 + (size_t)(n0 + c4 * 4) * 4;
+            if (n0 + c4 * 4 >= g.Cout) po[u] = NO_PIX;
+            v[u] = *(const f32x4 *)&tile[row * TS + c4 * 4];
+        }
+#pragma unroll
+        for (int u = 0; u < EB; ++u) {
+            const bool hm = side[u] && g.relu_src != nullptr, ha = side[u] && g.addend != nullptr;
+            mv[u] = *(const f32x4 *)(hm ? (const char *)g.relu_src + bo[u] : dummy);
+            av[u] = *(const f32x4 *)(ha ? (const char *)g.addend + bo[u] : dummy);
+            const size_t f = ha ? bo[u] >> 4 : 0;   // float4 index of these 4 elements
+            nb[u] = (amask[f >> 3] >> (4 * (int)(f & 7))) & 15u;
+        }
+#pragma unroll
+        for (int u = 0; u < EB; ++u) {
+            if (side[u] && g.relu_src != nullptr) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[u][q] = mv[u][q] > 0.f ? v[u][q] : 0.f;
+            }
+            if (side[u] && g.addend != nullptr) {
+                if (g.addend_mask == nullptr) nb[u] = 15u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[u][q] += (nb[u] >> q) & 1u ? av[u][q] : 0.f;
+            }
+            if (po[u] != NO_PIX) *(f32x4 *)(((po[u] >> 31) ? base1 : base0) + bo[u]) = v[u];
+        }
+    }
+}
+
+// Row-patch geometry the pre-split kernel needs: K x K tap lists in kernel-row order (forward: dx ascending, stride-1 data
+// gradient: descending) whose patch fills exactly the eleven 1 KB pieces per parity image the kernel issues.
+static bool pre_rowp(const Geom &g, const Taps &t, int *kdim, int *dxmin, int *kstep)
+{
+    if (g.is != 1 || g.os != 1 || g.oy0 != 0 || g.ox0 != 0 || g.Hout != g.GH || g.Wout != g.GW) return false;
+    int k = 1;
+    while (k * k < t.n) ++k;
+    if (k * k != t.n || k < 2) return false;
+    const int nseg_max = 2 + BM / g.GW, rows_max = BM + nseg_max * (k - 1);
+    if (rows_max * 5 > PPIECES * 64 || (BM + (k - 1)) * 5 <= (PPIECES - 1) * 64) return false; // all eleven pieces, no more
+    int mn = t.dx[0];
+    for (int i = 1; i < t.n; ++i) mn = t.dx[i] < mn ? t.dx[i] : mn;
+    for (int i = 0; i < t.n; ++i)
+        if (t.dy[i] != t.dy[(i / k) * k] || t.dx[i] < mn || t.dx[i] >= mn + k) return false;
+    const int ks = t.dx[0] == mn ? 1 : -1;
+    for (int i = 0; i < t.n; ++i)
+        if (t.dx[i] != (ks > 0 ? mn + i % k : mn + k - 1 - i % k)) return false;
+    *kdim = k; *dxmin = mn; *kstep = ks;
+    return true;
+}
+
+bool acg_igemm_x3_pre_ok(const Geom &g, const Taps &t)
+{
+    int a, b, c;
+    return g_acg_precision == ACG_PREC_BF16X3 && g_acg_conv_impl == ACG_IMPL_MFMA && !g.thin && g.Cout >= 128 && g.Cin % 32 == 0 &&
+           pre_rowp(g, t, &a, &b, &c);
+}
+
+// `in` is a pre-split (S16) tensor of g.Cin channels; Geom.out_s16 / relu_src describe the output side
+int acg_igemm_x3_pre_launch(const void *in, const void *wp, const float *bias, float *out, const Geom &g0, const Taps &t,
+                            long long n_w_elems, hipStream_t st, float *stats)
+{
+    Geom g = g0;
+    g.thin = 0;
+    int kdim = 0, dxmin = 0, kstep = 1;
+    ACG_REQUIRE(acg_igemm_x3_pre_ok(g, t) && pre_rowp(g, t, &kdim, &dxmin, &kstep), "igemm_conv_x3_pre: unsupported geometry");
+    dim3 grid(acg_cdiv(g.Mtot, BM) * (g.ncols_pad / BN));
+    const long long nimg = g.Mtot / ((long long)g.GH * g.GW);
+    const long long in_bytes = nimg * g.Hin * g.Win * g.Cin * 4;
+    const long long out_bytes = nimg * g.Hout * g.Wout * g.Cout * 4;
+    const long long w_bytes = n_w_elems * 2 * 2;
+    ACG_REQUIRE(in_bytes < (1LL << 32) && w_bytes < (1LL << 32) && out_bytes < (1LL << 34),
+                "igemm_conv_x3_pre: operand exceeds the buffer-addressing limit");
+    ACG_REQUIRE(stats == nullptr || (((long long)g.GH * g.GW) % BM == 0 && g.act == ACG_ACT_NONE && !g.out_s16),
+                "igemm_conv_x3_pre: per-tile statistics need whole 128-pixel tiles per image, no activation, fp32 output");
+    ACG_REQUIRE(!g.out_s16 || (g.addend == nullptr && g.Cout % 8 == 0), "igemm_conv_x3_pre: pre-split output takes no addend");
+    ACG_REQUIRE(g.relu_src == nullptr || g.fold_p > 0, "igemm_conv_x3_pre: the ReLU source needs the frame path");
+    const unsigned inb = (unsigned)in_bytes, wb = (unsigned)w_bytes, wlo = (unsigned)(n_w_elems * 2);
+    const Taps tp = acg_taps_pack(t);
+#define X3_PRE(R, S) hipLaunchKernelGGL((igemm_conv_x3_pre<R, S>), grid, dim3(512), 0, st, (const char *)in, (const __bf16 *)wp, bias, out, g, tp, inb, wb, wlo, stats, kdim, dxmin, kstep)
+    if (g.reflect) { if (stats) X3_PRE(true, true); else X3_PRE(true, false); }
+    else { if (stats) X3_PRE(false, true); else X3_PRE(false, false); }
+#undef X3_PRE
+    ACG_CHECK_LAUNCH("igemm_conv_x3_pre");
+    acg_note_kernel("igemm_conv_x3_pre<REFLECT=%d,STATS=%d>", g.reflect ? 1 : 0, stats ? 1 : 0);
+    return ACG_OK;
+}

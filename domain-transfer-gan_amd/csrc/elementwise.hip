@@ -54,6 +54,52 @@ extern "C" int acg_act_bwd(const float *dy, const float *y, float *dx, size_t n,
     return ACG_OK;
 }
 
+// ---------------------------------------------------------------- pre-split ("S16") storage: fp32 <-> (bf16 hi, bf16 lo)
+// per 8 consecutive elements: 16 bytes of hi then 16 bytes of lo (conv_internal.h, acg_split8): the operand form of the
+// bf16x3 convolutions, written once by the producer of an activation instead of by every loader that gathers it
+#include "conv_internal.h"
+__global__ void s16_encode_kernel(const float *__restrict__ x, char *__restrict__ y, long long n8)
+{
+    GRID_STRIDE(i, n8) {
+        const f32x4 a = *(const f32x4 *)(x + i * 8), c = *(const f32x4 *)(x + i * 8 + 4);
+        const float v[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+        acg_u32x4 hi, lo;
+        acg_split8(v, hi, lo);
+        *(acg_u32x4 *)(y + i * 32) = hi;
+        *(acg_u32x4 *)(y + i * 32 + 16) = lo;
+    }
+}
+__global__ void s16_decode_kernel(const char *__restrict__ x, float *__restrict__ y, long long n8)
+{
+    GRID_STRIDE(i, n8) {
+        const acg_u32x4 hi = *(const acg_u32x4 *)(x + i * 32), lo = *(const acg_u32x4 *)(x + i * 32 + 16);
+        f32x4 a, c;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            a[2 * q] = __builtin_bit_cast(float, hi[q] << 16) + __builtin_bit_cast(float, lo[q] << 16);
+            a[2 * q + 1] = __builtin_bit_cast(float, hi[q] & 0xffff0000u) + __builtin_bit_cast(float, lo[q] & 0xffff0000u);
+            c[2 * q] = __builtin_bit_cast(float, hi[2 + q] << 16) + __builtin_bit_cast(float, lo[2 + q] << 16);
+            c[2 * q + 1] = __builtin_bit_cast(float, hi[2 + q] & 0xffff0000u) + __builtin_bit_cast(float, lo[2 + q] & 0xffff0000u);
+        }
+        *(f32x4 *)(y + i * 8) = a;
+        *(f32x4 *)(y + i * 8 + 4) = c;
+    }
+}
+extern "C" int acg_s16_encode(const float *x, void *y, size_t n, void *stream)
+{
+    ACG_REQUIRE(n % 8 == 0, "acg_s16_encode: n %% 8 != 0");
+    hipLaunchKernelGGL(s16_encode_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, (hipStream_t)stream, x, (char *)y, (long long)(n / 8));
+    ACG_CHECK_LAUNCH("s16_encode_kernel");
+    return ACG_OK;
+}
+extern "C" int acg_s16_decode(const void *x, float *y, size_t n, void *stream)
+{
+    ACG_REQUIRE(n % 8 == 0, "acg_s16_decode: n %% 8 != 0");
+    hipLaunchKernelGGL(s16_decode_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, (hipStream_t)stream, (const char *)x, y, (long long)(n / 8));
+    ACG_CHECK_LAUNCH("s16_decode_kernel");
+    return ACG_OK;
+}
+
 // ---------------------------------------------------------------- layout at the API edge
 // NCHW (C real) -> NHWC with Cp channels (zeros beyond C).  One thread per (n, h, w) pixel-channel-quad.
 __global__ void nchw_to_nhwc_kernel(const float *__restrict__ s, float *__restrict__ d, int N, int C, int H, int W, int Cp)

@@ -200,11 +200,51 @@ class StepGraph(object):
     WARMUP = 2
 
     def __init__(self, model):
-        self.model, self.graph, self.key, self.calls = model, None, None, 0
+        self.model, self.graph, self.key, self.calls, self.ws = model, None, None, 0, None
 
     def _key(self, a, b, z):
-        lrs = tuple(opt.param_groups[0]['lr'] for opt in self.model._optimizers().values())
-        return (tuple(a.shape), tuple(b.shape), tuple(z.shape), lrs, self.model.netG_A_B.training)
+        m = self.model
+        lrs = tuple(opt.param_groups[0]['lr'] for opt in m._optimizers().values())
+        # everything a captured launch bakes in as an argument: shapes, learning rates, train/eval mode, the kernel
+        # configuration (precision / implementation switch) and the scalar options of the step
+        baked = tuple(getattr(m.opt, k, None) for k in ("max_gnorm", "lambda_A", "lambda_B", "lambda_z_B", "lambda_sup_A",
+                                                        "lambda_sup_B", "stoch_enc", "z_gan", "beta1"))
+        return (tuple(a.shape), tuple(b.shape), tuple(z.shape), lrs, m.netG_A_B.training, ops.CONFIG_EPOCH, baked)
+
+    def _capture(self, key, real_A, real_B, prior_z_B):
+        m = self.model
+        opts = list(m._optimizers().values())
+        inputs = [real_A.clone(), real_B.clone(), prior_z_B.clone()]
+        for opt in opts:
+            if opt.t_dev is None:
+                opt.t_dev = torch.zeros(1, dtype=torch.int32, device=real_A.device)
+        graph = torch.cuda.CUDAGraph()
+        # every derived tensor the step uses (packed weights, padded vectors) must be rebuilt INSIDE the graph: a cache
+        # that is still valid here — the discriminators', packed in the previous step's G phase — would be baked in as a
+        # pointer to eager memory and as the weights of one particular step
+        for net in m._nets():
+            mark_dirty(net)
+        # ... and so must the scratch buffers: the captured kernels keep the workspace POINTERS, and ops.workspace() replaces
+        # an eager buffer as soon as a later eager op (a larger evaluation batch) needs more.  The capture therefore starts
+        # from an empty workspace table, so its buffers come from the graph's private pool, and this object keeps them alive;
+        # the eager table is put back afterwards.
+        eager_ws, ops._WS = ops._WS, {}
+        t_before = [opt.t for opt in opts]
+        m._capturing = True
+        for opt in opts:
+            opt.dev_step = True
+        try:
+            with torch.cuda.graph(graph), _in_train_step():
+                pending = m._train_instance(*inputs)
+            graph_ws = ops._WS
+        finally:
+            ops._WS = eager_ws
+            m._capturing = False
+            for opt, t in zip(opts, t_before):     # the capture ran clip_and_step's host side without executing it
+                opt.t = t
+                opt.dev_step = False
+        # only a capture that completed is kept: a failed one leaves no half-built graph behind for the next call to replay
+        self.graph, self.key, self.inputs, self.pending, self.ws = graph, key, inputs, pending, graph_ws
 
     def __call__(self, real_A, real_B, prior_z_B):
         m = self.model
@@ -215,27 +255,8 @@ class StepGraph(object):
                 return m._train_instance(real_A, real_B, prior_z_B)
         opts = list(m._optimizers().values())
         if self.graph is None or key != self.key:
-            self.inputs = [real_A.clone(), real_B.clone(), prior_z_B.clone()]
-            for opt in opts:
-                if opt.t_dev is None:
-                    opt.t_dev = torch.zeros(1, dtype=torch.int32, device=real_A.device)
-            self.graph, self.key = torch.cuda.CUDAGraph(), key
-            # every derived tensor the step uses (packed weights, padded vectors) must be rebuilt INSIDE the graph: a cache
-            # that is still valid here — the discriminators', packed in the previous step's G phase — would be baked in as a
-            # pointer to eager memory and as the weights of one particular step
-            for net in m._nets():
-                mark_dirty(net)
-            m._capturing = True
-            for opt in opts:
-                opt.dev_step = True
-            try:
-                with torch.cuda.graph(self.graph), _in_train_step():
-                    self.pending = m._train_instance(*self.inputs)
-            finally:
-                m._capturing = False
-                for opt in opts:                      # the capture ran clip_and_step's host side once without executing it
-                    opt.t -= 1
-                    opt.dev_step = False
+            self.graph = self.key = None
+            self._capture(key, real_A, real_B, prior_z_B)
         for dst, src in zip(self.inputs, (real_A, real_B, prior_z_B)):
             dst.copy_(src)
         for opt in opts:

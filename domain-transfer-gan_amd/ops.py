@@ -229,11 +229,17 @@ class SkipGrad(object):
         self.mask = self.dy = None
 
     def take(self, dskip):
+        """-> (skip gradient, sign bitmask or None).  When the norm left its gradient un-materialised (mask set), what autograd
+        delivers must be that very tensor: anything else (a hook, a clone, a sum with another gradient) cannot be told apart
+        from dy * mask any more, so it is refused instead of being added unmasked."""
         mask, dy = self.mask, self.dy
         self.mask = self.dy = None
-        if mask is not None and dy is not None and dy.data_ptr() == dskip.data_ptr() and dy.shape == dskip.shape:
-            return mask
-        return None
+        if mask is None:
+            return dskip, None
+        if dy is None or dy.data_ptr() != dskip.data_ptr() or dy.shape != dskip.shape:
+            raise _lib.AcgError("the un-materialised skip gradient of a residual block was altered on its way to the block's "
+                                "first convolution (tensor hook / extra consumer of the skip tensor); set ACGAN_NO_LAZY_DRES=1")
+        return dskip, mask
 
 
 # Parameter gradients straight into .grad: a model.FlatNet marks its parameters `_acg_direct_grad`; their .grad tensors are
@@ -355,7 +361,7 @@ class Conv2dFn(torch.autograd.Function):
             if dskip is not None:
                 dskip = dskip.contiguous()
                 if ctx.skip_grad is not None:   # the skip gradient is dskip * sign-bitmask (NormAct lazy_dres)
-                    smask = ctx.skip_grad.take(dskip)
+                    dskip, smask = ctx.skip_grad.take(dskip)
             if dskip is not None and _lib.query("acg_conv2d_bwd_data_add_supported", ctypes.byref(d)) and \
                     (smask is None or (d.Hi * d.Wi * (d.Ci // 4)) % 8 == 0):
                 _lib.call("acg_conv2d_bwd_data_add", ctypes.byref(d), _ptr(g), _ptr(pk.wb), _ptr(dskip), _ptr(smask), _ptr(dx),
@@ -571,22 +577,24 @@ class SyncBatchNormAct(torch.autograd.Function):
         _lib.call("acg_norm_stats", _ptr(x), 1, P, C, eps, 0, _ptr(mean), _ptr(rstd), None, None, 0.0, _ptr(ws), nb, st)
         # local biased variance back from rstd, then combine across ranks: E[x], E[x^2] weighted by the pixel counts
         var = rstd.pow(-2) - eps
-        pack = torch.cat([mean * P, (var + mean * mean) * P])
+        pack = torch.cat([mean * P, (var + mean * mean) * P, mean.new_full((1,), float(P))])
         if td.get_backend() == "gloo" and pack.is_cuda:
             h = pack.cpu(); td.all_reduce(h); pack = h.to(x.device)
         else:
             td.all_reduce(pack)
-        # equal shards on every rank (the data-parallel contract: only then is the mean of the rank gradients the
-        # global-batch gradient, dist.py) -> the global pixel count is known on the host, no device->host sync here
+        # the global pixel count rides in the same all-reduce and stays on the device (no host sync): the statistics are
+        # exact for unequal shards too.  The backward's 1/Ptot is a launch argument and uses the equal-shard contract of
+        # the data-parallel step (only then is the mean of the rank gradients the global-batch gradient, dist.py).
+        cnt = pack[2 * C:]
         Ptot = float(P) * td.get_world_size()
-        gmean = pack[:C] / Ptot
-        gvar = (pack[C:2 * C] / Ptot - gmean * gmean).clamp_(min=0.0)
+        gmean = pack[:C] / cnt
+        gvar = (pack[C:2 * C] / cnt - gmean * gmean).clamp_(min=0.0)
         grstd = (gvar + eps).rsqrt()
         if run_mean is not None:
             nreal = run_mean.numel()
             with torch.no_grad():
                 run_mean.mul_(1 - momentum).add_(gmean[:nreal], alpha=momentum)
-                run_var.mul_(1 - momentum).add_(gvar[:nreal] * (Ptot / max(Ptot - 1, 1)), alpha=momentum)
+                run_var.mul_(1 - momentum).add_(gvar[:nreal] * (cnt / (cnt - 1).clamp(min=1.0)) * momentum)
         gmean, grstd = gmean.contiguous(), grstd.contiguous()
         y = torch.empty_like(x)
         _lib.call("acg_norm_apply", _ptr(x), _ptr(gmean), _ptr(grstd), _ptr(gamma_p), _ptr(beta_p), 0, None, _ptr(y), None, 1, P, C,

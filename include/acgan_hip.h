@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ACG_VERSION 100
+#define ACG_VERSION 110
 
 typedef enum {
     ACG_OK = 0,
@@ -124,6 +124,27 @@ int acg_conv2d_bwd_data_add(const acg_conv_desc *d, const float *dy, const float
  * its separate activation-backward pass is skipped (torch runs threshold_backward there).  Same support query as _add. */
 int acg_conv2d_bwd_data_relu(const acg_conv_desc *d, const float *dy, const float *wb, const float *x, float *dx,
                              void *ws, size_t ws_bytes, void *stream);
+/* ---- Pre-split ("S16") activation storage for the MFMA-bound 3x3 layers (the ResnetBlock / CINResnetBlock convolutions,
+ * modules.py:139-235, in the bf16x3 arithmetic).  An S16 tensor has the shape and byte size of its fp32 NHWC twin; per pixel
+ * and 8-channel group it holds 16 bytes of bf16 hi (RNE of x) followed by 16 bytes of bf16 lo (RNE of x - hi): the operand
+ * form the convolutions split every fp32 value into inside their loaders otherwise.  Written once by the producer of an
+ * activation (norm apply, convolution epilogue), it lets both operands of the convolution travel global -> LDS by LDS-DMA.
+ * acg_conv2d_s16_supported: forward, data gradient and weight gradient of this layer all take S16 operands. */
+int acg_s16_encode(const float *x, void *y_s16, size_t n, void *stream);   /* n elements, n % 8 == 0 */
+int acg_s16_decode(const void *x_s16, float *y, size_t n, void *stream);   /* y = hi + lo */
+int acg_conv2d_s16_supported(const acg_conv_desc *d);
+/* x S16; y fp32, or S16 when out_s16 != 0; stats (may be NULL): the per-tile statistics of acg_conv2d_fwd_stats (fp32 y,
+ * act NONE only) */
+int acg_conv2d_fwd_s16(const acg_conv_desc *d, const void *x_s16, const float *wf, const float *bias, void *y, int act,
+                       float *stats, int out_s16, void *stream);
+/* dy S16.  out_s16 == 0: dx fp32, optional addend (+ sign bitmask) as acg_conv2d_bwd_data_add.  out_s16 != 0: dx S16,
+ * optional relu_src_s16 as acg_conv2d_bwd_data_relu (the convolution's own S16 input; only its sign is read). */
+int acg_conv2d_bwd_data_s16(const acg_conv_desc *d, const void *dy_s16, const float *wb, void *dx, void *ws, size_t ws_bytes,
+                            const float *addend, const unsigned *addend_sign_mask, const void *relu_src_s16, int out_s16,
+                            void *stream);
+/* x and dy S16; dw / db as acg_conv2d_bwd_weight */
+int acg_conv2d_bwd_weight_s16(const acg_conv_desc *d, const void *x_s16, const void *dy_s16, float *dw, float *db, int Or,
+                              int Ir, void *ws, size_t ws_bytes, int accumulate, void *stream);
 /* weight (+bias) gradient: x, dy -> dw in torch OIHW layout (Or x Ir real channels), db[Or] (may be NULL).
  * Deterministic split-K over pixels with a second-stage reduction (no atomics).  accumulate != 0: the result is ADDED to
  * dw / db — pass the parameter's .grad (what autograd's AccumulateGrad does after loss.backward(), model.py:445, 509,

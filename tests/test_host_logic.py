@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     declared -= {"acg_status", "acg_act", "acg_pad_mode", "acg_conv_impl", "acg_conv_desc"}
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = _lib.load()  # binds every symbol; AttributeError if one is missing
-    assert lib.acg_version() == 100
+    assert lib.acg_version() == _lib.ABI_VERSION
     assert lib.acg_ncols_pad(16) == 32 and lib.acg_ncols_pad(64) == 64 and lib.acg_ncols_pad(256) == 256
 
 

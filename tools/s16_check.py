@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""GPU box: the pre-split (S16) convolution kernels against the fp32-operand kernels of the same arithmetic (they consume
+the same hi / lo halves in the same order, so outputs must agree bit for bit), then interleaved timings of both.
+    python tools/s16_check.py [--time] [--batch 32]"""
+import argparse
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import dtgan_amd  # noqa: E402
+from dtgan_amd import _lib, ops  # noqa: E402
+
+P = ops._ptr
+
+
+def enc(x):
+    y = torch.empty_like(x)
+    _lib.call("acg_s16_encode", P(x), P(y), x.numel(), ops._stream())
+    return y
+
+
+def dec(x):
+    y = torch.empty_like(x)
+    _lib.call("acg_s16_decode", P(x), P(y), x.numel(), ops._stream())
+    return y
+
+
+def check(name, a, b, exact=True):
+    d = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    ok = d == 0.0 if exact else d <= 1e-5 * ref
+    print("%-44s max|diff| %.3e (ref max %.3e) %s" % (name, d, ref, "OK" if ok else "MISMATCH"), flush=True)
+    return ok
+
+
+def run(N, H, W, C, time_it, iters):
+    dev = torch.device("cuda")
+    st = ops._stream()
+    d = ops.conv_desc(N, H, W, C, C, 3, 1, 1, 1, C, C)
+    assert _lib.query("acg_conv2d_s16_supported", ctypes.byref(d)), "layer not S16-capable"
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn((N, H, W, C), device=dev, generator=g)
+    x = torch.where(x > 0, x, torch.zeros_like(x))          # ReLU-like activations
+    dy = torch.randn((N, H, W, C), device=dev, generator=g) * 1e-3
+    w = torch.randn((C, C, 3, 3), device=dev, generator=g) * 0.05
+    b = torch.randn(C, device=dev, generator=g)
+    skip = torch.randn((N, H, W, C), device=dev, generator=g)
+    pk = ops.PackedConv(w, b, C, C)
+    xs, dys = enc(x), enc(dy)
+    ok = check("decode(encode(x)) vs x (2^-16 rel)", dec(xs), x, exact=False)
+    nb_d = _lib.query("acg_conv2d_bwd_data_workspace_bytes", ctypes.byref(d))
+    nb_w = _lib.query("acg_conv2d_bwd_weight_workspace_bytes", ctypes.byref(d))
+    ws = ops.workspace(max(nb_d, nb_w, 1))
+    D = ctypes.byref(d)
+    y0, y1, y2 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    part0 = torch.empty((N, H * W // 128, 2, C), device=dev)
+    part1 = torch.empty_like(part0)
+
+    def fwd_ref():
+        _lib.call("acg_conv2d_fwd_stats", D, P(x), P(pk.wf), P(pk.bias), P(y0), P(part0), st)
+
+    def fwd_s16():
+        _lib.call("acg_conv2d_fwd_s16", D, P(xs), P(pk.wf), P(pk.bias), P(y1), 0, P(part1), 0, st)
+
+    fwd_ref(); fwd_s16()
+    ok &= check("fwd + stats: y", y1, y0)
+    ok &= check("fwd + stats: tile statistics", part1, part0)
+    _lib.call("acg_conv2d_fwd", D, P(x), P(pk.wf), P(pk.bias), P(y0), 1, st)
+    _lib.call("acg_conv2d_fwd_s16", D, P(xs), P(pk.wf), P(pk.bias), P(y1), 1, None, 0, st)
+    ok &= check("fwd + ReLU (fp32 out)", y1, y0)
+    _lib.call("acg_conv2d_fwd_s16", D, P(xs), P(pk.wf), P(pk.bias), P(y2), 1, None, 1, st)
+    ok &= check("fwd + ReLU (S16 out) vs encode(fp32 out)", y2.view(torch.int32), enc(y0).view(torch.int32))
+
+    # data gradients
+    dx0, dx1 = torch.empty_like(x), torch.empty_like(x)
+
+    def dg_ref():
+        _lib.call("acg_conv2d_bwd_data", D, P(dy), P(pk.wb), P(dx0), P(ws), nb_d, st)
+
+    def dg_s16():
+        _lib.call("acg_conv2d_bwd_data_s16", D, P(dys), P(pk.wb), P(dx1), P(ws), nb_d, None, None, None, 0, st)
+
+    dg_ref(); dg_s16()
+    ok &= check("dgrad (fp32 out)", dx1, dx0)
+    mask = None
+    if (H * W * (C // 4)) % 8 == 0:
+        mask = torch.randint(-2 ** 31, 2 ** 31 - 1, ((N * H * W * C + 31) // 32,), device=dev, dtype=torch.int32, generator=g)
+    _lib.call("acg_conv2d_bwd_data_add", D, P(dy), P(pk.wb), P(skip), P(mask), P(dx0), P(ws), nb_d, st)
+    _lib.call("acg_conv2d_bwd_data_s16", D, P(dys), P(pk.wb), P(dx1), P(ws), nb_d, P(skip), P(mask), None, 0, st)
+    ok &= check("dgrad + masked skip addend (fp32 out)", dx1, dx0)
+    _lib.call("acg_conv2d_bwd_data_relu", D, P(dy), P(pk.wb), P(x), P(dx0), P(ws), nb_d, st)
+    _lib.call("acg_conv2d_bwd_data_s16", D, P(dys), P(pk.wb), P(dx1), P(ws), nb_d, None, None, P(xs), 1, st)
+    ok &= check("dgrad * (x > 0) (S16 out) vs encode(ref)", dx1.view(torch.int32), enc(dx0).view(torch.int32))
+
+    # weight gradient
+    dw0, dw1 = torch.empty_like(w), torch.empty_like(w)
+    db0, db1 = torch.empty_like(b), torch.empty_like(b)
+
+    def wg_ref():
+        _lib.call("acg_conv2d_bwd_weight", D, P(x), P(dy), P(dw0), P(db0), C, C, P(ws), nb_w, 0, st)
+
+    def wg_s16():
+        _lib.call("acg_conv2d_bwd_weight_s16", D, P(xs), P(dys), P(dw1), P(db1), C, C, P(ws), nb_w, 0, st)
+
+    wg_ref(); k0 = _lib.query("acg_last_kernel").decode()
+    wg_s16(); k1 = _lib.query("acg_last_kernel").decode()
+    ok &= check("wgrad: dw (%s vs %s)" % (k1, k0), dw1, dw0)
+    ok &= check("wgrad: db (hi + lo vs fp32 sums)", db1, db0, exact=False)
+    torch.cuda.synchronize()
+    if not time_it:
+        return ok
+    flops = 2.0 * N * H * W * C * C * 9
+    for rnd in range(3):
+        line = "round %d:" % rnd
+        for nm, f in (("fwd ref", fwd_ref), ("fwd s16", fwd_s16), ("dgrad ref", dg_ref), ("dgrad s16", dg_s16),
+                      ("wgrad ref", wg_ref), ("wgrad s16", wg_s16)):
+            f()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                f()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / iters
+            line += "  %s %.3f ms (%.0f TF)" % (nm, ms, flops / ms / 1e9)
+        print(line, flush=True)
+    return ok
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--time", action="store_true")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    ops.set_precision("bf16x3")
+    ok = run(2, 64, 64, 128, False, 0)      # two segments per tile
+    ok &= run(1, 32, 32, 128, False, 0)     # four segments per tile
+    ok &= run(2, 128, 128, 128, False, 0)   # the config-3 trunk geometry
+    if a.time:
+        ok &= run(a.batch, 128, 128, 128, True, a.iters)
+    print("ALL OK" if ok else "FAILED")
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
