@@ -87,9 +87,9 @@ SIGNATURES = {
     "acg_norm_stats_from_partials": (c_int, [_P, c_int, c_size_t, c_int, c_int, c_float, c_int, _P, _P, _P]),
     "acg_norm_stats": (c_int, [_P, c_int, c_size_t, c_int, c_float, c_int, _P, _P, _P, _P, c_float, _P, c_size_t, _P]),
     "acg_bn_eval_stats": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P, _P]),
-    "acg_norm_apply": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_size_t, c_int, c_int, _P]),
+    "acg_norm_apply": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_size_t, c_int, c_int, c_int, _P]),
     "acg_norm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_size_t, c_int, c_int,
-                             c_int, _P, c_size_t, _P]),
+                             c_int, c_int, _P, c_size_t, _P]),
     "acg_norm_bwd_sums": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_size_t, c_int, c_int, _P, c_size_t, _P]),
     "acg_norm_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_size_t, c_size_t, c_int, c_int, c_int, _P]),
     "acg_act_bwd": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),

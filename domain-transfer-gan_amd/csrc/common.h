@@ -11,6 +11,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 void acg_set_error(const char *fmt, ...);
 void acg_note_kernel(const char *fmt, ...);
 extern int g_acg_conv_impl;
+// A/B switches of the kernel dispatchers (ACG_NO_*: take the previous kernel instead of the current one, for interleaved
+// timings on one GPU box).  Development aids, not configuration: they are honoured only when ACG_DEBUG_SWITCHES is set, so a
+// stray variable in a production environment cannot change which kernels run.
+bool acg_debug_switch(const char *name);
 
 #define ACG_REQUIRE(cond, ...)                 \
     do {                                       \

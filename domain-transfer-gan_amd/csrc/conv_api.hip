@@ -878,7 +878,7 @@ static bool acg_wgrad_krow_s16_ok(const acg_conv_desc *d) // the conditions unde
 {
     return g_acg_precision == ACG_PREC_BF16X3 && g_acg_conv_impl == ACG_IMPL_MFMA && !thin_in(d) && d->K == 3 && d->stride == 1 &&
            d->pad == 1 && d->Hi == d->Ho && d->Wi == d->Wo && d->Wo % 32 == 0 && d->Ci % 128 == 0 && d->Co % 128 == 0 &&
-           getenv("ACG_NO_KROW") == nullptr;
+           !acg_debug_switch("ACG_NO_KROW");
 }
 
 static bool s16_dgrad_geom_ok(const acg_conv_desc *d)
@@ -963,7 +963,7 @@ static void wgrad_plan(const acg_conv_desc *d, int Cx, int Cg, long long Mtot, i
     int gran = KP;
     // kernel-row weight gradient (conv_wgrad_tr.hip, same conditions as acg_wgrad_krow_ok): three taps per workgroup, one
     // 512-thread workgroup per CU -> one residency wave of 256
-    static const bool no_krow = getenv("ACG_NO_KROW") != nullptr;
+    static const bool no_krow = acg_debug_switch("ACG_NO_KROW");
     if (!no_krow && g_acg_precision == ACG_PREC_BF16X3 && g_acg_conv_impl == ACG_IMPL_MFMA && !wgrad_thin(d) && d->K == 3 &&
         d->stride == 1 && d->pad == 1 && d->Hi == d->Ho && d->Wi == d->Wo && d->Wo % 32 == 0 && Cx % 128 == 0 && Cg % 128 == 0) {
         nblk = 3LL * (*CiP / 128) * (*CoP / 128);

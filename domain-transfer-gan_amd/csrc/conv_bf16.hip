@@ -231,7 +231,7 @@ static void launch_bf16_kc(int bn, dim3 grid, hipStream_t st, const float *in, c
 // does this launch go to the wave-specialised bf16x3 kernel (conv_x3.hip)?  128-column tiles, 32-channel stages
 bool acg_igemm_uses_ws(const Geom &g)
 {
-    static const bool no_ws = getenv("ACG_NO_WS") != nullptr; // A/B switch
+    static const bool no_ws = acg_debug_switch("ACG_NO_WS"); // A/B switch
     return !no_ws && g_acg_precision == ACG_PREC_BF16X3 && g_acg_conv_impl == ACG_IMPL_MFMA && !g.thin && g.Cout >= 128 &&
            g.Cin % 32 == 0;
 }
@@ -256,7 +256,7 @@ int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, fl
         else launch_bf16_kc<KCV, false, SP>(bn, grid, st, in, w, bias, out, g, t, inb, wb, wlo);            \
     } while (0)
     if (acg_igemm_uses_ws(g0)) return acg_igemm_x3_ws_launch(in, wp, bias, out, g0, t, n_w_elems, st);
-    static const bool no_patch = getenv("ACG_NO_PATCH") != nullptr; // A/B switch
+    static const bool no_patch = acg_debug_switch("ACG_NO_PATCH"); // A/B switch
     if (!no_patch && acg_conv_patch16_ok(g0, t)) return acg_conv_patch16_launch(in, wp, bias, out, g0, t, n_w_elems, st);
     ACG_REQUIRE(g0.fold_p == 0, "igemm_conv_bf16: the fold bypass is implemented by the wave-specialised kernel only");
     if (split) { // hi+lo images double the LDS: 32-channel stages keep 3-4 blocks per CU

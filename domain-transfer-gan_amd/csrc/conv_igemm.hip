@@ -291,7 +291,7 @@ int acg_igemm_launch(const float *in, const float *wp, const float *bias, float 
     dim3 grid(tiles_m * tiles_n);
     const unsigned inb = (unsigned)in_bytes, wb = (unsigned)w_bytes;
     const bool kc32 = (g.Cin % 32 == 0) || g.thin;
-    static const bool no_thin_x3 = getenv("ACG_NO_THIN_X3") != nullptr; // A/B switch
+    static const bool no_thin_x3 = acg_debug_switch("ACG_NO_THIN_X3"); // A/B switch
     const bool x3 = g_acg_precision != ACG_PREC_F32 && g_acg_conv_impl == ACG_IMPL_MFMA && !no_thin_x3;
     if (g.thin && x3) {
         if (g.reflect) launch_v<32, true, true, true>(bn, grid, st, in, wp, bias, out, g, t, inb, wb);

@@ -287,7 +287,7 @@ int acg_wgrad_launch(const float *x, const float *dy, float *part, const WGeom &
         hipLaunchKernelGGL((wgrad_f32<32, 64, 1, 2, 2, 64>), grid, block, 0, st, x, dy, part, g, t, xb, db);
     else if (bci == 64 && bco == 32)
         hipLaunchKernelGGL((wgrad_f32<64, 32, 2, 1, 2, 64>), grid, block, 0, st, x, dy, part, g, t, xb, db);
-    else if (g.thin && g_acg_precision != ACG_PREC_F32 && g_acg_conv_impl == ACG_IMPL_MFMA && getenv("ACG_NO_THIN_X3") == nullptr)
+    else if (g.thin && g_acg_precision != ACG_PREC_F32 && g_acg_conv_impl == ACG_IMPL_MFMA && !acg_debug_switch("ACG_NO_THIN_X3"))
         hipLaunchKernelGGL((wgrad_f32<32, 32, 1, 1, 4, 128, true>), grid, block, 0, st, x, dy, part, g, t, xb, db);
     else
         hipLaunchKernelGGL((wgrad_f32<32, 32, 1, 1, 4, 128>), grid, block, 0, st, x, dy, part, g, t, xb, db);

@@ -470,7 +470,7 @@ static bool krow_taps_ok(const WGeom &g, const Taps &t)
 // the 32 <-> 64 channel variant: whole-tensor channel tiles, width a multiple of the 128-pixel run
 bool acg_wgrad_krow_s_ok(const WGeom &g, const Taps &t)
 {
-    static const bool off = getenv("ACG_NO_KROW") != nullptr || getenv("ACG_NO_KROW_S") != nullptr; // A/B switches
+    static const bool off = acg_debug_switch("ACG_NO_KROW") || acg_debug_switch("ACG_NO_KROW_S"); // A/B switches
     if (off || !krow_taps_ok(g, t) || g.Wg % SKP != 0 || g.m_per_split % SKP != 0) return false;
     const bool c = (g.Cin == 32 && g.Cg == 64) || (g.Cin == 64 && g.Cg == 32);
     return c && g.CiP == g.Cin && g.CoP == g.Cg;
@@ -492,7 +492,7 @@ int acg_wgrad_krow_s_launch(const float *x, const float *dy, float *part, const 
 // stride-1 3x3, pad 1, same-size maps whose width is a multiple of the 32-pixel run, 128-multiple channels on both sides
 bool acg_wgrad_krow_ok(const WGeom &g, const Taps &t)
 {
-    static const bool off = getenv("ACG_NO_KROW") != nullptr; // A/B switch
+    static const bool off = acg_debug_switch("ACG_NO_KROW"); // A/B switch
     if (off || g_acg_precision != ACG_PREC_BF16X3 || g_acg_conv_impl != ACG_IMPL_MFMA || g.thin) return false;
     if (t.n != 9 || g.is != 1 || g.Hin != g.Hg || g.Win != g.Wg || g.Wg % KP != 0) return false;
     if (g.Cin % BC != 0 || g.Cg % BC != 0 || g.CiP != g.Cin || g.CoP != g.Cg || g.bias_from == 2) return false;

@@ -510,7 +510,7 @@ int acg_igemm_x3_ws_launch(const float *in, const void *wp, const float *bias, f
     // row-patch variant: K x K tap lists in kernel-row order (forward: dx ascending, stride-1 data gradient: descending) on
     // grids whose width divides the 128-pixel tile
     int kdim = 0, dxmin = 0, kstep = 1;
-    static const bool no_rowp = getenv("ACG_NO_ROWP") != nullptr; // A/B switch
+    static const bool no_rowp = acg_debug_switch("ACG_NO_ROWP"); // A/B switch
     if (!no_rowp && g.is == 1 && g.os == 1 && g.oy0 == 0 && g.ox0 == 0) {
         int k = 1;
         while (k * k < t.n) ++k;

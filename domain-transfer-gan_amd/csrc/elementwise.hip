@@ -1,6 +1,7 @@
 // Elementwise / reduction / small-dense kernels (all HBM- or latency-bound) and the optimiser.
 #include <math.h>
 #include "common.h"
+#include <cstdlib>
 
 static int ew_blocks(long long total, int per = 256)
 {
@@ -31,6 +32,11 @@ void acg_note_kernel(const char *fmt, ...)
     va_end(ap);
 }
 extern "C" const char *acg_last_kernel(void) { return g_kern; }
+bool acg_debug_switch(const char *name)
+{
+    static const bool enabled = getenv("ACG_DEBUG_SWITCHES") != nullptr;
+    return enabled && getenv(name) != nullptr;
+}
 extern "C" int acg_version(void) { return ACG_VERSION; }
 
 // ---------------------------------------------------------------- activation backward

@@ -111,6 +111,46 @@ __global__ __launch_bounds__(256) void norm_stats_final(const float *__restrict_
     }
 }
 
+// Pre-split ("S16", conv_internal.h) tensors in the float4-per-thread element-wise kernels: the 8-channel group of a
+// lane PAIR occupies 32 contiguous bytes, 16 of hi then 16 of lo.  Lane 2k moves the hi half and lane 2k+1 the lo half as one
+// 16-byte access each (fully contiguous across the wave), and the pair swaps 8 bytes through DPP so that each lane ends up
+// with (stores: starts from) hi and lo of its own four channels.  `o` is the lane's float index (a multiple of 4, parity
+// of o/4 == parity of the lane).
+typedef unsigned norm_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 s16_load4(const float *__restrict__ t, long long o)
+{
+    const int odd = (int)(o >> 2) & 1;
+    const norm_u32x4 own = *(const norm_u32x4 *)((const char *)t + 4 * (o & ~7LL) + 16 * odd);   // even lane: hi[0..7], odd lane: lo[0..7]
+    const unsigned s0 = odd ? own[0] : own[2], s1 = odd ? own[1] : own[3];                      // what the partner needs
+    const unsigned r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+    const unsigned h0 = odd ? r0 : own[0], h1 = odd ? r1 : own[1], l0 = odd ? own[2] : r0, l1 = odd ? own[3] : r1;
+    f32x4 v;
+    v[0] = __builtin_bit_cast(float, h0 << 16) + __builtin_bit_cast(float, l0 << 16);
+    v[1] = __builtin_bit_cast(float, h0 & 0xffff0000u) + __builtin_bit_cast(float, l0 & 0xffff0000u);
+    v[2] = __builtin_bit_cast(float, h1 << 16) + __builtin_bit_cast(float, l1 << 16);
+    v[3] = __builtin_bit_cast(float, h1 & 0xffff0000u) + __builtin_bit_cast(float, l1 & 0xffff0000u);
+    return v;
+}
+// every lane of a pair must call this (the exchange), `store` says whether the lane's own element is in range
+__device__ __forceinline__ void s16_store4(float *__restrict__ t, long long o, const f32x4 v, bool store)
+{
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    unsigned hi[2], lo[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { // the arithmetic of acg_split8
+        const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[2 * q], v[2 * q + 1]}, bf16x2_t));
+        const float ha = __builtin_bit_cast(float, h << 16), hb = __builtin_bit_cast(float, h & 0xffff0000u);
+        hi[q] = h;
+        lo[q] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[2 * q] - ha, v[2 * q + 1] - hb}, bf16x2_t));
+    }
+    const int odd = (int)(o >> 2) & 1;
+    const unsigned s0 = odd ? hi[0] : lo[0], s1 = odd ? hi[1] : lo[1];
+    const unsigned r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+    const norm_u32x4 w = odd ? (norm_u32x4){r0, r1, lo[0], lo[1]} : (norm_u32x4){hi[0], hi[1], r0, r1};
+    if (store) *(norm_u32x4 *)((char *)t + 4 * (o & ~7LL) + 16 * odd) = w;
+}
+
 // ACT / HAS_RES are template parameters: with run-time switches the body is a web of scalar branches with
 // s_waitcnt vmcnt(0) between them and the loads of a thread are issued one at a time (2.7-3.6 TB/s); specialised, all
 // loads of a thread go out back to back like a streaming copy.
@@ -119,7 +159,8 @@ __global__ __launch_bounds__(256) void norm_stats_final(const float *__restrict_
 // before the activation (without a residual it recomputes the sign from x).  Bit e%32 of word e/32 for the element at
 // float index e; a thread's float4 is one nibble, 8 consecutive lanes own one word (OR-butterfly over lanes ^1, ^2, ^4).
 // The backward passes then read 1/32 of a tensor instead of y itself: -2 of the 8 tensor streams of a block-output norm.
-template <int ACT, bool HAS_RES, bool MASK>
+// FMT bit 0: `res` is pre-split (S16), bit 1: y is written pre-split (both need C % 8 == 0 and whole lane pairs in range)
+template <int ACT, bool HAS_RES, bool MASK, int FMT = 0>
 __global__ __launch_bounds__(256) void norm_apply_kernel(const float *__restrict__ x, const float *__restrict__ mean,
                                                          const float *__restrict__ rstd,
                                                          const float *__restrict__ gamma,
@@ -141,7 +182,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float *__restrict
         ok[u] = i0 + u * 256 < total;
         const long long o = base + (ok[u] ? i0 + u * 256 : 0) * 4;
         v[u] = *(const f32x4 *)(x + o);
-        if (HAS_RES) rv[u] = *(const f32x4 *)(res + o);
+        if (HAS_RES) rv[u] = (FMT & 1) ? s16_load4(res, o) : *(const f32x4 *)(res + o);
     }
     int c = (int)(i0 % C4) * 4;
     f32x4 mu = *(const f32x4 *)(mean + g * C + c), rs = *(const f32x4 *)(rstd + g * C + c);
@@ -157,7 +198,8 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float *__restrict
         if (HAS_RES) o += rv[u];
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = acg_apply_act(o[k], ACT);
-        if (ok[u]) *(f32x4 *)(y + base + (i0 + u * 256) * 4) = o;
+        if (FMT & 2) s16_store4(y, base + (i0 + u * 256) * 4, o, ok[u]);
+        else if (ok[u]) *(f32x4 *)(y + base + (i0 + u * 256) * 4) = o;
         if (MASK) {
             const long long f = base / 4 + i0 + u * 256;   // float4 index; (f & 7) == (lane & 7): the launcher checks P*C/4 % 8 == 0
             unsigned v = ok[u] ? ((o[0] > 0.f ? 1u : 0u) | (o[1] > 0.f ? 2u : 0u) | (o[2] > 0.f ? 4u : 0u) | (o[3] > 0.f ? 8u : 0u)) : 0u;
@@ -312,7 +354,8 @@ __global__ void norm_bwd_params(const float *__restrict__ sums, int G, int C, in
 }
 
 // backward pass 2: dx = gamma*rstd*(gy - S1/P - xhat*S2/D) ; dres = gy
-template <int ACT, int MSRC, bool HAS_DRES> // activation mask: MSRC 0 = read y, 1 = recompute from x (y == nullptr), 2 = sign bitmask
+// DXS16: dx is written pre-split (S16)
+template <int ACT, int MSRC, bool HAS_DRES, bool DXS16 = false> // activation mask: MSRC 0 = read y, 1 = recompute from x (y == nullptr), 2 = sign bitmask
 __global__ __launch_bounds__(256) void norm_bwd_apply(const float *__restrict__ dy, const float *__restrict__ y,
                                                       const float *__restrict__ x, const float *__restrict__ mean,
                                                       const float *__restrict__ rstd,
@@ -368,10 +411,12 @@ __global__ __launch_bounds__(256) void norm_bwd_apply(const float *__restrict__ 
 #pragma unroll
             for (int k = 0; k < 4; ++k) gy[k] *= acg_act_grad_from_y(yy[k], ACT);
         }
-        if (ok[u]) {
+        {
             const long long o = base + (i0 + u * 256) * 4;
-            *(f32x4 *)(dx + o) = ga * rs * (gy - s1 - xh * s2);
-            if (HAS_DRES) *(f32x4 *)(dres + o) = gy;
+            const f32x4 d = ga * rs * (gy - s1 - xh * s2);
+            if (DXS16) s16_store4(dx, o, d, ok[u]);
+            else if (ok[u]) *(f32x4 *)(dx + o) = d;
+            if (HAS_DRES && ok[u]) *(f32x4 *)(dres + o) = gy;
         }
     }
 }
@@ -408,8 +453,15 @@ extern "C" int acg_mask_apply(const float *x, const unsigned *sign_mask, float *
 
 static void launch_norm_apply(dim3 grid, hipStream_t st, const float *x, const float *mean, const float *rstd,
                               const float *gamma, const float *beta, int gstride, const float *res, float *y, long long P,
-                              int C, int act, unsigned *mask)
+                              int C, int act, unsigned *mask, int fmt)
 {
+#define LA(A, R, K, F) hipLaunchKernelGGL((norm_apply_kernel<A, R, K, F>), grid, dim3(256), 0, st, x, mean, rstd, gamma, beta, gstride, res, y, P, C, mask)
+    if (fmt) { // pre-split I/O: the combinations the residual trunk uses (ReLU; residual + bitmask, or neither)
+        if (res && mask && fmt == 3) LA(ACG_ACT_RELU, true, true, 3);
+        else if (res && fmt == 3) LA(ACG_ACT_RELU, true, false, 3);
+        else LA(ACG_ACT_RELU, false, false, 2);
+        return;
+    }
 #define M(A)                                                                                                              \
     do {                                                                                                                  \
         if (res && mask) hipLaunchKernelGGL((norm_apply_kernel<A, true, true>), grid, dim3(256), 0, st, x, mean, rstd, gamma, beta, gstride, res, y, P, C, mask); \
@@ -418,6 +470,7 @@ static void launch_norm_apply(dim3 grid, hipStream_t st, const float *x, const f
     } while (0)
     NORM_ACT_SWITCH(act, M)
 #undef M
+#undef LA
 }
 
 static void launch_norm_bwd_partial(dim3 grid, hipStream_t st, const float *dy, const float *y, const float *x, const float *mean,
@@ -439,8 +492,14 @@ static void launch_norm_bwd_partial(dim3 grid, hipStream_t st, const float *dy, 
 static void launch_norm_bwd_apply(dim3 grid, hipStream_t st, const float *dy, const float *y, const float *x,
                                   const float *mean, const float *rstd, const float *gamma, const float *beta, int gstride,
                                   const float *sums, float *dx, float *dres, long long P, int C, int act, float invP,
-                                  float invD, const unsigned *mask)
+                                  float invD, const unsigned *mask, int dx_s16 = 0)
 {
+#define LS(A, R) hipLaunchKernelGGL((norm_bwd_apply<A, R, false, true>), grid, dim3(256), 0, st, dy, y, x, mean, rstd, gamma, beta, gstride, sums, dx, dres, P, C, invP, invD, mask)
+    if (dx_s16) { // pre-split dx: ReLU with the sign bitmask (block-output norm) or recomputed from x (CondInstanceNorm)
+        if (mask) LS(ACG_ACT_RELU, 2);
+        else LS(ACG_ACT_RELU, 1);
+        return;
+    }
 #define L(A, R, D) hipLaunchKernelGGL((norm_bwd_apply<A, R, D>), grid, dim3(256), 0, st, dy, y, x, mean, rstd, gamma, beta, gstride, sums, dx, dres, P, C, invP, invD, mask)
 #define M(A)                                                                         \
     do {                                                                             \
@@ -455,6 +514,7 @@ static void launch_norm_bwd_apply(dim3 grid, hipStream_t st, const float *dy, co
     NORM_ACT_SWITCH(act, M)
 #undef M
 #undef L
+#undef LS
 }
 
 // BatchNorm eval mode: statistics come from the running buffers
@@ -537,15 +597,17 @@ static int ew_blocks(long long total)
 
 extern "C" int acg_norm_apply(const float *x, const float *mean, const float *rstd, const float *gamma,
                               const float *beta, int gstride, const float *res, float *y, unsigned *mask, int G, size_t P,
-                              int C, int act, void *stream)
+                              int C, int act, int fmt, void *stream)
 {
     int rc = check_norm(G, P, C, "acg_norm_apply");
     if (rc) return rc;
+    ACG_REQUIRE(fmt == 0 || ((fmt == 2 || (fmt == 3 && res != nullptr)) && act == ACG_ACT_RELU && C % 8 == 0 && (mask == nullptr || res != nullptr)),
+                "acg_norm_apply: pre-split I/O (fmt %d) is implemented for ReLU with y pre-split and, if given, the residual too", fmt);
     ACG_REQUIRE(gstride == 0 || gstride == C, "acg_norm_apply: gstride must be 0 or C");
     ACG_REQUIRE(mask == nullptr || (res != nullptr && ((long long)P * (C / 4)) % 8 == 0 && (act == ACG_ACT_RELU || act == ACG_ACT_LRELU)),
                 "acg_norm_apply: the sign bitmask needs a residual, ReLU / LeakyReLU and P*C/4 %% 8 == 0");
     launch_norm_apply(dim3(ew_blocks((long long)P * (C / 4)), G), (hipStream_t)stream, x, mean, rstd, gamma, beta, gstride, res,
-                      y, (long long)P, C, act, mask);
+                      y, (long long)P, C, act, mask, fmt);
     ACG_CHECK_LAUNCH("norm_apply_kernel");
     return ACG_OK;
 }
@@ -592,10 +654,12 @@ extern "C" int acg_norm_bwd(const float *dy, const float *y, const unsigned *mas
                             const float *rstd,
                             const float *gamma, const float *beta, int gstride, float *dx, float *dres, float *dgamma,
                             float *dbeta, int nparam, int accumulate, int G, size_t P, int C, int act, int unbiased,
-                            void *ws, size_t ws_bytes, void *stream)
+                            int dx_s16, void *ws, size_t ws_bytes, void *stream)
 {
     int rc = check_norm(G, P, C, "acg_norm_bwd");
     if (rc) return rc;
+    ACG_REQUIRE(dx_s16 == 0 || (act == ACG_ACT_RELU && dres == nullptr && C % 8 == 0 && (mask != nullptr || y == nullptr)),
+                "acg_norm_bwd: pre-split dx is implemented for ReLU with the sign bitmask or the mask recomputed from x, without dres");
     ACG_REQUIRE(gstride != 0 || (nparam >= 0 && nparam <= C), "acg_norm_bwd: nparam=%d exceeds C=%d", nparam, C);
     ACG_REQUIRE(gstride == 0 || accumulate == 0, "acg_norm_bwd: accumulate is for shared (gstride == 0) parameters");
     ACG_REQUIRE(gstride == 0 || gstride == C, "acg_norm_bwd: gstride must be 0 or C");
@@ -621,7 +685,7 @@ extern "C" int acg_norm_bwd(const float *dy, const float *y, const unsigned *mas
     const float invP = unbiased == 2 ? 0.f : 1.f / (float)P;
     const float invD = unbiased == 2 ? 0.f : (unbiased ? 1.f / (float)(P - 1) : invP);
     launch_norm_bwd_apply(dim3(ew_blocks((long long)P * (C / 4)), G), st, dy, y, x, mean, rstd, gamma, beta, gstride,
-                          (const float *)sums, dx, dres, (long long)P, C, act, invP, invD, mask);
+                          (const float *)sums, dx, dres, (long long)P, C, act, invP, invD, mask, dx_s16);
     ACG_CHECK_LAUNCH("norm_bwd");
     return ACG_OK;
 }

@@ -72,13 +72,19 @@ class Conv2d(nn.Conv2d, _Cached):
         return self._cached(lambda: ops.PackedConv(self.weight, self.bias, cpad(self.in_channels), cpad(self.out_channels)))
 
     def forward_nhwc(self, x, act=ACT_NONE, reflect_pad=0, want_stats=None, want_identity=False, link_out=None,
-                     link_in=None, skip_grad=None):
+                     link_in=None, skip_grad=None, s16=None):
         if reflect_pad:
             pad, mode = reflect_pad, PAD_REFLECT
         else:
             pad, mode = self.padding[0], PAD_ZERO
-        return ops.Conv2dFn.apply(x, self.weight, self.bias, self.packed(), self.stride[0], pad, mode, act, want_stats,
-                                  want_identity, link_out, link_in, skip_grad)
+        out = ops.Conv2dFn.apply(x, self.weight, self.bias, self.packed(), self.stride[0], pad, mode, act, want_stats,
+                                 want_identity, link_out, link_in, skip_grad, s16)
+        if s16 is not None and s16.x:   # tag what left the convolution pre-split: its output (conv + ReLU) and the alias of x
+            if want_identity:
+                ops.tag_s16(out[1])
+            if s16.y:
+                ops.tag_s16(out[0] if want_identity else out)
+        return out
 
     def forward(self, input):
         return ops.ToNCHW.apply(self.forward_nhwc(ops.ToNHWC.apply(input)), self.out_channels)
@@ -222,9 +228,11 @@ class InstanceNorm(nn.Module, _Cached):
         dev = self.scale.device
         return torch.ones(C, device=dev), torch.zeros(C, device=dev)
 
-    def forward_act(self, x, act=ACT_NONE, res=None, lazy_dres=None, stats=None):
+    def forward_act(self, x, act=ACT_NONE, res=None, lazy_dres=None, stats=None, s16_out=False, s16_dx=False):
         g, b = self._gb()
-        return ops.NormAct.apply(x, self.scale, self.shift, res, "in", act, self.eps, g, b, None, None, 0.0, lazy_dres, stats)
+        y = ops.NormAct.apply(x, self.scale, self.shift, res, "in", act, self.eps, g, b, None, None, 0.0, lazy_dres, stats,
+                              s16_out, s16_dx, res is not None and ops.is_s16(res))
+        return ops.tag_s16(y) if s16_out else y
 
     def forward(self, input):
         return ops.ToNCHW.apply(self.forward_act(ops.ToNHWC.apply(input)), self.num_features)
@@ -246,11 +254,12 @@ class CondInstanceNorm(TwoInputModule):
         self.shift_conv = nn.Sequential(Conv2d(z_dim, x_dim, kernel_size=1, padding=0, bias=True), nn.ReLU(True))
         self.scale_conv = nn.Sequential(Conv2d(z_dim, x_dim, kernel_size=1, padding=0, bias=True), nn.ReLU(True))
 
-    def forward_act(self, x, z, act=ACT_NONE, stats=None):
+    def forward_act(self, x, z, act=ACT_NONE, stats=None, s16_out=False, s16_dx=False):
         Cp = x.shape[-1]
         sh = ops.LinearFn.apply(z, self.shift_conv[0].weight, self.shift_conv[0].bias, ACT_RELU, Cp)
         sc = ops.LinearFn.apply(z, self.scale_conv[0].weight, self.scale_conv[0].bias, ACT_RELU, Cp)
-        return ops.NormAct.apply(x, sc, sh, None, "cin", act, self.eps, None, None, None, None, 0.0, None, stats)
+        y = ops.NormAct.apply(x, sc, sh, None, "cin", act, self.eps, None, None, None, None, 0.0, None, stats, s16_out, s16_dx)
+        return ops.tag_s16(y) if s16_out else y
 
     def forward(self, input, noise):
         y = self.forward_act(ops.ToNHWC.apply(input), as_latent(noise))
@@ -282,6 +291,12 @@ def run_sequence(mods, x, C, z=None, res=None):
     skip_routed = False
     relu_link = None   # set by a conv+ReLU whose output goes straight into the next convolution (ops.ReluLink)
     skip_grad = None   # ops.SkipGrad slot shared by the block's first convolution and its last norm
+    # Pre-split ("S16") storage of the residual trunk (ops.S16Plan): the norm in front of the first block writes its
+    # output pre-split when that block can take it, every tensor a 3x3 trunk convolution reads stays pre-split from there
+    # (block outputs, conv + ReLU outputs, the gradients the norms and the fused data gradients write), and the first
+    # layer behind the last block gets it decoded.  s16 = this list is the inside of such a block.
+    s16 = res is not None and ops.is_s16(x)
+    nconv = 0
     while i < n:
         m = mods[i]
         if isinstance(m, nn.ReflectionPad2d):
@@ -292,6 +307,8 @@ def run_sequence(mods, x, C, z=None, res=None):
             x = m.forward_nhwc(x, z)
             i += 1
             continue
+        if res is None and ops.is_s16(x):
+            x = ops.S16Decode.apply(x)
         conv, norm, stats = None, None, None
         if isinstance(m, MergeModule):
             conv, norm = m.module1, m.module2
@@ -331,7 +348,17 @@ def run_sequence(mods, x, C, z=None, res=None):
             stats = ops.ConvStats() if isinstance(norm, (InstanceNorm, CondInstanceNorm)) else None
             if skip_here:
                 skip_grad = ops.SkipGrad()
-            x = conv.forward_nhwc(x, cact, reflect, stats, skip_here, link_out, link_in, skip_grad if skip_here else None)
+            plan = None
+            if s16:
+                # first convolution: writes pre-split iff it is a conv + ReLU (then its dy arrives pre-split and masked from the
+                # next convolution's data gradient), dx fp32 + skip gradient; second: dy pre-split from the block-output norm,
+                # dx pre-split with the first one's ReLU mask where that link exists (else fp32 for the norm in between)
+                plan = ops.S16Plan(x=True, y=(cact == ACT_RELU and link_out is not None), gy=norm is not None,
+                                   dx=(nconv > 0 and link_in is not None))
+                if nconv == 0 and not skip_here:
+                    raise NotImplementedError("pre-split trunk: the block's first layer must be its first convolution")
+            nconv += 1
+            x = conv.forward_nhwc(x, cact, reflect, stats, skip_here, link_out, link_in, skip_grad if skip_here else None, plan)
             if skip_here:  # the skip connection continues from the conv's identity output: its gradient is added
                 x, res = x  # inside that conv's data-gradient epilogue
                 skip_routed = True
@@ -341,20 +368,52 @@ def run_sequence(mods, x, C, z=None, res=None):
             fuse_res = res is not None and norm_idx == last_norm
             if fuse_res and act != ACT_NONE:
                 raise NotImplementedError("residual fusion expects the block to end with its norm")
+            # pre-split output: inside a pre-split block always (its consumer is a trunk convolution or the next block);
+            # outside, when the next module is a block that can take it
+            emit = s16
+            if not s16 and res is None and act == ACT_RELU and i < n and isinstance(mods[i], (ResnetBlock, CINResnetBlock)) \
+                    and isinstance(norm, (InstanceNorm, CondInstanceNorm)):
+                emit = mods[i].s16_ok(x)
             if isinstance(norm, CondInstanceNorm):
                 if fuse_res:
                     raise NotImplementedError("residual after CondInstanceNorm")
-                x = norm.forward_act(x, z, act, stats.part if stats is not None else None)
+                if s16 and act != ACT_RELU:
+                    raise NotImplementedError("pre-split trunk: CondInstanceNorm without ReLU")
+                x = norm.forward_act(x, z, act, stats.part if stats is not None else None, emit, s16)
             elif isinstance(norm, InstanceNorm):
                 # skip_routed: `res` is the identity output of the block's first convolution, i.e. its gradient goes to that
                 # convolution's data-gradient epilogue and nowhere else -> it may stay un-materialised (ops.NormAct lazy_dres)
+                if s16 and not (fuse_res and skip_routed):
+                    raise NotImplementedError("pre-split trunk: InstanceNorm that is not the block output")
                 x = norm.forward_act(x, ACT_RELU if fuse_res else act, res if fuse_res else None,
-                                     skip_grad if (fuse_res and skip_routed) else None, stats.part if stats is not None else None)
+                                     skip_grad if (fuse_res and skip_routed) else None, stats.part if stats is not None else None,
+                                     emit, s16)
             else:
                 if fuse_res:
                     raise NotImplementedError("residual after BatchNorm")
                 x = norm.forward_act(x, act)
+    if res is None and ops.is_s16(x):   # the list ended with a block
+        x = ops.S16Decode.apply(x)
     return x, C
+
+
+def _block_s16_ok(block, x):
+    """can this residual block run on pre-split tensors (ops.S16Plan) for an input of x's shape?  Reflection-padded
+    3x3 stride-1 C -> C convolutions, no dropout, and a library that takes pre-split operands in all three passes."""
+    key = (tuple(x.shape), ops.CONFIG_EPOCH, ops.S16_ENABLED)
+    cache = block.__dict__.setdefault("_acg_s16_ok", {})
+    if key not in cache:
+        mods = list(block.conv_block._modules.values())
+        convs = [m.module1 if isinstance(m, MergeModule) else m for m in mods if isinstance(m, (Conv2d, MergeModule))]
+        pads = [m for m in mods if isinstance(m, nn.ReflectionPad2d)]
+        N, H, W, C = x.shape
+        ok = (len(convs) == 2 and len(pads) == 2 and all(p.padding[0] == 1 for p in pads)
+              and not any(isinstance(m, nn.Dropout) for m in mods)
+              and all(c.kernel_size[0] == 3 and c.stride[0] == 1 and c.padding[0] == 0 and c.in_channels == C
+                      and c.out_channels == C for c in convs)
+              and ops.conv_s16_supported(N, H, W, C, 3, 1, PAD_REFLECT))
+        cache[key] = bool(ok)
+    return cache[key]
 
 
 # padding of the residual blocks' 3x3 convolutions: 'reflect' = a ReflectionPad2d(1) module in front of an unpadded conv,
@@ -402,6 +461,9 @@ class CINResnetBlock(TwoInputModule):
                   [conv(), InstanceNorm2d(x_dim, affine=True)]]
         return TwoInputSequential(*[m for st in stages for m in _pad_front(padding_type) + st])
 
+    def s16_ok(self, x):
+        return _block_s16_ok(self, x)
+
     def forward_nhwc(self, x, z):
         y, _ = run_sequence(list(self.conv_block._modules.values()), x, None, z, res=x)
         return y
@@ -426,6 +488,9 @@ class ResnetBlock(nn.Module):
         stages = [[conv(), nn.ReLU(True)] + _dropout(use_dropout),
                   [conv(), norm_layer(dim)]]
         return Sequential(*[m for st in stages for m in _pad_front(padding_type) + st])
+
+    def s16_ok(self, x):
+        return _block_s16_ok(self, x)
 
     def forward_nhwc(self, x, z=None):
         y, _ = run_sequence(list(self.conv_block._modules.values()), x, None, None, res=x)

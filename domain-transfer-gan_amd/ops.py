@@ -46,6 +46,12 @@ def _check(*ts):
 _WS = {}
 
 
+def _debug_switch(name):
+    """A/B switches (ACGAN_NO_*: run the un-fused / previous path, for interleaved timings on one GPU box and for the
+    bit-identity tests of the fusions).  Development aids: honoured only when ACGAN_DEBUG_SWITCHES is set."""
+    return os.environ.get("ACGAN_DEBUG_SWITCHES") is not None and os.environ.get(name) is not None
+
+
 def workspace(nbytes, slot=0):
     """Stream-ordered scratch (one buffer per device/slot, grown on demand)."""
     dev = torch.cuda.current_device()
@@ -186,11 +192,30 @@ class PackedConv(object):
 
 
 class ConvTimer(object):
-    """bench.py hook: HIP events (on the launch stream) around the forward launches of ONE conv shape,
-    so the roofline numerator/denominator come from the live timed region."""
+    """bench.py hook: HIP events (on the launch stream) around the launches of ONE pass ("fwd", "dgrad" or "wgrad") of ONE
+    conv shape, so the roofline numerator/denominator come from the live timed region."""
 
-    def __init__(self, match):
-        self.match, self.events, self.kernel = match, [], None
+    def __init__(self, match, kind="fwd"):
+        self.match, self.kind, self.events, self.kernel = match, kind, [], None
+
+    class _Span(object):
+        def __init__(self, timers):
+            self.timers = timers
+            if timers:
+                self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                self.e0.record()
+
+        def done(self):
+            if self.timers:
+                self.e1.record()
+                for t in self.timers:
+                    t.events.append((self.e0, self.e1))
+                    t.kernel = _lib.query("acg_last_kernel").decode()   # what the dispatcher actually launched
+
+    @staticmethod
+    def span(kind, d):
+        """-> object whose done() closes the bracket (a no-op unless a timer of this kind matches descriptor d)"""
+        return ConvTimer._Span([t for t in CONV_TIMERS if t.kind == kind and t.match(d)])
 
     def ms(self):
         return [a.elapsed_time(b) for a, b in self.events]
@@ -207,7 +232,7 @@ def conv_desc(N, Hi, Wi, Ci, Co, K, stride, pad, pad_mode, Cir=0, Cor=0):
 
 
 STATS_ROWS = 128
-CONV_STATS_ENABLED = os.environ.get("ACGAN_NO_CONV_STATS") is None  # A/B switch
+CONV_STATS_ENABLED = not _debug_switch("ACGAN_NO_CONV_STATS")  # A/B switch
 
 
 class ConvStats(object):
@@ -247,7 +272,7 @@ class SkipGrad(object):
 # (accumulate=1) instead of returning a fresh tensor for autograd's AccumulateGrad to add with one more kernel per parameter
 # (564 five-microsecond launches per training step).  The Function then returns None for that parameter, so the
 # post-accumulate hooks of the data-parallel exchange (dist.hook_params) are fired by hand.
-DIRECT_GRAD = os.environ.get("ACGAN_NO_DIRECT_GRAD") is None   # A/B switch
+DIRECT_GRAD = not _debug_switch("ACGAN_NO_DIRECT_GRAD")   # A/B switch
 
 
 def _direct_grad(*params):
@@ -274,7 +299,7 @@ def _grads_done(*params):
                 h(p)
 
 
-LAZY_DRES = os.environ.get("ACGAN_NO_LAZY_DRES") is None   # A/B switch (SkipGrad)
+LAZY_DRES = not _debug_switch("ACGAN_NO_LAZY_DRES")   # A/B switch (SkipGrad)
 
 
 class ReluLink(object):
@@ -288,7 +313,69 @@ class ReluLink(object):
         self.done = False
 
 
-RELU_LINK = os.environ.get("ACGAN_NO_RELU_LINK") is None   # A/B switch
+RELU_LINK = not _debug_switch("ACGAN_NO_RELU_LINK")   # A/B switch
+
+
+# Pre-split ("S16") activation storage of the residual trunk (include/acgan_hip.h, acg_s16_encode): an S16 tensor is carried
+# as an fp32-typed torch tensor of the same shape whose BYTES are (bf16 hi, bf16 lo) groups, tagged `_acg_s16`; only the
+# Functions below read or write it, and every one of them knows from its forward-time plan which of its tensors are S16
+# (autograd only ever hands such a gradient from the one Function that wrote it to the one that reads it).
+S16_ENABLED = not _debug_switch("ACGAN_NO_S16")   # A/B switch
+
+
+def is_s16(t):
+    return getattr(t, "_acg_s16", False)
+
+
+def tag_s16(t):
+    t._acg_s16 = True
+    return t
+
+
+class S16Plan(object):
+    """which tensors of one convolution are pre-split: x (input), y (output; then dy arrives pre-split and already masked
+    by the consumer's data gradient), gy (dy arrives pre-split from the norm behind the convolution), dx (what the data
+    gradient writes: pre-split with the ReLU mask of x, or fp32)"""
+
+    def __init__(self, x=False, y=False, gy=False, dx=False):
+        self.x, self.y, self.gy, self.dx = x, y, gy, dx
+
+
+def conv_s16_supported(N, Hi, Wi, C, K, pad, pad_mode):
+    """can the stride-1 C -> C convolution take pre-split operands in forward, data gradient and weight gradient?"""
+    if not S16_ENABLED or _PRECISION != "bf16x3" or not (LAZY_DRES and RELU_LINK and NORM_SIGN_MASK and CONV_STATS_ENABLED):
+        return False
+    d = conv_desc(N, Hi, Wi, C, C, K, 1, pad, pad_mode, C, C)
+    return bool(_lib.query("acg_conv2d_s16_supported", ctypes.byref(d)))
+
+
+class S16Decode(torch.autograd.Function):
+    """pre-split -> fp32 where the residual trunk hands over to a layer that reads fp32 (its gradient is fp32 already)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.empty_like(x)
+        _lib.call("acg_s16_decode", _ptr(x), _ptr(y), x.numel(), _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class S16Encode(torch.autograd.Function):
+    """fp32 -> pre-split (a trunk entered from a tensor that was not written pre-split)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _lib.call("acg_s16_encode", _ptr(x), _ptr(y), x.numel(), _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
 
 
 class Conv2dFn(torch.autograd.Function):
@@ -301,7 +388,7 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, packed, stride, pad, pad_mode, act, want_stats=None, want_identity=False,
-                link_out=None, link_in=None, skip_grad=None):
+                link_out=None, link_in=None, skip_grad=None, s16=None):
         x = x.contiguous()
         _check(x)
         N, Hi, Wi, Ci = x.shape
@@ -311,11 +398,15 @@ class Conv2dFn(torch.autograd.Function):
         if d.Ho <= 0 or d.Wo <= 0:
             raise _lib.AcgError("conv: input %dx%d too small for kernel %d" % (Hi, Wi, packed.K))
         y = torch.empty((N, d.Ho, d.Wo, packed.Co), device=x.device, dtype=torch.float32)
-        timed = [t for t in CONV_TIMERS if t.match(d)]
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        if want_stats is not None and CONV_STATS_ENABLED and act == ACT_NONE and \
+        span = ConvTimer.span("fwd", d)
+        if s16 is not None and s16.x:   # pre-split input (and, for a conv + ReLU inside the trunk, output)
+            part = None
+            if want_stats is not None and act == ACT_NONE and not s16.y:
+                part = torch.empty((N, (d.Ho * d.Wo) // STATS_ROWS, 2, packed.Co), device=x.device, dtype=torch.float32)
+                want_stats.part = part
+            _lib.call("acg_conv2d_fwd_s16", ctypes.byref(d), _ptr(x), _ptr(packed.wf), _ptr(packed.bias if bias is not None else None),
+                      _ptr(y), act, _ptr(part), 1 if s16.y else 0, _stream())
+        elif want_stats is not None and CONV_STATS_ENABLED and act == ACT_NONE and \
                 _lib.query("acg_conv2d_fwd_stats_supported", ctypes.byref(d)):
             part = torch.empty((N, (d.Ho * d.Wo) // STATS_ROWS, 2, packed.Co), device=x.device, dtype=torch.float32)
             _lib.call("acg_conv2d_fwd_stats", ctypes.byref(d), _ptr(x), _ptr(packed.wf),
@@ -324,16 +415,13 @@ class Conv2dFn(torch.autograd.Function):
         else:
             _lib.call("acg_conv2d_fwd", ctypes.byref(d), _ptr(x), _ptr(packed.wf), _ptr(packed.bias if bias is not None else None),
                       _ptr(y), act, _stream())
-        if timed:
-            e1.record()
-            for t in timed:
-                t.events.append((e0, e1))
-                t.kernel = _lib.query("acg_last_kernel").decode()   # what the dispatcher actually launched
+        span.done()
         ctx.d, ctx.packed, ctx.act, ctx.has_bias = d, packed, act, bias is not None
         ctx.wparam, ctx.bparam = weight, bias
         ctx.link_out, ctx.link_in = (link_out if act == ACT_RELU else None), link_in
         ctx.skip_grad = skip_grad
-        ctx.save_for_backward(x, y if act != ACT_NONE else None)
+        ctx.s16 = s16 if (s16 is not None and s16.x) else None
+        ctx.save_for_backward(x, y if (act != ACT_NONE and ctx.s16 is None) else None)
         if want_identity:
             return y, x.view_as(x)
         return y
@@ -344,6 +432,8 @@ class Conv2dFn(torch.autograd.Function):
         d, pk = ctx.d, ctx.packed
         dy = dy.contiguous()
         st = _stream()
+        if ctx.s16 is not None:
+            return Conv2dFn._backward_s16(ctx, x, dy, dskip)
         if ctx.link_out is not None and ctx.link_out.done:
             ctx.link_out.done = False   # the consumer's data-gradient epilogue already applied this ReLU's mask
             g = dy
@@ -358,6 +448,7 @@ class Conv2dFn(torch.autograd.Function):
             nb = _lib.query("acg_conv2d_bwd_data_workspace_bytes", ctypes.byref(d))
             ws = workspace(nb) if nb else None
             smask = None
+            span = ConvTimer.span("dgrad", d)
             if dskip is not None:
                 dskip = dskip.contiguous()
                 if ctx.skip_grad is not None:   # the skip gradient is dskip * sign-bitmask (NormAct lazy_dres)
@@ -379,6 +470,7 @@ class Conv2dFn(torch.autograd.Function):
                         _lib.call("acg_mask_apply", _ptr(dskip), _ptr(smask), _ptr(m), dskip.numel(), st)
                         dskip = m
                     dx = dx + dskip
+            span.done()
         if ctx.needs_input_grad[1]:
             direct = _direct_grad(ctx.wparam, ctx.bparam)
             if direct is not None:
@@ -388,12 +480,69 @@ class Conv2dFn(torch.autograd.Function):
                 db = torch.empty(pk.Or, device=x.device, dtype=torch.float32) if ctx.has_bias else None
             nb = _lib.query("acg_conv2d_bwd_weight_workspace_bytes", ctypes.byref(d))
             ws = workspace(nb)
+            span = ConvTimer.span("wgrad", d)
             _lib.call("acg_conv2d_bwd_weight", ctypes.byref(d), _ptr(x), _ptr(g), _ptr(dw), _ptr(db), pk.Or, pk.Ir, _ptr(ws),
                       nb, 1 if direct is not None else 0, st)
+            span.done()
             if direct is not None:
                 dw = db = None
                 _grads_done(ctx.wparam, ctx.bparam)
-        return dx, dw, db, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
+
+
+def _conv_backward_s16(ctx, x, dy, dskip):
+    """Conv2dFn.backward on pre-split operands: x and dy are S16 (dy comes from the norm behind this convolution, or — for
+    a conv + ReLU — from the next convolution's data gradient, which already applied the ReLU mask)."""
+    d, pk, p = ctx.d, ctx.packed, ctx.s16
+    st = _stream()
+    if p.y:
+        if ctx.link_out is None or not ctx.link_out.done:
+            raise _lib.AcgError("pre-split trunk: the gradient of a conv + ReLU output must come from the next convolution's "
+                                "fused data gradient")
+        ctx.link_out.done = False
+    dx = None
+    if ctx.needs_input_grad[0]:
+        dx = torch.empty_like(x)
+        nb = _lib.query("acg_conv2d_bwd_data_workspace_bytes", ctypes.byref(d))
+        ws = workspace(nb) if nb else None
+        span = ConvTimer.span("dgrad", d)
+        if p.dx:     # the gradient w.r.t. the pre-activation of the conv + ReLU in front, pre-split for its own backward
+            if dskip is not None or ctx.link_in is None:
+                raise _lib.AcgError("pre-split trunk: unexpected skip gradient / missing ReLU link")
+            _lib.call("acg_conv2d_bwd_data_s16", ctypes.byref(d), _ptr(dy), _ptr(pk.wb), _ptr(dx), _ptr(ws), nb, None, None,
+                      _ptr(x), 1, st)
+            ctx.link_in.done = True
+        else:
+            smask = None
+            if dskip is not None:
+                dskip = dskip.contiguous()
+                if ctx.skip_grad is not None:
+                    dskip, smask = ctx.skip_grad.take(dskip)
+            _lib.call("acg_conv2d_bwd_data_s16", ctypes.byref(d), _ptr(dy), _ptr(pk.wb), _ptr(dx), _ptr(ws), nb, _ptr(dskip),
+                      _ptr(smask), None, 0, st)
+        span.done()
+    if ctx.needs_input_grad[1]:
+        direct = _direct_grad(ctx.wparam, ctx.bparam)
+        if direct is not None:
+            dw, db = direct
+        else:
+            dw = torch.empty((pk.Or, pk.Ir, pk.K, pk.K), device=x.device, dtype=torch.float32)
+            db = torch.empty(pk.Or, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+        nb = _lib.query("acg_conv2d_bwd_weight_workspace_bytes", ctypes.byref(d))
+        ws = workspace(nb)
+        span = ConvTimer.span("wgrad", d)
+        _lib.call("acg_conv2d_bwd_weight_s16", ctypes.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), pk.Or, pk.Ir, _ptr(ws),
+                  nb, 1 if direct is not None else 0, st)
+        span.done()
+        if direct is not None:
+            dw = db = None
+            _grads_done(ctx.wparam, ctx.bparam)
+    else:
+        dw = db = None
+    return (dx, dw, db) + (None,) * 11
+
+
+Conv2dFn._backward_s16 = staticmethod(_conv_backward_s16)
 
 
 class ConvTranspose2dFn(torch.autograd.Function):
@@ -457,7 +606,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------------
 # normalisation (+ fused activation / residual)
 # ----------------------------------------------------------------------------------------------
-NORM_SIGN_MASK = os.environ.get("ACGAN_NO_NORM_MASK") is None   # A/B switch
+NORM_SIGN_MASK = not _debug_switch("ACGAN_NO_NORM_MASK")   # A/B switch
 
 
 class NormAct(torch.autograd.Function):
@@ -471,7 +620,7 @@ class NormAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, res, kind, act, eps, gamma_p, beta_p, run_mean, run_var, momentum, lazy_dres=None,
-                stats=None):
+                stats=None, s16_out=False, s16_dx=False, s16_res=False):
         """lazy_dres: a SkipGrad slot (the caller guarantees that the gradient w.r.t. `res` goes only to the Conv2dFn holding
         the same slot) or None.  stats: per-tile (mean, M2) partials a convolution epilogue produced (ConvStats.part)."""
         x = x.contiguous()
@@ -515,8 +664,13 @@ class NormAct(torch.autograd.Function):
         mask = None
         if need_y and NORM_SIGN_MASK and act in (ACT_RELU, ACT_LRELU) and (P * (C // 4)) % 8 == 0 and any(ctx.needs_input_grad):
             mask = torch.empty((G * P * C + 31) // 32, device=x.device, dtype=torch.int32)
+        # pre-split (S16) output for the convolution behind this norm; a residual that arrives tagged S16 is read that way
+        fmt = (2 if s16_out else 0) | (1 if (res is not None and s16_res) else 0)
+        if fmt == 1:
+            raise _lib.AcgError("norm: a pre-split residual needs a pre-split output")
         _lib.call("acg_norm_apply", _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gp), _ptr(bp), gstride, _ptr(res), _ptr(y), _ptr(mask),
-                  G, P, C, act, st)
+                  G, P, C, act, fmt, st)
+        ctx.s16_dx = bool(s16_dx)
         ctx.cfg = (kind, act, G, P, C, unbiased, gstride, res is not None, gamma.shape)
         ctx.gparam, ctx.bparam = (gamma, beta) if kind != "cin" else (None, None)
         ctx.lazy_dres = lazy_dres if (lazy_dres is not None and LAZY_DRES and mask is not None) else None
@@ -530,6 +684,8 @@ class NormAct(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if (has_res and ctx.lazy_dres is None) else None
+        if ctx.s16_dx and dres is not None:
+            raise _lib.AcgError("norm: a pre-split dx needs the un-materialised skip gradient")
         direct = _direct_grad(ctx.gparam, ctx.bparam) if (kind != "cin" and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]) else None
         if direct is not None:      # shared affine parameters: add into their .grad (first gshape[0] = real channels)
             dgamma, dbeta = direct
@@ -541,7 +697,7 @@ class NormAct(torch.autograd.Function):
         ws = workspace(nb)
         _lib.call("acg_norm_bwd", _ptr(dy), _ptr(y), _ptr(mask), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gp), _ptr(bp), gstride, _ptr(dx),
                   _ptr(dres), _ptr(dgamma), _ptr(dbeta), 0 if gstride else gshape[0], 1 if direct is not None else 0, G, P, C,
-                  act, unbiased, _ptr(ws), nb, _stream())
+                  act, unbiased, 1 if ctx.s16_dx else 0, _ptr(ws), nb, _stream())
         if kind == "cin":
             dg, db = dgamma.view(G, C), dbeta.view(G, C)
         elif direct is not None:
@@ -554,7 +710,7 @@ class NormAct(torch.autograd.Function):
         elif ctx.lazy_dres is not None:
             ctx.lazy_dres.mask, ctx.lazy_dres.dy = mask, dy
             dres = dy
-        return dx, dg, db, dres, None, None, None, None, None, None, None, None, None, None
+        return dx, dg, db, dres, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 class SyncBatchNormAct(torch.autograd.Function):
@@ -598,7 +754,7 @@ class SyncBatchNormAct(torch.autograd.Function):
         gmean, grstd = gmean.contiguous(), grstd.contiguous()
         y = torch.empty_like(x)
         _lib.call("acg_norm_apply", _ptr(x), _ptr(gmean), _ptr(grstd), _ptr(gamma_p), _ptr(beta_p), 0, None, _ptr(y), None, 1, P, C,
-                  act, st)
+                  act, 0, st)
         ctx.cfg = (act, P, int(Ptot), C, gamma.shape)
         ctx.save_for_backward(x, y if act != ACT_NONE else None, gmean, grstd, gamma_p)
         return y
@@ -662,7 +818,7 @@ class LinearFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
-LATENT_MLP = os.environ.get("ACGAN_NO_LATENT_MLP") is None   # A/B switch
+LATENT_MLP = not _debug_switch("ACGAN_NO_LATENT_MLP")   # A/B switch
 
 
 def latent_mlp_supported(N, I, H):

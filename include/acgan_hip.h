@@ -180,8 +180,11 @@ int acg_bn_eval_stats(const float *run_mean, const float *run_var, int C, int Cp
                       void *stream);
 /* y = act((x-mean)*rstd*gamma + beta [+ res]); gamma/beta indexed [g*gstride + c] (gstride 0 or C) */
 int acg_norm_apply(const float *x, const float *mean, const float *rstd, const float *gamma, const float *beta,
-                   int gstride, const float *res, float *y, unsigned *sign_mask, int G, size_t P, int C, int act,
+                   int gstride, const float *res, float *y, unsigned *sign_mask, int G, size_t P, int C, int act, int fmt,
                    void *stream);
+/* fmt: 0 = fp32 tensors; bit 1 set: y is written pre-split (S16, see acg_s16_encode), bit 0 set: res is read pre-split
+ * (fmt 2 or 3; ReLU, C % 8 == 0): the producer of a residual-block activation writes the operand form of the next
+ * convolution once, instead of every convolution loader splitting it again. */
 /* sign_mask (may be NULL; needs res, ReLU/LeakyReLU, P*C/4 % 8 == 0): ceil(G*P*C/32) words, bit e%32 of word e/32 =
  * (y[e] > 0).  acg_norm_bwd takes it in place of y: the backward of ReLU(x + IN(conv(..))) (modules.py:185-188, 232-235)
  * needs only the sign of y, and reads 1/32 of a tensor instead of the tensor, twice. */
@@ -195,8 +198,9 @@ int acg_norm_apply(const float *x, const float *mean, const float *rstd, const f
 int acg_norm_bwd(const float *dy, const float *y, const unsigned *sign_mask, const float *x, const float *mean,
                  const float *rstd,
                  const float *gamma, const float *beta, int gstride, float *dx, float *dres, float *dgamma, float *dbeta,
-                 int nparam, int accumulate, int G, size_t P, int C, int act, int unbiased, void *workspace, size_t ws_bytes,
-                 void *stream);
+                 int nparam, int accumulate, int G, size_t P, int C, int act, int unbiased, int dx_s16, void *workspace,
+                 size_t ws_bytes, void *stream);
+/* dx_s16 != 0: dx is written pre-split (S16) for the convolution gradients that consume it (ReLU, no dres, C % 8 == 0) */
 
 /* the two halves of acg_norm_bwd, for SyncBN: local sums[(g*2+{0,1})*C+c] = (sum gy, sum gy*xhat), then — after the
  * caller has all-reduced them — the apply pass with the GLOBAL pixel count Ptot. */

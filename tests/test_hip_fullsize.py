@@ -225,6 +225,21 @@ def test_config5_step_512x512x1():
     _agree(rx3[0], r32[0])
 
 
+def test_config3_full_batch_step():
+    """configs[2] exactly as named — 256x256x3, 9 resblocks, E_B + D_z_B, batch 32 — the step the bench times: the bf16x3 step
+    (pre-split trunk storage, every fused path) is deterministic bit for bit and agrees with the exact-fp32 arithmetic, whose
+    kernels differ all the way down, at the north-star bar on all 13 losses and the four image tensors."""
+    full = dict(FULL)
+    rx3 = _run_cfg(full, 256, 32, "bf16x3", seed=0, in_seed=90)
+    rx3b = _run_cfg(full, 256, 32, "bf16x3", seed=0, in_seed=90)
+    assert rx3[0][0] == rx3b[0][0] and rx3[0][2] == rx3b[0][2]
+    assert np.array_equal(rx3[0][1]["rec_B"], rx3b[0][1]["rec_B"])
+    del rx3b
+    assert rx3[0][1]["fake_B"].shape == (32, 3, 256, 256)
+    r32 = _run_cfg(full, 256, 32, "f32", seed=0, in_seed=90)
+    _agree(rx3[0], r32[0])
+
+
 def test_config5_full_per_gpu_batch_runs():
     """the full per-GPU batch of configs[4] (16 x 512x512x1): one bf16x3 step, finite, deterministic operand sizes"""
     (losses, visuals, gnorms), = _run_cfg(CFG5, 512, 16, "bf16x3")

@@ -15,7 +15,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from golden_util import load, names  # noqa: E402
+from golden_util import load, names, digest  # noqa: E402
 
 
 def make_opt(**kw):
@@ -63,11 +63,55 @@ REC_TOL = {("f32", "init"): (2e-4, 2e-2), ("f32", "rich"): (3e-4, 4e-2),
            ("bf16x3", "init"): (1e-3, 4e-2), ("bf16x3", "rich"): (3e-3, 6e-2)}
 
 
+# What the fixtures hold beyond losses and images (tools/make_goldens.py:292-304, taken from the reference after
+# `optimizer.step()`, model.py:447-452, 510-515): per-tensor digests of .grad and of the applied update (post - pre), and
+# the BatchNorm buffers after the last step.  (grad, update) tolerances on the abs-sum / L2 digests, step 0 only — later
+# steps are chaotic per tensor (tests/test_oracle_golden.py).  bf16x3 gradients are norm-wise quantities: a ReLU mask that
+# flips under the 2^-17 operand rounding changes single entries discretely (tools/conditioning_probe.py).
+# Measured worst over the five fixtures: f32 inside (3e-3, 5e-3); bf16x3 1.2e-2 on one CondInstanceNorm shift-conv weight of
+# the full-width config-1 fixture (a sum over ReLU-gated per-sample shifts), all other tensors < 1e-2.
+DIGEST_TOL = {"f32": (3e-3, 5e-3), "bf16x3": (2e-2, 2e-2)}
+# Networks whose .grad after the step is comparable: the reference lets loss_G.backward() pile the (unused) G-phase
+# gradients on top of the discriminators' D-phase .grad (model.py:509, no zero_grad for them); the HIP path skips those
+# weight gradients, so the discriminators are pinned by their UPDATE digests (which only see the D-phase gradient).
+GRAD_NETS = ("netG_A_B", "netG_B_A", "netE_B")
+
+
+def _check_digests(m, arr, pre, prec):
+    gt, ut = DIGEST_TOL[prec]
+    bad, seen = [], 0
+    for nname, net in m._net_dict().items():
+        params = dict(net.named_parameters())
+        grads = {k: (p.grad.detach().cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32))
+                 for k, p in params.items()}
+        gmax = max([float(np.max(np.abs(g))) for g in grads.values()] + [0.0])
+        for k, p in params.items():
+            key = "s0/grad/%s/%s" % (nname, k)
+            assert key in arr, key
+            g = grads[k]
+            if nname in GRAD_NETS:
+                dg, rg = digest(g), arr[key]
+                floor = 3e-5 * gmax * np.array([g.size, np.sqrt(g.size)])    # summation noise on analytically-zero gradients
+                if not np.all(np.abs(dg[1:3] - rg[1:3]) <= gt * np.abs(rg[1:3]) + floor):
+                    bad.append(("grad", nname, k, dg[1:3], rg[1:3]))
+                seen += 1
+            d = digest(p.detach().cpu().numpy().astype(np.float64) - pre[nname][k].astype(np.float64))
+            r = arr["s0/upd/%s/%s" % (nname, k)]
+            # Adam's g / (|g| + eps) amplifies rounding noise on ~zero gradients to O(lr): well-conditioned tensors only (for
+            # the discriminators the criterion uses this side's D-phase gradient, which is what their update was made from)
+            if np.min(np.abs(g)) > 1e-5 * gmax and np.min(np.abs(g)) > 1e-6:
+                if not (abs(d[1] - r[1]) <= ut * r[1] + 1e-12 and abs(d[2] - r[2]) <= ut * r[2] + 1e-12):
+                    bad.append(("upd", nname, k, d[1:3], r[1:3]))
+                seen += 1
+    assert seen > 50 and not bad, (len(bad), bad[:6])
+
+
 def _check_steps(name, prec):
     from hip_util import t, n, rel
     from dtgan_amd import model as M
     arr, meta = load(name)
     m = build_model(meta)
+    pre = {nn_: {k: p.detach().cpu().numpy().copy() for k, p in net.named_parameters()} for nn_, net in m._net_dict().items()}
     orig_reparam = M.gauss_reparametrize
     for st in range(meta["steps"]):
         A, B, z = (t(arr["s%d/%s" % (st, k)]) for k in ("real_A", "real_B", "prior_z_B"))
@@ -96,6 +140,16 @@ def _check_steps(name, prec):
             assert rel(n(visuals[k]), arr["s%d/%s" % (st, k)]) < rt, (k, st, rel(n(visuals[k]), arr["s%d/%s" % (st, k)]))
         for k in ("real_A", "real_B"):
             assert np.array_equal(n(visuals[k]), arr["s%d/%s" % (st, k)])
+        if st == 0:
+            _check_digests(m, arr, pre, prec)
+    if meta["aug"]:   # BatchNorm running buffers after the last step (networks.py:407-415, 450-462)
+        for nname in ("netE_B", "netD_z_B"):
+            for k, b in m._net_dict()[nname].named_buffers():
+                ref = arr["final/buf/%s/%s" % (nname, k)]
+                if k.endswith("num_batches_tracked"):
+                    assert int(b) == int(ref), (nname, k)
+                else:
+                    assert rel(n(b), ref) < (2e-3 if prec == "f32" else 5e-3), (nname, k, rel(n(b), ref))
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16x3"])
@@ -195,12 +249,52 @@ def test_step_as_one_captured_graph_matches_the_eager_step(aug):
         lr_, vr, gn_r = ref.train_instance(a, b, z)
         lg, vg, gn_g = gr.train_instance(a, b, z)
         assert list(lr_.keys()) == list(lg.keys()) and list(gn_r.keys()) == list(gn_g.keys())
+        # the first three steps run the same kernels on the same numbers (two eager warm-up calls, then the capture replayed
+        # with the device-side bias correction, which differs from the host's by an ulp of pow()): equal to rounding.
+        # Later steps inherit Adam's amplification of that ulp on ~zero gradients (cf. STEP_TOL's second row).
+        lt, gt, vt = (1e-5, 1e-4, 1e-5) if step < 3 else (2e-3, 2e-2, 2e-2)
         for k in lr_:
-            assert abs(lr_[k] - lg[k]) <= 2e-3 * max(1.0, abs(lr_[k])), (step, k, lr_[k], lg[k])
+            assert abs(lr_[k] - lg[k]) <= lt * max(1.0, abs(lr_[k])), (step, k, lr_[k], lg[k])
         for k in gn_r:
-            assert abs(gn_r[k] - gn_g[k]) <= 2e-2 * max(1e-3, abs(gn_r[k])), (step, k, gn_r[k], gn_g[k])
-        assert float((vr["fake_B"] - vg["fake_B"]).abs().max()) < 2e-2
+            assert abs(gn_r[k] - gn_g[k]) <= gt * max(1e-3, abs(gn_r[k])), (step, k, gn_r[k], gn_g[k])
+        assert float((vr["fake_B"] - vg["fake_B"]).abs().max()) < vt
         assert vg["real_A"].shape == a.shape and torch.equal(vg["real_A"], a)
     assert gr._step_graph.graph is not None
     for o_r, o_g in zip(ref._optimizers().values(), gr._optimizers().values()):
         assert o_r.t == o_g.t == 7
+
+
+def test_step_graph_owns_its_scratch():
+    """The captured kernels keep the POINTERS of the scratch buffers ops.workspace() handed out during the capture.  An eager
+    op that needs more scratch afterwards (a larger evaluation batch backpropagating through G_A_B, train.py's eval_ubo_B)
+    replaces the eager buffer; the graph must not write into the block that went back to the allocator."""
+    from dtgan_amd import ops
+    meta = dict(opt=dict(input_nc=1, output_nc=1, n_blocks=2), aug=True, seed=5, flavour="init")
+    gr = build_model(meta)
+    gr.enable_step_graph()
+    g = torch.Generator(device="cuda").manual_seed(4)
+
+    def batch(nb):
+        return (torch.randn(nb, 1, 64, 64, device="cuda", generator=g).clamp_(-1, 1),
+                torch.randn(nb, 1, 64, 64, device="cuda", generator=g).clamp_(-1, 1),
+                torch.randn(nb, 16, 1, 1, device="cuda", generator=g))
+    for _ in range(4):                                   # two eager warm-up calls, the capture, one replay
+        gr.train_instance(*batch(4))
+    sg = gr._step_graph
+    assert sg.graph is not None and sg.ws, "the capture keeps its own workspace table"
+    graph_ptrs = {k: v.data_ptr() for k, v in sg.ws.items()}
+    eager_before = {k: v.data_ptr() for k, v in ops._WS.items()}
+    assert not set(graph_ptrs.values()) & set(eager_before.values())
+    # an eager backward at three times the batch: grows / replaces the eager workspaces
+    a, b, z = batch(12)
+    zz = z.clone().requires_grad_(True)
+    gr.predict_B(a, zz).sum().backward()
+    torch.cuda.synchronize()
+    # whatever the allocator hands out now must survive further replays
+    canary = [torch.full((1 << 18,), 7.0, device="cuda") for _ in range(8)]
+    for _ in range(2):
+        losses, _, _ = gr.train_instance(*batch(4))
+        assert all(np.isfinite(v) for v in losses.values())
+    torch.cuda.synchronize()
+    assert all(bool((c == 7.0).all()) for c in canary)
+    assert {k: v.data_ptr() for k, v in sg.ws.items()} == graph_ptrs
