@@ -367,15 +367,15 @@ def test_backward_fusions_are_bit_identical_to_the_separate_passes(switch):
     assert np.abs(res[True][1]).max() > 0
 
 
-@pytest.mark.parametrize("N,nlatent,ndf,flat", [(4, 16, 64, False), (32, 16, 64, True), (96, 16, 64, True), (7, 8, 32, False),
+@pytest.mark.parametrize("N,nlatent,ndf,flat", [(4, 16, 64, False), (32, 16, 64, True), (64, 16, 64, True), (96, 16, 64, True), (7, 8, 32, False),
                                                 (1024, 16, 64, False)])
 def test_fused_latent_discriminator_equals_the_layer_chain(N, nlatent, ndf, flat):
     """DiscriminatorLatent (networks.py:396-433) as one launch per direction against the Linear / BatchNorm1d / LeakyReLU
     launches it replaces: output, input gradient, every parameter gradient (as autograd tensors and added into a FlatNet's
-    .grad), running statistics and num_batches_tracked.  fp32 sums in a different order: 2e-5.  N=1024 does not fit one
-    workgroup's LDS and must take the layer chain by itself."""
+    .grad), running statistics and num_batches_tracked.  fp32 sums in a different order: 2e-5.  N = 96 and 1024 are beyond
+    the fused kernel's 4096 activations per layer and must take the layer chain by themselves."""
     from hip_util import t, n, rel
-    from dtgan_amd import networks, ops
+    from dtgan_amd import networks, ops, _lib
     from dtgan_amd.model import FlatNet
     rs = np.random.RandomState(N)
     z, r = rs.normal(0, 1, (N, nlatent)).astype(np.float32), rs.normal(0, 1, (N, 1)).astype(np.float32)
@@ -408,7 +408,8 @@ def test_fused_latent_discriminator_equals_the_layer_chain(N, nlatent, ndf, flat
             res[fused] = [n(y), n(zt.grad), grads] + [n(v.float()) for k, v in net.state_dict().items() if "running" in k or "num_batches" in k]
         finally:
             ops.LATENT_MLP = True
-    fits = N * ndf * 12 + 8 * ndf <= 159 * 1024
+    fits = bool(_lib.query("acg_latent_mlp_supported", N, nlatent, ndf))   # 256 % H == 0 and N * H <= 4096
+    assert fits == (256 % ndf == 0 and N * ndf <= 4096)
     assert ("acg_latent_mlp_fwd" in used[True]) == fits and ("acg_latent_mlp_bwd" in used[True]) == fits
     assert "acg_latent_mlp_fwd" not in used[False]
     if fits:
