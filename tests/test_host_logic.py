@@ -209,3 +209,95 @@ def test_bench_launches_its_own_ranks():
                          env=env, capture_output=True, text=True, timeout=300)
     if not torch.cuda.is_available():
         assert bad.returncode != 0 and "rank exit codes" in bad.stderr
+
+
+def test_phase_exchange_async_handles_complete_out_of_order(monkeypatch):
+    """The shape of the RCCL path (dist._allreduce_avg_async with backend "nccl": async handles returned from hooks that
+    fire inside backward(), waited for later, per network) with a fake transport whose collectives complete OUT OF ORDER on
+    another thread: launches must still be issued in the armed order from inside backward(), wait(bucket) must wait for
+    that bucket's own handle only, and a gradient buffer must hold the reduced value exactly once after its wait."""
+    import threading
+    import time
+    from dtgan_amd import dist as D
+
+    class Work(object):
+        def __init__(self, buf, idx):
+            self.buf, self.idx, self.ev, self.waited = buf, idx, threading.Event(), False
+
+        def wait(self):
+            self.waited = True
+            assert self.ev.wait(timeout=30), "collective %d never completed" % self.idx
+            return True
+
+    launched, completed, works = [], [], []
+    lock = threading.Lock()
+
+    def network():           # completes the LATEST launched collective first, each after a delay
+        done = 0
+        while done < want[0]:
+            with lock:
+                pend = [w for w in works if not w.ev.is_set()]
+            if len(pend) < min(2, want[0] - done) and not stop.is_set():   # hold back until two are in flight
+                time.sleep(0.002)
+                continue
+            w = pend[-1]
+            time.sleep(0.01)
+            w.buf.mul_(3.0)   # the "all-reduce": a marker that must be applied exactly once
+            completed.append(w.idx)
+            w.ev.set()
+            done += 1
+
+    def fake_async(buf):
+        w = Work(buf, len(launched))
+        launched.append((len(launched), in_backward[0]))
+        with lock:
+            works.append(w)
+        return w
+
+    monkeypatch.setattr(D, "_allreduce_avg_async", fake_async)
+
+    class Bucket(object):
+        def __init__(self, shapes):
+            n = sum(int(torch.tensor(s).prod()) for s in shapes)
+            self.g = torch.zeros(n + D.SCALAR_TAIL)
+            self.params, o = [], 0
+            for s in shapes:
+                p = torch.nn.Parameter(torch.ones(s)); k = p.numel()
+                p.grad = self.g[o:o + k].view(s); o += k
+                self.params.append(p)
+            D.hook_params(self)
+
+    b1, b2, b3 = Bucket([(3,), (2, 2)]), Bucket([(5,)]), Bucket([(4,), (1,)])
+    ex = D.PhaseExchange("async-test")
+    in_backward, want, stop = [False], [3], threading.Event()
+    for step in range(3):
+        for b in (b1, b2, b3):
+            b.g.zero_()
+        del launched[:], completed[:], works[:]
+        stop.clear()
+        th = threading.Thread(target=network)
+        th.start()
+        x = torch.full((1,), 2.0)
+        loss = sum((p * x).sum() for b in (b1, b2, b3) for p in b.params)
+        ex.arm([b3, b2, b1])                       # completion order of the gradients: the reverse of the build order
+        in_backward[0] = True
+        try:
+            loss.backward()
+        finally:
+            in_backward[0] = False
+            ex.flush()
+        stop.set()
+        assert [i for i, _ in launched] == [0, 1, 2]
+        if step > 0:                               # from the second step on every bucket is launched by its hooks, inside backward()
+            assert all(inside for _, inside in launched), launched
+        # wait for the FIRST-armed bucket only: it completes last in this transport, the others may or may not be done
+        ex.wait(b3)
+        assert works[0].waited and works[0].ev.is_set()
+        assert torch.equal(b3.g[:5], torch.full((5,), 6.0))
+        assert not works[1].waited and not works[2].waited
+        ex.wait(b1); ex.wait(b2)
+        th.join(timeout=30)
+        assert completed[0] != 0, completed        # the transport really did complete out of order
+        assert torch.equal(b1.g[:7], torch.full((7,), 6.0)) and torch.equal(b2.g[:5], torch.full((5,), 6.0))
+        ex.wait(b1)                                # a second wait is a no-op (handle dropped): the marker is not re-applied
+        assert torch.equal(b1.g[:7], torch.full((7,), 6.0))
