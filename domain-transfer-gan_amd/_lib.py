@@ -75,6 +75,8 @@ SIGNATURES = {
     "acg_conv2d_bwd_weight_workspace_bytes": (c_size_t, [_D]),
     "acg_conv2d_bwd_weight": (c_int, [_D, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
     "acg_conv_transpose2d_fwd": (c_int, [_D, _P, _P, _P, _P, c_int, _P]),
+    "acg_conv_transpose2d_fwd_stats_supported": (c_int, [_D]),
+    "acg_conv_transpose2d_fwd_stats": (c_int, [_D, _P, _P, _P, _P, _P, _P]),
     "acg_conv_transpose2d_bwd_data": (c_int, [_D, _P, _P, _P, _P]),
     "acg_conv_transpose2d_bwd_weight": (c_int, [_D, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
     "acg_norm_workspace_bytes": (c_size_t, [c_int, c_size_t, c_int]),

@@ -684,7 +684,7 @@ static bool dgrad_frame_ok(const acg_conv_desc *d, const Geom &g)
 static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb, const float *bias, float *dst,
                        int act, void *ws, size_t ws_bytes, hipStream_t st, const float *addend = nullptr,
                        const float *relu_src = nullptr, const unsigned *addend_mask = nullptr, int in_s16 = 0, int out_s16 = 0,
-                       int relu_s16 = 0)
+                       int relu_s16 = 0, float *stats = nullptr)
 {
     Geom g; Taps t;
     g.Hin = d->Ho; g.Win = d->Wo; g.Cin = d->Co;
@@ -767,6 +767,10 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
                 }
             }
             ACG_REQUIRE(t.n > 0, "dgrad: empty phase (K=%d p=%d)", K, p);
+            if (stats != nullptr) { // each phase owns a quarter of every image's 128-pixel chunks
+                const int per = (int)(((long long)g.GH * g.GW) / 128);
+                g.stats = stats; g.stats_cpi = 4 * per; g.stats_chunk0 = (py * 2 + px) * per;
+            }
             int rc = thin_in_valu_dgrad(d) ? thin_out_launch(src, wb, bias, dst, g, t, st) : acg_igemm_launch(src, wb, bias, dst, g, t, st);
             if (rc != ACG_OK) return rc;
         }
@@ -800,8 +804,9 @@ extern "C" int acg_conv2d_fwd(const acg_conv_desc *d, const float *x, const floa
 // bf16x3 kernel implements it: 128-column tiles, Cin % 32 == 0, Ho*Wo % 128 == 0.  stats: [N][Ho*Wo/128][2][Co].
 extern "C" int acg_conv2d_fwd_stats_supported(const acg_conv_desc *d)
 {
-    if (d == nullptr || g_acg_precision != ACG_PREC_BF16X3 || g_acg_conv_impl != ACG_IMPL_MFMA) return 0;
-    if (thin_in(d) || thin_out(d) || d->Co < 128 || d->Ci % 32 != 0) return 0;
+    if (d == nullptr || g_acg_precision == ACG_PREC_F32 || g_acg_conv_impl != ACG_IMPL_MFMA) return 0;
+    if (thin_in(d) || thin_out(d) || d->Co < 32 || d->Ci % 16 != 0) return 0;    // MFMA tiles of the bf16 kernels only
+    if (d->Co < 128 && acg_debug_switch("ACG_NO_GENERIC_STATS")) return 0;   // A/B switch: statistics pass for the narrow layers
     return ((long long)d->Ho * d->Wo) % 128 == 0 ? 1 : 0;
 }
 
@@ -813,8 +818,20 @@ extern "C" int acg_conv2d_fwd_stats(const acg_conv_desc *d, const float *x, cons
     ACG_REQUIRE(acg_conv2d_fwd_stats_supported(d) && stats != nullptr, "acg_conv2d_fwd_stats: unsupported shape or mode");
     Geom g; Taps t;
     fwd_geom(d, &g, &t, ACG_ACT_NONE);
-    const Taps tp = acg_taps_pack(t);
-    return acg_igemm_x3_ws_launch(x, wf, bias, y, g, tp, g.w_elems, (hipStream_t)stream, stats);
+    g.stats = stats; g.stats_chunk0 = 0; g.stats_cpi = (int)(((long long)d->Ho * d->Wo) / 128);
+    return acg_igemm_launch(x, wf, bias, y, g, t, (hipStream_t)stream);
+}
+
+// ConvTranspose2d forward that also emits the per-tile statistics: its four sub-pixel phase launches each cover a quarter
+// of every image's pixels and write their own chunks.  stats: [N][Hi*Wi/128][2][Ci] (Hi x Wi = the transposed
+// convolution's OUTPUT, Ci its output channels).
+extern "C" int acg_conv_transpose2d_fwd_stats_supported(const acg_conv_desc *d)
+{
+    if (d == nullptr || g_acg_precision == ACG_PREC_F32 || g_acg_conv_impl != ACG_IMPL_MFMA) return 0;
+    if (d->stride != 2 || thin_in(d) || thin_out(d) || d->Ci < 32 || d->Co % 16 != 0 || d->Ci >= 128) return 0;
+    if (acg_debug_switch("ACG_NO_GENERIC_STATS")) return 0;
+    if (d->Hi % 2 || d->Wi % 2) return 0;
+    return ((long long)(d->Hi / 2) * (d->Wi / 2)) % 128 == 0 ? 1 : 0;
 }
 
 extern "C" size_t acg_conv2d_bwd_data_workspace_bytes(const acg_conv_desc *d)
@@ -1161,6 +1178,15 @@ extern "C" int acg_conv_transpose2d_fwd(const acg_conv_desc *d, const float *x, 
         return ACG_OK;
     }
     return dgrad_igemm(d, x, wb, bias, y, act, nullptr, 0, st);
+}
+
+extern "C" int acg_conv_transpose2d_fwd_stats(const acg_conv_desc *d, const float *x, const float *wb, const float *bias,
+                                             float *y, float *stats, void *stream)
+{
+    int rc = check_desc(d, "acg_conv_transpose2d_fwd_stats");
+    if (rc) return rc;
+    ACG_REQUIRE(acg_conv_transpose2d_fwd_stats_supported(d) && stats != nullptr, "acg_conv_transpose2d_fwd_stats: unsupported shape or mode");
+    return dgrad_igemm(d, x, wb, bias, y, ACG_ACT_NONE, nullptr, 0, (hipStream_t)stream, nullptr, nullptr, nullptr, 0, 0, 0, stats);
 }
 
 extern "C" int acg_conv_transpose2d_bwd_data(const acg_conv_desc *d, const float *dy, const float *wf, float *dx,

@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
     __shared__ __attribute__((aligned(16))) __bf16 As[NIMG * A_IMG];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[NIMG * B_IMG];
     __shared__ long long out_off[BM];
+    __shared__ float sred[WM * BN];   // cross-wave fold of the per-tile statistics (Geom.stats)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -198,6 +199,50 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
         }
     }
 
+    if (g.stats != nullptr) {
+        // Per-tile (mean, M2) of every output column over the tile's 128 pixels, for the InstanceNorm that follows (the norm's
+        // statistics pass then merges these partials instead of re-reading the tensor; full tiles inside one image and
+        // act == NONE are guaranteed by the launcher).  A column's 128 values sit in 16 x MB registers of the two lanes
+        // l, l + 32 of the WM waves that share the column range: register sums, one shuffle, one LDS fold; twice (mean,
+        // then squared deviations, like the two-pass formula of modules.py:83-97).
+        float mu[NB];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int co = n0 + wn * TN + j * 32 + (lane & 31);
+                const float bv = (bias != nullptr && co < g.Cout) ? bias[co] : 0.f;
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[i][j][r] + bv;
+                        s += pass == 0 ? v : (v - mu[j]) * (v - mu[j]);
+                    }
+                s += __shfl_xor(s, 32);
+                if (lane < 32) sred[wm * BN + wn * TN + j * 32 + lane] = s;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int cl = wn * TN + j * 32 + (lane & 31);
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) s += sred[w * BN + cl];
+                if (pass == 0) {
+                    mu[j] = s * (1.f / BM);
+                } else if (wm == 0 && lane < 32 && n0 + cl < g.Cout) {
+                    const long long tile = m0 / BM, tpi = (long long)GHW / BM;     // tile index, tiles per image in this launch
+                    const long long chunk = (tile / tpi) * g.stats_cpi + g.stats_chunk0 + tile % tpi;
+                    float *o = g.stats + chunk * 2 * g.Cout + n0 + cl;
+                    o[0] = mu[j];
+                    o[g.Cout] = s;
+                }
+            }
+            __syncthreads();
+        }
+    }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int co = n0 + wn * TN + j * 32 + (lane & 31);
@@ -255,9 +300,18 @@ int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, fl
         if (g.reflect) launch_bf16_kc<KCV, true, SP>(bn, grid, st, in, w, bias, out, g, t, inb, wb, wlo);   \
         else launch_bf16_kc<KCV, false, SP>(bn, grid, st, in, w, bias, out, g, t, inb, wb, wlo);            \
     } while (0)
-    if (acg_igemm_uses_ws(g0)) return acg_igemm_x3_ws_launch(in, wp, bias, out, g0, t, n_w_elems, st);
+    if (acg_igemm_uses_ws(g0)) {
+        ACG_REQUIRE(g0.stats == nullptr || (g0.stats_chunk0 == 0 && g0.stats_cpi == (int)(((long long)g0.GH * g0.GW) / 128)),
+                    "igemm_conv_x3_ws: per-tile statistics of a phased launch");
+        return acg_igemm_x3_ws_launch(in, wp, bias, out, g0, t, n_w_elems, st, g0.stats);
+    }
     static const bool no_patch = acg_debug_switch("ACG_NO_PATCH"); // A/B switch
-    if (!no_patch && acg_conv_patch16_ok(g0, t)) return acg_conv_patch16_launch(in, wp, bias, out, g0, t, n_w_elems, st);
+    if (!no_patch && acg_conv_patch16_ok(g0, t)) {
+        ACG_REQUIRE(g0.stats == nullptr, "conv_patch16: no statistics epilogue");
+        return acg_conv_patch16_launch(in, wp, bias, out, g0, t, n_w_elems, st);
+    }
+    ACG_REQUIRE(g0.stats == nullptr || (((long long)g0.GH * g0.GW) % 128 == 0 && g0.act == ACG_ACT_NONE && g0.Mtot % 128 == 0),
+                "igemm_conv_bf16: per-tile statistics need whole 128-pixel tiles per image and no activation");
     ACG_REQUIRE(g0.fold_p == 0, "igemm_conv_bf16: the fold bypass is implemented by the wave-specialised kernel only");
     if (split) { // hi+lo images double the LDS: 32-channel stages keep 3-4 blocks per CU
         if (g.Cin % 32 == 0) BF16_DISPATCH(32, true);

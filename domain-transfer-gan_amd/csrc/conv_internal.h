@@ -51,6 +51,12 @@ struct Geom {
     // (x = hi + lo + O(2^-17 |x|); the same 4 bytes per element as fp32).  out_s16: the written tensor (out2 on the frame
     // path) takes that form; relu_s16: relu_src is stored that way (its sign = the sign of the hi halves).
     int out_s16 = 0, relu_s16 = 0;
+    // per-tile statistics for an InstanceNorm behind the convolution (acg_conv2d_fwd_stats): (mean, M2) of every output
+    // channel over the 128 output pixels of a tile, written to stats[((img * stats_cpi + stats_chunk0 + tile) * 2 + {0,1}) *
+    // Cout + c], tile = the tile's index within its image in THIS launch (stats_cpi = chunks per image over all launches
+    // that fill the tensor: the four sub-pixel phases of a ConvTranspose2d each add their own chunks)
+    float *stats = nullptr;
+    int stats_cpi = 0, stats_chunk0 = 0;
     int thin;             // 1: K flattened over (tap, 4 channels): stage s = taps 8s..8s+7, channels 0..3 of each
     int bk8;              // 8-float k-chunks per packed weight slab (Cin/8; thin: 4*ceil(ntaps/8), single slab)
     long long Mtot;       // N*GH*GW

@@ -97,9 +97,9 @@ class ConvTranspose2d(nn.ConvTranspose2d, _Cached):
         # weight (Cin_T, Cout_T, k, k) == OIHW of the Conv2d(Cout_T -> Cin_T) it is the adjoint of
         return self._cached(lambda: ops.PackedConv(self.weight, self.bias, cpad(self.out_channels), cpad(self.in_channels)))
 
-    def forward_nhwc(self, x, act=ACT_NONE):
+    def forward_nhwc(self, x, act=ACT_NONE, want_stats=None):
         return ops.ConvTranspose2dFn.apply(x, self.weight, self.bias, self.packed(), self.stride[0], self.padding[0],
-                                           self.output_padding[0], act)
+                                           self.output_padding[0], act, want_stats)
 
     def forward(self, input, output_size=None):
         return ops.ToNCHW.apply(self.forward_nhwc(ops.ToNHWC.apply(input)), self.out_channels)
@@ -336,7 +336,8 @@ def run_sequence(mods, x, C, z=None, res=None):
         if isinstance(conv, ConvTranspose2d):
             if reflect:
                 raise NotImplementedError("reflection pad before ConvTranspose2d")
-            x = conv.forward_nhwc(x, cact)
+            stats = ops.ConvStats() if isinstance(norm, (InstanceNorm, CondInstanceNorm)) else None
+            x = conv.forward_nhwc(x, cact, stats)
         else:  # an (Cond)InstanceNorm right behind the conv can take its statistics from the conv epilogue
             skip_here = res is not None and not skip_routed and x is res  # the block's FIRST convolution
             link_in, relu_link = relu_link, None

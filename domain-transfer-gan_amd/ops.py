@@ -550,7 +550,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
     (Cin_T, Cout_T, k, k) packed as the OIHW weight of the Conv2d it is the adjoint of."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, packed, stride, pad, out_pad, act):
+    def forward(ctx, x, weight, bias, packed, stride, pad, out_pad, act, want_stats=None):
         x = x.contiguous()
         _check(x)
         N, H, W, Cs = x.shape
@@ -564,8 +564,15 @@ class ConvTranspose2dFn(torch.autograd.Function):
         if (d.Ho, d.Wo) != (H, W):
             raise _lib.AcgError("conv_transpose: inconsistent geometry")
         y = torch.empty((N, Hl, Wl, packed.Ci), device=x.device, dtype=torch.float32)
-        _lib.call("acg_conv_transpose2d_fwd", ctypes.byref(d), _ptr(x), _ptr(packed.wb),
-                  _ptr(packed.bias if bias is not None else None), _ptr(y), act, _stream())
+        if want_stats is not None and CONV_STATS_ENABLED and act == ACT_NONE and \
+                _lib.query("acg_conv_transpose2d_fwd_stats_supported", ctypes.byref(d)):
+            part = torch.empty((N, (Hl * Wl) // STATS_ROWS, 2, packed.Ci), device=x.device, dtype=torch.float32)
+            _lib.call("acg_conv_transpose2d_fwd_stats", ctypes.byref(d), _ptr(x), _ptr(packed.wb),
+                      _ptr(packed.bias if bias is not None else None), _ptr(y), _ptr(part), _stream())
+            want_stats.part = part
+        else:
+            _lib.call("acg_conv_transpose2d_fwd", ctypes.byref(d), _ptr(x), _ptr(packed.wb),
+                      _ptr(packed.bias if bias is not None else None), _ptr(y), act, _stream())
         ctx.d, ctx.packed, ctx.act, ctx.has_bias = d, packed, act, bias is not None
         ctx.wparam, ctx.bparam = weight, bias
         ctx.save_for_backward(x, y if act != ACT_NONE else None)
@@ -600,7 +607,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
             if direct is not None:
                 dw = db = None
                 _grads_done(ctx.wparam, ctx.bparam)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------

@@ -157,6 +157,11 @@ int acg_conv2d_bwd_weight(const acg_conv_desc *d, const float *x, const float *d
  *      Conv2d it is the adjoint of (Hi,Wi,Ci = the LARGE side = ConvTranspose output). ---- */
 int acg_conv_transpose2d_fwd(const acg_conv_desc *d, const float *x, const float *wb, const float *bias, float *y,
                              int act, void *stream);
+/* ... that also emits the per-tile statistics of acg_conv2d_fwd_stats for an InstanceNorm behind the transposed convolution
+ * (networks.py:178-181, 231-236): stats [N][Hi*Wi/128][2][Ci], Hi x Wi x Ci = the transposed convolution's OUTPUT. */
+int acg_conv_transpose2d_fwd_stats_supported(const acg_conv_desc *d);
+int acg_conv_transpose2d_fwd_stats(const acg_conv_desc *d, const float *x, const float *wb, const float *bias, float *y,
+                                   float *stats, void *stream);
 int acg_conv_transpose2d_bwd_data(const acg_conv_desc *d, const float *dy, const float *wf, float *dx, void *stream);
 int acg_conv_transpose2d_bwd_weight(const acg_conv_desc *d, const float *x, const float *dy, float *dw_oihw,
                                     float *db, int Or, int Ir, void *workspace, size_t ws_bytes, int accumulate,

@@ -617,3 +617,65 @@ def test_c_abi_error_convention():
     with pytest.raises(_lib.AcgError):
         _lib.call("acg_adam_step", P(x), P(x), P(x), P(x), 16, None, 1.0, 1e-3, 0.5, 0.999, 1e-8, 0, 0, st)   # step < 1
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("case", [("conv", 32, 64, 3, 1, 32, 32), ("conv", 64, 32, 3, 1, 16, 64), ("conv", 16, 32, 3, 2, 32, 32),
+                                  ("conv", 32, 32, 3, 1, 32, 32), ("conv", 16, 32, 3, 2, 64, 64), ("conv", 32, 32, 3, 1, 8, 16),
+                                  ("conv", 64, 128, 3, 2, 32, 32), ("convT", 128, 64, 3, 2, 32, 32), ("convT", 64, 32, 3, 2, 16, 32)])
+def test_conv_epilogue_statistics_equal_the_statistics_pass(case):
+    """Per-tile (mean, M2) from the convolution epilogues (generic bf16 tile, wave-specialised tile, the four phase launches
+    of ConvTranspose2d) merged by acg_norm_stats_from_partials against acg_norm_stats on the stored output: the mean / rstd
+    an InstanceNorm behind the convolution would use (modules.py:83-97)."""
+    import ctypes
+    from hip_util import t, n, rel, precision
+    from dtgan_amd import ops, _lib
+    kind, Ci, Co, K, stride, H, W = case
+    P = ops._ptr
+    with precision("bf16x3"):
+        st = ops._stream()
+        rs = np.random.RandomState(Ci + Co)
+        NB = 4
+        if kind == "conv":
+            d = ops.conv_desc(NB, H, W, Ci, Co, K, stride, 1, 1 if stride == 1 else 0, Ci, Co)
+            x = t(rs.normal(0.3, 1, (NB, H, W, Ci)))
+            w = t(rs.normal(0, 0.2, (Co, Ci, K, K))); b = t(rs.normal(0, 1, Co))
+            pk = ops.PackedConv(w, b, Ci, Co)
+            y = torch.empty((NB, d.Ho, d.Wo, Co), device="cuda")
+            assert _lib.query("acg_conv2d_fwd_stats_supported", ctypes.byref(d))
+            part = torch.zeros((NB, d.Ho * d.Wo // 128, 2, Co), device="cuda")
+            _lib.call("acg_conv2d_fwd_stats", ctypes.byref(d), P(x), P(pk.wf), P(pk.bias), P(y), P(part), st)
+            y2 = torch.empty_like(y)
+            _lib.call("acg_conv2d_fwd", ctypes.byref(d), P(x), P(pk.wf), P(pk.bias), P(y2), 0, st)
+            C = Co
+        else:   # descriptor = the Conv2d (Co <- Ci ... ) the transposed convolution is the adjoint of: its input side is the output
+            Cs, Cl = Ci, Co          # small-side (input of convT) channels, large-side (output) channels
+            d = ops.conv_desc(NB, 2 * H, 2 * W, Cl, Cs, K, 2, 1, 0, Cl, Cs)
+            x = t(rs.normal(0.3, 1, (NB, H, W, Cs)))
+            w = t(rs.normal(0, 0.2, (Cs, Cl, K, K))); b = t(rs.normal(0, 1, Cl))
+            pk = ops.PackedConv(w, b, Cl, Cs)
+            y = torch.empty((NB, 2 * H, 2 * W, Cl), device="cuda")
+            assert _lib.query("acg_conv_transpose2d_fwd_stats_supported", ctypes.byref(d))
+            part = torch.zeros((NB, 4 * H * W // 128, 2, Cl), device="cuda")
+            _lib.call("acg_conv_transpose2d_fwd_stats", ctypes.byref(d), P(x), P(pk.wb), P(pk.bias), P(y), P(part), st)
+            y2 = torch.empty_like(y)
+            _lib.call("acg_conv_transpose2d_fwd", ctypes.byref(d), P(x), P(pk.wb), P(pk.bias), P(y2), 0, st)
+            C = Cl
+        assert torch.equal(y, y2)
+        Pn = y.shape[1] * y.shape[2]
+        for unbiased in (0, 1):   # InstanceNorm / CondInstanceNorm
+            m1, r1 = torch.empty(NB * C, device="cuda"), torch.empty(NB * C, device="cuda")
+            m2, r2 = torch.empty(NB * C, device="cuda"), torch.empty(NB * C, device="cuda")
+            _lib.call("acg_norm_stats_from_partials", P(part), NB, Pn, C, 128, 1e-5, unbiased, P(m1), P(r1), st)
+            nb = _lib.query("acg_norm_workspace_bytes", NB, Pn, C)
+            ws = ops.workspace(nb)
+            _lib.call("acg_norm_stats", P(y), NB, Pn, C, 1e-5, unbiased, P(m2), P(r2), None, None, 0.0, P(ws), nb, st)
+            yy = n(y).reshape(NB, Pn, C).astype(np.float64)
+            assert rel(n(m2), yy.mean(1).ravel()) < 1e-5
+            var = yy.var(1, ddof=unbiased).ravel()
+            assert np.max(np.abs(n(r2) * np.sqrt(var + 1e-5) - 1)) < 1e-5
+            sd = np.sqrt(var)
+            print("stats vs fp64 (%s, unbiased %d): mean error / sigma: epilogue %.1e, pass %.1e; rstd rel error: epilogue %.1e, pass %.1e"
+                  % (str(case), unbiased, np.max(np.abs(n(m1) - yy.mean(1).ravel()) / sd), np.max(np.abs(n(m2) - yy.mean(1).ravel()) / sd),
+                     np.max(np.abs(n(r1) * np.sqrt(var + 1e-5) - 1)), np.max(np.abs(n(r2) * np.sqrt(var + 1e-5) - 1))))
+            assert np.max(np.abs(n(m1) - n(m2))) < 1e-5 * np.max(np.abs(n(m2))), np.max(np.abs(n(m1) - n(m2)))
+            assert np.max(np.abs(n(r1) / n(r2) - 1)) < 1e-5, np.max(np.abs(n(r1) / n(r2) - 1))

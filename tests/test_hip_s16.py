@@ -77,7 +77,7 @@ def test_generator_with_presplit_trunk_matches_fp32_storage(kind):
     assert rel(pre[0], plain[0]) < 2e-5 and rel(pre[0], ref[0]) < 1e-3           # images: storage rounding only
     e_plain, e_pre = l2rel(plain[1], ref[1]), l2rel(pre[1], ref[1])
     print("input gradient vs exact fp32: fp32 storage %.2e, pre-split %.2e" % (e_plain, e_pre))
-    assert e_pre < max(3 * e_plain, 1e-2), (e_plain, e_pre)
+    assert e_pre < max(3 * e_plain, 2e-2), (e_plain, e_pre)
     worst = 0.0
     for k in ref[2]:
         a, b, c = pre[2][k], plain[2][k], ref[2][k]
@@ -86,7 +86,7 @@ def test_generator_with_presplit_trunk_matches_fp32_storage(kind):
         if np.linalg.norm(c) > 1e-4 * np.sqrt(c.size):
             ea, eb = l2rel(a, c), l2rel(b, c)
             worst = max(worst, ea)
-            assert ea < max(3 * eb, 1e-2), (k, ea, eb)
+            assert ea < max(3 * eb, 2e-2), (k, ea, eb)
     print("worst parameter gradient vs exact fp32, pre-split: %.2e" % worst)
 
 

@@ -8,6 +8,7 @@ the bar itself: 1e-3 losses and images, 3e-3 gradient norms.  Later steps inheri
 noise on ~zero-gradient tensors (see tests/test_oracle_golden.py): 1e-2 / 6e-2 / 5e-3, and 2e-2 / 6e-2 / 2e-2.
 """
 import argparse
+import os
 
 import numpy as np
 import pytest
@@ -68,17 +69,23 @@ REC_TOL = {("f32", "init"): (2e-4, 2e-2), ("f32", "rich"): (3e-4, 4e-2),
 # the BatchNorm buffers after the last step.  (grad, update) tolerances on the abs-sum / L2 digests, step 0 only — later
 # steps are chaotic per tensor (tests/test_oracle_golden.py).  bf16x3 gradients are norm-wise quantities: a ReLU mask that
 # flips under the 2^-17 operand rounding changes single entries discretely (tools/conditioning_probe.py).
-# Measured worst over the five fixtures: f32 inside (3e-3, 5e-3); bf16x3 1.2e-2 on one CondInstanceNorm shift-conv weight of
-# the full-width config-1 fixture (a sum over ReLU-gated per-sample shifts), all other tensors < 1e-2.
+# Measured worst over the five fixtures: f32 inside (3e-3, 5e-3); bf16x3 on the 'init' flavour (the reference's own
+# initialisation statistics) 1.2e-2 on one CondInstanceNorm shift-conv weight of the full-width config-1 fixture (a sum over
+# ReLU-gated per-sample shifts), all other tensors < 1e-2.  On the deliberately ill-conditioned 'rich' flavour the bf16x3
+# digests are not a pin: switching the InstanceNorm statistics between two equally accurate fp32 methods (both 1e-7 from fp64,
+# test_conv_epilogue_statistics_equal_the_statistics_pass) moves the forward by 3e-5 and the CondInstanceNorm shift / scale
+# convolution gradients by up to 17 % there (tools/debug_stats_ab.py); those fixtures pin the gradients in the f32 mode and
+# are held to 0.25 in bf16x3.
 DIGEST_TOL = {"f32": (3e-3, 5e-3), "bf16x3": (2e-2, 2e-2)}
+DIGEST_TOL_RICH_X3 = (0.25, 0.25)
 # Networks whose .grad after the step is comparable: the reference lets loss_G.backward() pile the (unused) G-phase
 # gradients on top of the discriminators' D-phase .grad (model.py:509, no zero_grad for them); the HIP path skips those
 # weight gradients, so the discriminators are pinned by their UPDATE digests (which only see the D-phase gradient).
 GRAD_NETS = ("netG_A_B", "netG_B_A", "netE_B")
 
 
-def _check_digests(m, arr, pre, prec):
-    gt, ut = DIGEST_TOL[prec]
+def _check_digests(m, arr, pre, prec, flavour="init"):
+    gt, ut = DIGEST_TOL_RICH_X3 if (prec == "bf16x3" and flavour == "rich") else DIGEST_TOL[prec]
     bad, seen = [], 0
     for nname, net in m._net_dict().items():
         params = dict(net.named_parameters())
@@ -94,6 +101,8 @@ def _check_digests(m, arr, pre, prec):
                 floor = 3e-5 * gmax * np.array([g.size, np.sqrt(g.size)])    # summation noise on analytically-zero gradients
                 if not np.all(np.abs(dg[1:3] - rg[1:3]) <= gt * np.abs(rg[1:3]) + floor):
                     bad.append(("grad", nname, k, dg[1:3], rg[1:3]))
+                if os.environ.get("ACG_TEST_VERBOSE") and "_conv" in k:
+                    print("digest", nname, k, np.abs(dg[1:3] - rg[1:3]) / np.abs(rg[1:3]))
                 seen += 1
             d = digest(p.detach().cpu().numpy().astype(np.float64) - pre[nname][k].astype(np.float64))
             r = arr["s0/upd/%s/%s" % (nname, k)]
@@ -141,7 +150,7 @@ def _check_steps(name, prec):
         for k in ("real_A", "real_B"):
             assert np.array_equal(n(visuals[k]), arr["s%d/%s" % (st, k)])
         if st == 0:
-            _check_digests(m, arr, pre, prec)
+            _check_digests(m, arr, pre, prec, meta["flavour"])
     if meta["aug"]:   # BatchNorm running buffers after the last step (networks.py:407-415, 450-462)
         for nname in ("netE_B", "netD_z_B"):
             for k, b in m._net_dict()[nname].named_buffers():
