@@ -751,21 +751,47 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
     // stride 2: four sub-pixel phases, each a dense small-tap convolution (no zero insertion)
     ACG_REQUIRE(d->pad_mode == ACG_PAD_ZERO, "dgrad: stride 2 needs zero padding");
     g.Hout = d->Hi; g.Wout = d->Wi; g.os = 2;
+    auto phase_taps = [&](int py, int px, Taps &tt, int base) {
+        int n = 0;
+        for (int kh = 0; kh < K; ++kh) {
+            if ((py + p - kh) & 1) continue;
+            for (int kw = 0; kw < K; ++kw) {
+                if ((px + p - kw) & 1) continue;
+                tt.dy[base + n] = (short)((py + p - kh) / 2); tt.dx[base + n] = (short)((px + p - kw) / 2);
+                tt.w[base + n] = (short)(kh * K + kw);
+                n++;
+            }
+        }
+        return n;
+    };
+    // One launch for the four phases where the generic bf16 tile runs them anyway: even output sizes (equal phase grids of
+    // whole 128-pixel tiles), at most 16 taps per phase.  The phases of a tile read the same rows of `src`: side by side on
+    // one XCD they fetch them from HBM once (four launches: 2.0x the algorithmic traffic, profiles/r02_a_layer_traffic).
+    static const bool no_phased = acg_debug_switch("ACG_NO_PHASED");   // A/B switch
+    g.GH = d->Hi / 2; g.GW = d->Wi / 2; g.oy0 = 0; g.ox0 = 0;
+    g.Mtot = (long long)d->N * g.GH * g.GW;
+    if (!no_phased && d->Hi % 2 == 0 && d->Wi % 2 == 0 && g.Mtot % 128 == 0 && (K + 1) / 2 * ((K + 1) / 2) <= 16 &&
+        g_acg_precision != ACG_PREC_F32 && g_acg_conv_impl == ACG_IMPL_MFMA && !g.thin && !thin_in_valu_dgrad(d) && !thin_out(d) &&
+        !acg_igemm_uses_ws(g)) {
+        t.n = 64;
+        for (int i = 0; i < 64; ++i) { t.dy[i] = 0; t.dx[i] = 0; t.w[i] = 0; }
+        g.nphase = 4;
+        for (int ph = 0; ph < 4; ++ph) {
+            g.ph_ntaps[ph] = phase_taps(ph >> 1, ph & 1, t, 16 * ph);
+            ACG_REQUIRE(g.ph_ntaps[ph] > 0, "dgrad: empty phase (K=%d p=%d)", K, p);
+        }
+        if (stats != nullptr) {
+            const int per = (int)(((long long)g.GH * g.GW) / 128);
+            g.stats = stats; g.stats_cpi = 4 * per; g.stats_chunk0 = 0;
+        }
+        return acg_igemm_launch(src, wb, bias, dst, g, t, st);
+    }
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
             g.oy0 = py; g.ox0 = px;
             g.GH = (d->Hi - py + 1) / 2; g.GW = (d->Wi - px + 1) / 2;
             g.Mtot = (long long)d->N * g.GH * g.GW;
-            t.n = 0;
-            for (int kh = 0; kh < K; ++kh) {
-                if ((py + p - kh) & 1) continue;
-                for (int kw = 0; kw < K; ++kw) {
-                    if ((px + p - kw) & 1) continue;
-                    t.dy[t.n] = (short)((py + p - kh) / 2); t.dx[t.n] = (short)((px + p - kw) / 2);
-                    t.w[t.n] = (short)(kh * K + kw);
-                    t.n++;
-                }
-            }
+            t.n = phase_taps(py, px, t, 0);
             ACG_REQUIRE(t.n > 0, "dgrad: empty phase (K=%d p=%d)", K, p);
             if (stats != nullptr) { // each phase owns a quarter of every image's 128-pixel chunks
                 const int per = (int)(((long long)g.GH * g.GW) / 128);

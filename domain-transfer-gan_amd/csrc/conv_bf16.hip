@@ -52,7 +52,12 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
     const int wm = wave / WN, wn = wave % WN;
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
-    const int swz = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    int swz = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    // phased launch (Geom.nphase): phase = the low two bits of the tile number
+    const int ph = g.nphase ? (swz & 3) : 0;
+    if (g.nphase) swz >>= 2;
+    const int tbase = ph * 16, ntap = g.nphase ? g.ph_ntaps[ph] : taps.n;
+    const int oy0 = g.nphase ? (ph >> 1) : g.oy0, ox0 = g.nphase ? (ph & 1) : g.ox0;
     const int tiles_n = g.ncols_pad / BN;
     const int tile_n = swz % tiles_n, tile_m = swz / tiles_n;
     const int n0 = tile_n * BN;
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
             const int n = (int)(m / GHW);
             const int r = (int)(m - (long long)n * GHW);
             const int gy = r / g.GW, gx = r - gy * g.GW;
-            off = (((long long)n * g.Hout + (gy * g.os + g.oy0)) * g.Wout + (gx * g.os + g.ox0)) * g.Cout;
+            off = (((long long)n * g.Hout + (gy * g.os + oy0)) * g.Wout + (gx * g.os + ox0)) * g.Cout;
         }
         out_off[tid] = off;
     }
@@ -106,15 +111,15 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int S = taps.n * (g.Cin / KC);
+    const int S = ntap * (g.Cin / KC);
     f32x8 ra[AL];
     u32x4 rb[BL], rbl[BL]; // 8 bf16 each (hi, lo)
 
     auto load_stage = [&](int s) {
-        const int cc = s / taps.n;
-        const int t = s - cc * taps.n;
+        const int cc = s / ntap;
+        const int t = s - cc * ntap;
         const int c0 = cc * KC;
-        const int pk = taps.pk[t]; // scalar load: (dy, dx, weight slab) of this stage
+        const int pk = taps.pk[tbase + t]; // scalar load: (dy, dx, weight slab) of this stage
         const int ty = (pk << 24) >> 24, tx = (pk << 16) >> 24, tw = pk >> 16;
 #pragma unroll
         for (int j = 0; j < AL; ++j) {
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
                     mu[j] = s * (1.f / BM);
                 } else if (wm == 0 && lane < 32 && n0 + cl < g.Cout) {
                     const long long tile = m0 / BM, tpi = (long long)GHW / BM;     // tile index, tiles per image in this launch
-                    const long long chunk = (tile / tpi) * g.stats_cpi + g.stats_chunk0 + tile % tpi;
+                    const long long chunk = (tile / tpi) * g.stats_cpi + g.stats_chunk0 + ph * tpi + tile % tpi;
                     float *o = g.stats + chunk * 2 * g.Cout + n0 + cl;
                     o[0] = mu[j];
                     o[g.Cout] = s;
@@ -287,8 +292,10 @@ int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, fl
 {
     Geom g = g0;
     g.thin = 0;
-    dim3 grid(acg_cdiv(g.Mtot, 128) * (g.ncols_pad / bn));
+    dim3 grid(acg_cdiv(g.Mtot, 128) * (g.ncols_pad / bn) * (g.nphase ? 4 : 1));
     const __bf16 *w = (const __bf16 *)wp;
+    ACG_REQUIRE(g.nphase == 0 || (g.nphase == 4 && !acg_igemm_uses_ws(g0) && g.Mtot % 128 == 0),
+                "igemm_conv_bf16: phased launches are for the generic tile, whole tiles per phase");
     const bool split = g_acg_precision == ACG_PREC_BF16X3;
     const long long nimg = g.Mtot / ((long long)g.GH * g.GW);
     const long long in_bytes = nimg * g.Hin * g.Win * g.Cin * 4;

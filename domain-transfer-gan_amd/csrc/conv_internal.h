@@ -57,6 +57,12 @@ struct Geom {
     // that fill the tensor: the four sub-pixel phases of a ConvTranspose2d each add their own chunks)
     float *stats = nullptr;
     int stats_cpi = 0, stats_chunk0 = 0;
+    // nphase == 4 (generic bf16 tile only): the four sub-pixel phases of a stride-2 data gradient / ConvTranspose2d forward
+    // in ONE launch.  Phase ph = 2 py + px writes output pixels (2 gy + py, 2 gx + px) from the taps pk[16 ph .. 16 ph +
+    // ph_ntaps[ph]); all phases share GH x GW (even output sizes).  Workgroup w handles phase w % 4 of tile w / 4, so the four
+    // phases of a tile — which gather the same rows of the input — run side by side on one XCD and share its L2.
+    int nphase = 0;
+    int ph_ntaps[4] = {0, 0, 0, 0};
     int thin;             // 1: K flattened over (tap, 4 channels): stage s = taps 8s..8s+7, channels 0..3 of each
     int bk8;              // 8-float k-chunks per packed weight slab (Cin/8; thin: 4*ceil(ntaps/8), single slab)
     long long Mtot;       // N*GH*GW
