@@ -776,9 +776,11 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
         t.n = 64;
         for (int i = 0; i < 64; ++i) { t.dy[i] = 0; t.dx[i] = 0; t.w[i] = 0; }
         g.nphase = 4;
+        g.ph_ntaps = 0;
         for (int ph = 0; ph < 4; ++ph) {
-            g.ph_ntaps[ph] = phase_taps(ph >> 1, ph & 1, t, 16 * ph);
-            ACG_REQUIRE(g.ph_ntaps[ph] > 0, "dgrad: empty phase (K=%d p=%d)", K, p);
+            const int nt = phase_taps(ph >> 1, ph & 1, t, 16 * ph);
+            ACG_REQUIRE(nt > 0, "dgrad: empty phase (K=%d p=%d)", K, p);
+            g.ph_ntaps |= nt << (8 * ph);
         }
         if (stats != nullptr) {
             const int per = (int)(((long long)g.GH * g.GW) / 128);

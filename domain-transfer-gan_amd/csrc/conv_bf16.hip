@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
     // phased launch (Geom.nphase): phase = the low two bits of the tile number
     const int ph = g.nphase ? (swz & 3) : 0;
     if (g.nphase) swz >>= 2;
-    const int tbase = ph * 16, ntap = g.nphase ? g.ph_ntaps[ph] : taps.n;
+    const int tbase = ph * 16, ntap = g.nphase ? ((g.ph_ntaps >> (8 * ph)) & 0xff) : taps.n;
     const int oy0 = g.nphase ? (ph >> 1) : g.oy0, ox0 = g.nphase ? (ph & 1) : g.ox0;
     const int tiles_n = g.ncols_pad / BN;
     const int tile_n = swz % tiles_n, tile_m = swz / tiles_n;

@@ -62,7 +62,8 @@ struct Geom {
     // ph_ntaps[ph]); all phases share GH x GW (even output sizes).  Workgroup w handles phase w % 4 of tile w / 4, so the four
     // phases of a tile — which gather the same rows of the input — run side by side on one XCD and share its L2.
     int nphase = 0;
-    int ph_ntaps[4] = {0, 0, 0, 0};
+    int ph_ntaps = 0;     // tap counts of the four phases, one byte each (an array here would be indexed at run time in the
+                          // kernel and drag the by-value argument structs into scratch memory: 2-3x slower, measured)
     int thin;             // 1: K flattened over (tap, 4 channels): stage s = taps 8s..8s+7, channels 0..3 of each
     int bk8;              // 8-float k-chunks per packed weight slab (Cin/8; thin: 4*ceil(ntaps/8), single slab)
     long long Mtot;       // N*GH*GW
