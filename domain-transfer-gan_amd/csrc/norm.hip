@@ -363,9 +363,21 @@ __global__ __launch_bounds__(256) void norm_bwd_apply(const float *__restrict__ 
                                                       const float *__restrict__ beta, int gstride,
                                                       const float *__restrict__ sums, float *__restrict__ dx,
                                                       float *__restrict__ dres, long long P, int C, float invP,
-                                                      float invD, const unsigned *__restrict__ mask)
+                                                      float invD, const unsigned *__restrict__ mask, int pG, int nparam,
+                                                      int accumulate, float *__restrict__ dgamma, float *__restrict__ dbeta)
 {
     constexpr bool RECOMPUTE = MSRC == 1;
+    // shared affine parameters (InstanceNorm / BatchNorm): dgamma[c] = sum_g S2, dbeta[c] = sum_g S1 for the first nparam
+    // (real) channels, by the first workgroup on the side — it used to be a launch of its own (norm_bwd_params: one
+    // workgroup, 9 us, 72 times per training step)
+    if (nparam > 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+        for (int i = threadIdx.x; i < nparam; i += 256) {
+            float a = 0.f, b = 0.f;
+            for (int gg = 0; gg < pG; ++gg) { a += sums[(gg * 2) * C + i]; b += sums[(gg * 2 + 1) * C + i]; }
+            if (dbeta) dbeta[i] = (accumulate ? dbeta[i] : 0.f) + a;
+            if (dgamma) dgamma[i] = (accumulate ? dgamma[i] : 0.f) + b;
+        }
+    }
     const int C4 = C / 4;
     const int g = blockIdx.y;
     const long long total = P * C4;
@@ -492,15 +504,16 @@ static void launch_norm_bwd_partial(dim3 grid, hipStream_t st, const float *dy, 
 static void launch_norm_bwd_apply(dim3 grid, hipStream_t st, const float *dy, const float *y, const float *x,
                                   const float *mean, const float *rstd, const float *gamma, const float *beta, int gstride,
                                   const float *sums, float *dx, float *dres, long long P, int C, int act, float invP,
-                                  float invD, const unsigned *mask, int dx_s16 = 0)
+                                  float invD, const unsigned *mask, int dx_s16 = 0, int pG = 0, int nparam = 0, int accumulate = 0,
+                                  float *dgamma = nullptr, float *dbeta = nullptr)
 {
-#define LS(A, R) hipLaunchKernelGGL((norm_bwd_apply<A, R, false, true>), grid, dim3(256), 0, st, dy, y, x, mean, rstd, gamma, beta, gstride, sums, dx, dres, P, C, invP, invD, mask)
+#define LS(A, R) hipLaunchKernelGGL((norm_bwd_apply<A, R, false, true>), grid, dim3(256), 0, st, dy, y, x, mean, rstd, gamma, beta, gstride, sums, dx, dres, P, C, invP, invD, mask, pG, nparam, accumulate, dgamma, dbeta)
     if (dx_s16) { // pre-split dx: ReLU with the sign bitmask (block-output norm) or recomputed from x (CondInstanceNorm)
         if (mask) LS(ACG_ACT_RELU, 2);
         else LS(ACG_ACT_RELU, 1);
         return;
     }
-#define L(A, R, D) hipLaunchKernelGGL((norm_bwd_apply<A, R, D>), grid, dim3(256), 0, st, dy, y, x, mean, rstd, gamma, beta, gstride, sums, dx, dres, P, C, invP, invD, mask)
+#define L(A, R, D) hipLaunchKernelGGL((norm_bwd_apply<A, R, D>), grid, dim3(256), 0, st, dy, y, x, mean, rstd, gamma, beta, gstride, sums, dx, dres, P, C, invP, invD, mask, pG, nparam, accumulate, dgamma, dbeta)
 #define M(A)                                                                         \
     do {                                                                             \
         const bool rc = y == nullptr && mask == nullptr;                             \
@@ -678,14 +691,13 @@ extern "C" int acg_norm_bwd(const float *dy, const float *y, const unsigned *mas
     launch_norm_bwd_partial(dim3(nch, G), st, dy, y, x, mean, rstd, gamma, beta, gstride, (long long)P, C, nch, act, part, mask);
     hipLaunchKernelGGL(norm_bwd_final, dim3(G * acg_cdiv(C, FIN_CH)), dim3(256), 0, st, (const float *)part, G, C,
                        nch, sums, gstride ? dgamma : (float *)nullptr, gstride ? dbeta : (float *)nullptr);
-    if (gstride == 0 && nparam > 0 && (dgamma != nullptr || dbeta != nullptr))
-        hipLaunchKernelGGL(norm_bwd_params, dim3(acg_cdiv(nparam, 256)), dim3(256), 0, st, (const float *)sums, G, C, nparam,
-                           accumulate, dgamma, dbeta);
+    const bool params = gstride == 0 && nparam > 0 && (dgamma != nullptr || dbeta != nullptr);
     // unbiased == 2: statistics are constants (BatchNorm eval mode) -> dx = gamma * rstd * gy
     const float invP = unbiased == 2 ? 0.f : 1.f / (float)P;
     const float invD = unbiased == 2 ? 0.f : (unbiased ? 1.f / (float)(P - 1) : invP);
     launch_norm_bwd_apply(dim3(ew_blocks((long long)P * (C / 4)), G), st, dy, y, x, mean, rstd, gamma, beta, gstride,
-                          (const float *)sums, dx, dres, (long long)P, C, act, invP, invD, mask, dx_s16);
+                          (const float *)sums, dx, dres, (long long)P, C, act, invP, invD, mask, dx_s16, G, params ? nparam : 0,
+                          accumulate, dgamma, dbeta);
     ACG_CHECK_LAUNCH("norm_bwd");
     return ACG_OK;
 }

@@ -57,6 +57,8 @@ class _Cached(object):
 
 
 def _padded_vec(v, npad):
+    if v.numel() == npad and v.is_contiguous() and v.dtype == torch.float32:
+        return v.detach()   # already a multiple of 16 channels: the kernels read the parameter itself (no copy, never stale)
     out = torch.empty(npad, device=v.device, dtype=torch.float32)
     ops._lib.call("acg_pad_vector", ops._ptr(v.detach().contiguous()), v.numel(), ops._ptr(out), npad, ops._stream())
     return out

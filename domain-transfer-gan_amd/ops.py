@@ -186,9 +186,12 @@ class PackedConv(object):
         if bias is not None:
             n = bias.numel()
             npad = cpad(n)
-            if self.bias is None:
-                self.bias = torch.empty(npad, device=w.device, dtype=torch.float32)
-            _lib.call("acg_pad_vector", _ptr(bias.detach()), n, _ptr(self.bias), npad, _stream())
+            if n == npad and bias.is_contiguous() and bias.dtype == torch.float32:
+                self.bias = bias.detach()   # no padding needed: the kernels read the parameter itself
+            else:
+                if self.bias is None or self.bias.data_ptr() == bias.data_ptr():
+                    self.bias = torch.empty(npad, device=w.device, dtype=torch.float32)
+                _lib.call("acg_pad_vector", _ptr(bias.detach()), n, _ptr(self.bias), npad, _stream())
 
 
 class ConvTimer(object):
