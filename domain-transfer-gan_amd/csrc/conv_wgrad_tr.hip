@@ -545,13 +545,21 @@ __device__ __forceinline__ bf16x8 tr_frag_s(const lds_char *p)
 // s+1 are complete and stage s+2 is in flight, so a wave's fragment reads run one tap-step AHEAD of its MFMAs across the
 // stage boundary (the A fragments of the next tap — and the B fragments of the next 16 pixels — are issued before the six
 // MFMAs of the current tap): the LDS latency that used to open every stage behind the barrier is covered by MFMAs.
-__global__ __launch_bounds__(640) void wgrad_x3_krow_s16(const char *__restrict__ x, const char *__restrict__ dy,
+#ifndef ACG_KROW_NDW
+#define ACG_KROW_NDW 4
+#endif
+template <bool REFLECT>
+__global__ __launch_bounds__(512 + 64 * ACG_KROW_NDW) void wgrad_x3_krow_s16(const char *__restrict__ x, const char *__restrict__ dy,
                                                          float *__restrict__ part, WGeom g, unsigned x_bytes, unsigned d_bytes)
 {
     __shared__ __attribute__((aligned(1024))) char lds[SNB * SBUF];
     typedef __attribute__((address_space(3))) void lds_void;
-    constexpr int PW = (SXP + SDP) / 2;                    // pieces per DMA wave and stage
-    static_assert((SXP + SDP) % 2 == 0 && KP == 32 && SNB == 4, "piece plan / pipeline depth");
+    // DMA waves: issuing a piece costs a wave 100-200 cycles beside a busy CU, 38 pieces per stage; with two such waves the
+    // MFMA waves stood at the barrier 26-50 % of the loop waiting for the ISSUE of the pieces (in-kernel stamps,
+    // -DACG_STAMP), not for their data: four waves share the pieces (10, 10, 9, 9)
+    constexpr int NDW = ACG_KROW_NDW;
+    constexpr int PMIN = SXP / NDW + SDP / NDW;            // pieces per DMA wave and stage: at least this many
+    static_assert(KP == 32 && SNB == 4 && (NDW == 2 || NDW == 4), "piece plan / pipeline depth");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_ci = g.CiP / BC, tiles_co = g.CoP / BC;
@@ -585,27 +593,37 @@ __global__ __launch_bounds__(640) void wgrad_x3_krow_s16(const char *__restrict_
             lox = rr - loy * W;
         }
         long long lm = mbeg;
-        // piece e = dw + 2 j; e < SXP: x window piece e, else dy piece e - SXP.  Lane L of a piece holds chunk L % 36 of image
-        // row L / 36: chunks 0..15 = hi of channel groups 0..15, 16..31 = lo, 32..35 = pad (masked)
-        int p_row[PW], p_lds[PW];
-        unsigned p_col[PW];
-        bool p_ok[PW];
+        // Pieces of wave dw: x window pieces dw + NDW j (j < PX) and dy pieces dw + NDW j (j < PD) — which kind a slot is is known
+        // at compile time, and the per-piece address arithmetic is branch-free (the first version decided kind, reflection
+        // and validity per piece with run-time branches: ~30 instructions and five branches per piece, and issuing the
+        // pieces, not their data, paced the loop).  Lane L of a piece holds chunk L % 36 of image row L / 36: chunks 0..15 =
+        // hi of channel groups 0..15, 16..31 = lo, 32..35 = pad (masked).
+        constexpr int PX = (SXP + NDW - 1) / NDW, PD = (SDP + NDW - 1) / NDW;
+        int x_row[PX], x_lds[PX], d_lds[PD];
+        unsigned x_col[PX], d_off[PD];
+        bool x_ok[PX], d_ok[PD];
 #pragma unroll
-        for (int j = 0; j < PW; ++j) {
-            const int e = dw + 2 * j;
-            const bool isx = e < SXP;
-            const int pc = isx ? e : e - SXP;
-            const int L = pc * 64 + lane;
+        for (int j = 0; j < PX; ++j) {
+            const int pc = dw + NDW * j, L = pc * 64 + lane;
             const int row = L / SLANES, ch = L - row * SLANES;
-            p_row[j] = row;
-            p_col[j] = (unsigned)((isx ? ci0 : co0) * 4 + (ch & 15) * 32 + (ch >> 4) * 16);
-            p_ok[j] = ch < 32 && row < (isx ? XW : KP);
-            p_lds[j] = __builtin_amdgcn_readfirstlane((isx ? 0 : SXB) + pc * 1024);
+            x_row[j] = row - 1;
+            x_col[j] = (unsigned)(ci0 * 4 + (ch & 15) * 32 + (ch >> 4) * 16);
+            x_ok[j] = pc < SXP && ch < 32 && row < XW;
+            x_lds[j] = __builtin_amdgcn_readfirstlane(pc * 1024);
         }
+#pragma unroll
+        for (int j = 0; j < PD; ++j) {
+            const int pc = dw + NDW * j, L = pc * 64 + lane;
+            const int row = L / SLANES, ch = L - row * SLANES;
+            d_off[j] = (unsigned)row * (unsigned)(g.Cg * 4) + (unsigned)(co0 * 4 + (ch & 15) * 32 + (ch >> 4) * 16);
+            d_ok[j] = pc < SDP && ch < 32 && row < KP;
+            d_lds[j] = __builtin_amdgcn_readfirstlane(SXB + pc * 1024);
+        }
+        const unsigned xpitch = (unsigned)(g.Cin * 4), dpitch = (unsigned)(g.Cg * 4);
         auto issue_stage = [&](int buf) {
             int iy = loy + ky - 1;
             bool rowok = true;
-            if (g.reflect) {
+            if (REFLECT) {
                 iy = iy < 0 ? -iy : iy;
                 iy = iy >= H ? 2 * (H - 1) - iy : iy;
             } else {
@@ -614,38 +632,40 @@ __global__ __launch_bounds__(640) void wgrad_x3_krow_s16(const char *__restrict_
             const int rowbase = (ln * H + iy) * W;
             char *Bb = lds + buf * SBUF;
 #pragma unroll
-            for (int j = 0; j < PW; ++j) {
-                const int e = dw + 2 * j;
-                bool ok = p_ok[j];
-                if (e < SXP) { // wave-uniform
-                    int ix = lox - 1 + p_row[j];
-                    ok = ok && rowok;
-                    if (g.reflect) {
+            for (int j = 0; j < PX; ++j) {
+                if (dw + NDW * j < SXP) { // wave-uniform
+                    int ix = lox + x_row[j];
+                    bool ok = x_ok[j] && rowok;
+                    if (REFLECT) {
                         ix = ix < 0 ? -ix : ix;
                         ix = ix >= W ? 2 * (W - 1) - ix : ix;
                     } else {
                         ok = ok && (unsigned)ix < (unsigned)W;
                     }
-                    const unsigned off = (unsigned)(rowbase + ix) * (unsigned)(g.Cin * 4) + p_col[j];
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_void *)(Bb + p_lds[j]), 16, acg_masked_off(off, ok), 0, 0, 0);
-                } else {
-                    const unsigned off = (unsigned)((int)lm + p_row[j]) * (unsigned)(g.Cg * 4) + p_col[j];
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rd_, (lds_void *)(Bb + p_lds[j]), 16, acg_masked_off(off, ok), 0, 0, 0);
+                    const unsigned off = (unsigned)(rowbase + ix) * xpitch + x_col[j];
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_void *)(Bb + x_lds[j]), 16, acg_masked_off(off, ok), 0, 0, 0);
                 }
+            }
+            const unsigned dbase = (unsigned)(int)lm * dpitch;
+#pragma unroll
+            for (int j = 0; j < PD; ++j) {
+                if (dw + NDW * j < SDP) // wave-uniform
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rd_, (lds_void *)(Bb + d_lds[j]), 16, acg_masked_off(dbase + d_off[j], d_ok[j]), 0, 0, 0);
             }
             lm += KP;
             lox += KP;
             if (lox == W) { lox = 0; if (++loy == H) { loy = 0; ++ln; } }
         };
         // Bias gradient (column sums of dy) on the side: the DMA waves have the time and the registers.  Lane (pixel group
-        // pg = 4 dw + lane / 16, channel group c8 = lane % 16) adds hi + lo of 8 channels of the 4 pixels 4 pg .. 4 pg + 3 of
-        // every landed dy image; the eight pixel groups meet in LDS at the end, in fixed order.
+        // pg = 4 dw + lane / 16, channel group c8 = lane % 16) adds hi + lo of 8 channels of its KP / (4 NDW) pixels of
+        // every landed dy image; the 4 NDW pixel groups meet in LDS at the end, in fixed order.
         float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        constexpr int BRW = KP / (4 * NDW);                 // pixel rows per lane group
         const int bc8 = lane & 15, bpg = 4 * dw + (lane >> 4);
         auto bias_stage = [&](int buf) {
-            const char *dp = lds + buf * SBUF + SXB + (4 * bpg) * SP + bc8 * 16;
+            const char *dp = lds + buf * SBUF + SXB + (BRW * bpg) * SP + bc8 * 16;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < BRW; ++r) {
                 const u32x4 h = *(const u32x4 *)(dp + r * SP), l = *(const u32x4 *)(dp + r * SP + 256);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -658,14 +678,14 @@ __global__ __launch_bounds__(640) void wgrad_x3_krow_s16(const char *__restrict_
         if (nst > 0) issue_stage(0);
         if (nst > 1) issue_stage(1);
         if (nst > 2) issue_stage(2);
-        if (nst > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
-        else if (nst > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+        if (nst > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PMIN) : "memory");
+        else if (nst > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PMIN) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                    // barrier -1: stage 0 is complete
         if (do_bias && nst > 0) bias_stage(0);
         int nxt = 3, bb = 1;
         for (int s = 0; s < nst; ++s) {
-            if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");   // stage s+1 complete, s+2 in flight
+            if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PMIN) : "memory");  // stage s+1 complete, s+2 in flight
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                // barrier s: every MFMA wave has finished reading stage s-1
             if (s + 3 < nst) issue_stage(nxt);           // ... whose buffer stage s+3 takes
@@ -680,11 +700,13 @@ __global__ __launch_bounds__(640) void wgrad_x3_krow_s16(const char *__restrict_
             for (int e = 0; e < 8; ++e) red[(bpg * 16 + bc8) * 8 + e] = bsum[e];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                // (the MFMA waves join it)
-            const int c = (tid - 512);                   // 128 threads, one per channel
-            float sum = 0.f;
+            const int c = (tid - 512);                   // the first 128 threads: one per channel
+            if (c < BC) {
+                float sum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) sum += red[(r * 16 + (c >> 3)) * 8 + (c & 7)];
-            g.bias_part[(long long)split * g.CoP + co0 + c] = sum;
+                for (int r = 0; r < 4 * NDW; ++r) sum += red[(r * 16 + (c >> 3)) * 8 + (c & 7)];
+                g.bias_part[(long long)split * g.CoP + co0 + c] = sum;
+            }
         }
         return;
     }
@@ -733,6 +755,9 @@ __global__ __launch_bounds__(640) void wgrad_x3_krow_s16(const char *__restrict_
     };
 
     __syncthreads();                                     // barrier -1
+#ifdef ACG_STAMP
+    unsigned long long st_wait = 0, st_work = 0, st_t = __builtin_amdgcn_s_memtime();
+#endif
     AF a0, a1;
     BF b0, b1;
     if (nst > 0) {
@@ -753,7 +778,13 @@ __global__ __launch_bounds__(640) void wgrad_x3_krow_s16(const char *__restrict_
         mma(0, a1, b1);
         a1 = load_a(cur, 1, 2);
         mma(1, a0, b1);
+#ifdef ACG_STAMP
+        { const unsigned long long t = __builtin_amdgcn_s_memtime(); st_work += t - st_t; st_t = t; }
+#endif
         __syncthreads();                                 // barrier s: stage s+1 is complete
+#ifdef ACG_STAMP
+        { const unsigned long long t = __builtin_amdgcn_s_memtime(); st_wait += t - st_t; st_t = t; }
+#endif
         const int nb = (cur + 1) & (SNB - 1);
         if (s + 1 < nst) {
             b0 = load_b(nb, 0);
@@ -762,6 +793,12 @@ __global__ __launch_bounds__(640) void wgrad_x3_krow_s16(const char *__restrict_
         mma(2, a1, b1);
         cur = nb;
     }
+#ifdef ACG_STAMP
+    if (lane == 0 && g.bias_part != nullptr) { // diagnostic build only: (barrier wait, the rest) cycles of this wave's main loop
+        unsigned long long *dbg = (unsigned long long *)((char *)g.bias_part + 49152) + ((long long)blockIdx.x * 8 + wave) * 2;
+        dbg[0] = st_wait; dbg[1] = st_work + (__builtin_amdgcn_s_memtime() - st_t);
+    }
+#endif
     __syncthreads();
     if (do_bias) __syncthreads();                        // the DMA waves' fold of the bias sums
 
@@ -785,8 +822,12 @@ int acg_wgrad_krow_s16_launch(const void *x, const void *dy, float *part, const 
     const long long nimg = g.Mtot / ((long long)g.Hg * g.Wg);
     const long long xbytes = nimg * g.Hin * g.Win * g.Cin * 4, dbytes = g.Mtot * g.Cg * 4;
     ACG_REQUIRE(xbytes < (1LL << 32) && dbytes < (1LL << 32), "wgrad_x3_krow_s16: operand exceeds the 4 GiB buffer-addressing limit");
-    hipLaunchKernelGGL(wgrad_x3_krow_s16, dim3(blocks), dim3(640), 0, st, (const char *)x, (const char *)dy, part, g, (unsigned)xbytes,
-                       (unsigned)dbytes);
+    if (g.reflect)
+        hipLaunchKernelGGL(wgrad_x3_krow_s16<true>, dim3(blocks), dim3(512 + 64 * ACG_KROW_NDW), 0, st, (const char *)x, (const char *)dy, part, g,
+                           (unsigned)xbytes, (unsigned)dbytes);
+    else
+        hipLaunchKernelGGL(wgrad_x3_krow_s16<false>, dim3(blocks), dim3(512 + 64 * ACG_KROW_NDW), 0, st, (const char *)x, (const char *)dy, part, g,
+                           (unsigned)xbytes, (unsigned)dbytes);
     ACG_CHECK_LAUNCH("wgrad_x3_krow_s16");
     acg_note_kernel("wgrad_x3_krow_s16");
     return ACG_OK;

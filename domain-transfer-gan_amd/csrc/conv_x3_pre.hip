@@ -41,6 +41,15 @@ constexpr int NPW = 6;                      // A pieces per producer wave and ke
 constexpr unsigned NO_PIX = 0xFFFFFFFFu;
 }
 
+#ifdef ACG_STAMP
+// diagnostic build only: per consumer wave (barrier wait, rest) cycles of the main loop, [workgroup][wave][2]
+__device__ unsigned long long g_pre_stamps[8192 * 4 * 2];
+extern "C" int acg_debug_pre_stamps(unsigned long long *host, size_t n)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pre_stamps), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 template <bool REFLECT, bool STATS>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
@@ -60,16 +69,19 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
     const int tiles_n = g.ncols_pad / BN;
     const int tile_n = swz % tiles_n, tile_m = swz / tiles_n;
     const int n0 = tile_n * BN;
-    const long long m0 = (long long)tile_m * BM;
+    // 32-bit pixel arithmetic: the launcher bounds the gathered tensor to 4 GiB, i.e. Mtot < 2^25 (64-bit divisions are
+    // ~150 instructions each on this chip, and nine of them per producer thread stood in front of the first DMA of a tile)
+    const int m0 = tile_m * BM;
+    const int Mt = (int)g.Mtot;
     const int GHW = g.GH * g.GW;
     const int S = taps.n * (g.Cin / KC);
 
     if (tid < BM) {
-        const long long m = m0 + tid;
+        const int m = m0 + tid;
         unsigned po = NO_PIX;
-        if (m < g.Mtot) {
-            const int n = (int)(m / GHW);
-            const int r = (int)(m - (long long)n * GHW);
+        if (m < Mt) {
+            const int n = m / GHW;
+            const int r = m - n * GHW;
             const int gy = r / g.GW, gx = r - gy * g.GW;
             po = (unsigned)(((((long long)n * g.Hout + gy) * g.Wout + gx) * g.Cout) >> 2);
             if (g.fold_p > 0) { // reflect data gradient: pixels nothing is mirrored onto bypass the fold
@@ -112,17 +124,18 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
             if (++bt == taps.n) { bt = 0; bc0 += KC; }
         };
         static_assert(BL == 2, "the vmcnt immediates below count 2 * BL = 4 B pieces per stage");
+        dma_b(0);   // the first weight tile is on its way while the patch geometry below is worked out
 
         // The tile's 128 consecutive output pixels form SEGMENTS, one per grid row it touches (the first starts at column
         // x0, the others at 0); segment s occupies image rows [row0(s), row0(s) + len(s) + K-1).  Piece e = pw + 4 j of a
         // kernel row fills 1 KB of parity image e / 11; its lane L holds chunk L % 5 of image row L / 5.
-        const long long grow0 = m0 / g.GW;                     // global grid row (image * GH + gy) of the first pixel
-        const int x0 = (int)(m0 - grow0 * g.GW);
+        const int grow0 = m0 / g.GW;                           // global grid row (image * GH + gy) of the first pixel
+        const int x0 = m0 - grow0 * g.GW;
         const int first = g.GW - x0 < BM ? g.GW - x0 : BM;     // pixels in segment 0
         const int RW = g.GW + kdim - 1;
         const int nseg = first >= BM ? 1 : 1 + (BM - first + g.GW - 1) / g.GW;
         const int nrows = BM + nseg * (kdim - 1);
-        const long long grows = g.Mtot / g.GW;                 // grid rows in the whole tensor
+        const int grows = Mt / g.GW;                           // grid rows in the whole tensor
         int pa_gy[NPW], pa_nb[NPW], pa_lds[NPW];
         unsigned pa_col[NPW];
         bool pa_ok[NPW];
@@ -138,8 +151,8 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
                 seg = 1 + qq / RW;
                 px = qq - (seg - 1) * RW;
             }
-            const long long grow = grow0 + seg;
-            const int n_img = (int)(grow / g.GH);
+            const int grow = grow0 + seg;
+            const int n_img = grow / g.GH;
             int ix = (seg == 0 ? x0 : 0) + px + dxmin;
             bool ok = e < 2 * PPIECES && ch < 4 && row < nrows && grow < grows;
             if (REFLECT) {
@@ -148,7 +161,7 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
             } else {
                 ok = ok && (unsigned)ix < (unsigned)g.Win;
             }
-            pa_gy[j] = (int)(grow - (long long)n_img * g.GH);
+            pa_gy[j] = grow - n_img * g.GH;
             pa_nb[j] = n_img * g.Hin;
             pa_col[j] = (unsigned)(ix * g.Cin * 4 + (q + 2 * (ch >> 1)) * 32 + (ch & 1) * 16);
             pa_ok[j] = ok;
@@ -186,12 +199,16 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
         // this kernel, resblock forward 0.372 ms: no DMA at all after the first row 0.290; weight pieces only 0.311; patch
         // pieces only 0.329; not waiting for the weight pieces 0.340; weight pieces from one cache-hot tile 0.365; patch
         // pieces reading 1 KB contiguous each 0.346 — the loop is paced by the DMA traffic itself, the patch costing more
-        // per byte than the weights, not by the latency of one stage of look-ahead.)
+        // per byte than the weights, not by the latency of one stage of look-ahead.  The patch in two halves behind the B
+        // pieces of the second and third iteration (4, 7, 7 pieces per iteration instead of 4, 10, 4): +-0.  In-kernel stamps
+        // (-DACG_STAMP): a consumer wave's main loop is 67 k cycles per tile = 1 870 per stage, 27 % of it at the barrier;
+        // the two consumer waves of a SIMD need 1 536 matrix cycles per stage, i.e. the loop itself runs the pipe at 82 %
+        // and the tile's set-up and epilogue (a quarter of a tile's 90 k cycles) account for the rest of the 65 % busy.)
         const int rows = S / kdim;
         dma_a(0);
         int pk_k = 0, row = 0;
         for (int s = 0; s < S; ++s) {
-            dma_b(s & 1);
+            if (s > 0) dma_b(s & 1);
             if (pk_k == 1 && row + 1 < rows) {
                 dma_a((row + 1) & 1);
                 asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
@@ -216,7 +233,7 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
     const int pl = lane >> 4, lr = lane & 15;
     int a_base[4]; // byte offset of this lane's hi chunk in row-tile i at tap column 0 (lo: + 16)
     {
-        const int x0c = (int)(m0 % g.GW), firstc = g.GW - x0c < BM ? g.GW - x0c : BM, RWc = g.GW + kdim - 1;
+        const int x0c = m0 % g.GW, firstc = g.GW - x0c < BM ? g.GW - x0c : BM, RWc = g.GW + kdim - 1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int tp = wm * TM + i * 16 + lr;
@@ -255,6 +272,9 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
             }
     };
     const char *pb0 = ldsb + A_BYTES + b_base, *pb1 = pb0 + BBUF;
+#ifdef ACG_STAMP
+    unsigned long long st_wait = 0, st_work = 0, st_t = __builtin_amdgcn_s_memtime();
+#endif
     bool done = false;
     if (kdim == 3 && S % 6 == 0) {
         // 3 x 3 layers: six stages (two kernel rows) per trip, so buffer, tap column and B buffer of every stage are
@@ -264,7 +284,13 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
             for (int it = 0; it < S / 6; ++it) {
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
+#ifdef ACG_STAMP
+                    { const unsigned long long t = __builtin_amdgcn_s_memtime(); st_work += t - st_t; st_t = t; }
+#endif
                     __syncthreads();
+#ifdef ACG_STAMP
+                    { const unsigned long long t = __builtin_amdgcn_s_memtime(); st_wait += t - st_t; st_t = t; }
+#endif
                     const int kx = KS > 0 ? k % 3 : 2 - k % 3;
                     stage(ldsb + (k / 3) * ABUF + kx * PROW, (k & 1) ? pb1 : pb0);
                 }
@@ -284,6 +310,12 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
         }
     }
     __builtin_amdgcn_s_setprio(0);
+#ifdef ACG_STAMP
+    if (lane == 0 && blockIdx.x < 8192) {
+        g_pre_stamps[(blockIdx.x * 4 + wave) * 2] = st_wait;
+        g_pre_stamps[(blockIdx.x * 4 + wave) * 2 + 1] = st_work + (__builtin_amdgcn_s_memtime() - st_t);
+    }
+#endif
     // Epilogue through LDS: the tile (accumulator + bias, activation) is staged in the LDS the main loop no longer needs
     // and leaves in coalesced rows.
     constexpr int TS = BN; // row stride (floats)
@@ -457,7 +489,7 @@ int acg_igemm_x3_pre_launch(const void *in, const void *wp, const float *bias, f
     const long long in_bytes = nimg * g.Hin * g.Win * g.Cin * 4;
     const long long out_bytes = nimg * g.Hout * g.Wout * g.Cout * 4;
     const long long w_bytes = n_w_elems * 2 * 2;
-    ACG_REQUIRE(in_bytes < (1LL << 32) && w_bytes < (1LL << 32) && out_bytes < (1LL << 34),
+    ACG_REQUIRE(in_bytes < (1LL << 32) && w_bytes < (1LL << 32) && out_bytes < (1LL << 34) && g.Mtot < (1LL << 30),
                 "igemm_conv_x3_pre: operand exceeds the buffer-addressing limit");
     ACG_REQUIRE(stats == nullptr || (((long long)g.GH * g.GW) % BM == 0 && g.act == ACG_ACT_NONE && !g.out_s16),
                 "igemm_conv_x3_pre: per-tile statistics need whole 128-pixel tiles per image, no activation, fp32 output");

@@ -111,6 +111,32 @@ def run(N, H, W, C, time_it, iters):
     ok &= check("wgrad: dw (%s vs %s)" % (k1, k0), dw1, dw0)
     ok &= check("wgrad: db (hi + lo vs fp32 sums)", db1, db0, exact=False)
     torch.cuda.synchronize()
+    if os.environ.get("ACG_STAMPS") and N == 32 and hasattr(_lib.load(), "acg_debug_pre_stamps"):
+        import numpy as np
+        for name, f, nwg in (("fwd", fwd_s16, 4096), ("dgrad", dg_s16, 4225)):
+            for _ in range(3):
+                f()
+            torch.cuda.synchronize()
+            buf = (ctypes.c_ulonglong * (nwg * 8))()
+            assert _lib.load().acg_debug_pre_stamps(buf, nwg * 8) == 0
+            raw = np.frombuffer(buf, dtype=np.uint64).reshape(nwg, 4, 2).astype(np.float64)
+            wait, work = raw[..., 0], raw[..., 1]
+            print("%s consumer stamps: loop cycles per wave %.0f, barrier wait share %.1f %% (by wave %s)"
+                  % (name, (wait + work).mean(), 100 * wait.sum() / (wait + work).sum(), np.round(100 * (wait / (wait + work)).mean(0), 1)))
+    if os.environ.get("ACG_STAMPS"):   # diagnostic library (-DACG_STAMP): per-wave (barrier wait, rest) cycles of the main loop
+        import numpy as np
+        for _ in range(5):
+            wg_s16()
+        torch.cuda.synchronize()
+        need = 85 * 9 * C * C * 4 if N == 32 else None
+        if need is not None:
+            off = (need + 255) // 256 * 256 + 49152
+            raw = ws[off: off + 255 * 8 * 16].view(torch.int64).cpu().numpy().reshape(255, 8, 2)
+            wait, work = raw[..., 0].astype(np.float64), raw[..., 1].astype(np.float64)
+            print("stamps (cycles per wave over the whole loop): wait mean %.0f  work mean %.0f  -> wait share %.1f %%; per-wave wait share min %.1f max %.1f"
+                  % (wait.mean(), work.mean(), 100 * wait.sum() / (wait.sum() + work.sum()),
+                     100 * (wait / (wait + work)).min(), 100 * (wait / (wait + work)).max()))
+            print("wait share by wave index:", np.round(100 * (wait / (wait + work)).mean(0), 1))
     if not time_it:
         return ok
     flops = 2.0 * N * H * W * C * C * 9
