@@ -43,7 +43,7 @@ constexpr unsigned NO_PIX = 0xFFFFFFFFu;
 
 #ifdef ACG_STAMP
 // diagnostic build only: per consumer wave (barrier wait, rest) cycles of the main loop, [workgroup][wave][2]
-__device__ unsigned long long g_pre_stamps[8192 * 4 * 2];
+__device__ unsigned long long g_pre_stamps[8192 * 8 * 3];   // [workgroup][wave][3]
 extern "C" int acg_debug_pre_stamps(unsigned long long *host, size_t n)
 {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pre_stamps), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
@@ -207,17 +207,35 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
         const int rows = S / kdim;
         dma_a(0);
         int pk_k = 0, row = 0;
+#ifdef ACG_STAMP
+        unsigned long long p_issue = 0, p_land = 0, p_bar = 0, p_t = __builtin_amdgcn_s_memtime();
+#define PSTAMP(acc) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - p_t; p_t = t_; }
+#else
+#define PSTAMP(acc)
+#endif
         for (int s = 0; s < S; ++s) {
             if (s > 0) dma_b(s & 1);
             if (pk_k == 1 && row + 1 < rows) {
                 dma_a((row + 1) & 1);
+                PSTAMP(p_issue)
                 asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             } else {
+                PSTAMP(p_issue)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            PSTAMP(p_land)
             if (++pk_k == kdim) { pk_k = 0; ++row; }
             __builtin_amdgcn_s_barrier();
+            PSTAMP(p_bar)
         }
+#ifdef ACG_STAMP
+        if (lane == 0 && blockIdx.x < 8192) {
+            g_pre_stamps[(blockIdx.x * 8 + wave) * 3] = p_issue;
+            g_pre_stamps[(blockIdx.x * 8 + wave) * 3 + 1] = p_land;
+            g_pre_stamps[(blockIdx.x * 8 + wave) * 3 + 2] = p_bar;
+        }
+#endif
+#undef PSTAMP
         return;
     }
 
@@ -312,8 +330,9 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
     __builtin_amdgcn_s_setprio(0);
 #ifdef ACG_STAMP
     if (lane == 0 && blockIdx.x < 8192) {
-        g_pre_stamps[(blockIdx.x * 4 + wave) * 2] = st_wait;
-        g_pre_stamps[(blockIdx.x * 4 + wave) * 2 + 1] = st_work + (__builtin_amdgcn_s_memtime() - st_t);
+        g_pre_stamps[(blockIdx.x * 8 + wave) * 3] = st_wait;
+        g_pre_stamps[(blockIdx.x * 8 + wave) * 3 + 1] = st_work + (__builtin_amdgcn_s_memtime() - st_t);
+        g_pre_stamps[(blockIdx.x * 8 + wave) * 3 + 2] = 0;
     }
 #endif
     // Epilogue through LDS: the tile (accumulator + bias, activation) is staged in the LDS the main loop no longer needs

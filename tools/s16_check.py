@@ -117,12 +117,16 @@ def run(N, H, W, C, time_it, iters):
             for _ in range(3):
                 f()
             torch.cuda.synchronize()
-            buf = (ctypes.c_ulonglong * (nwg * 8))()
-            assert _lib.load().acg_debug_pre_stamps(buf, nwg * 8) == 0
-            raw = np.frombuffer(buf, dtype=np.uint64).reshape(nwg, 4, 2).astype(np.float64)
-            wait, work = raw[..., 0], raw[..., 1]
+            buf = (ctypes.c_ulonglong * (nwg * 24))()
+            assert _lib.load().acg_debug_pre_stamps(buf, nwg * 24) == 0
+            raw = np.frombuffer(buf, dtype=np.uint64).reshape(nwg, 8, 3).astype(np.float64)
+            wait, work = raw[:, :4, 0], raw[:, :4, 1]
             print("%s consumer stamps: loop cycles per wave %.0f, barrier wait share %.1f %% (by wave %s)"
                   % (name, (wait + work).mean(), 100 * wait.sum() / (wait + work).sum(), np.round(100 * (wait / (wait + work)).mean(0), 1)))
+            pr = raw[:, 4:, :]
+            tot = pr.sum(-1).mean()
+            print("%s producer stamps: loop cycles per wave %.0f: issuing %.1f %%, waiting for the pieces to land %.1f %%, at the barrier %.1f %%"
+                  % (name, tot, 100 * pr[..., 0].mean() / tot, 100 * pr[..., 1].mean() / tot, 100 * pr[..., 2].mean() / tot))
     if os.environ.get("ACG_STAMPS"):   # diagnostic library (-DACG_STAMP): per-wave (barrier wait, rest) cycles of the main loop
         import numpy as np
         for _ in range(5):
