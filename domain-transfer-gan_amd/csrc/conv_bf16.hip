@@ -19,7 +19,14 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // SPLIT: operands as bf16 hi + lo, products hi*hi + hi*lo + lo*hi (fp32-grade: ~2^-16 per product).  The lo images
 // live behind the hi images in LDS; packed weights carry their lo part at +w_lo_off elements.
-template <int BM, int BN, int WM, int WN, int KC, bool REFLECT, bool SPLIT>
+//
+// RP ("row patch", stride-1 gathers on grids whose rows are whole tiles): a stage is one ROW of the kernel instead of one
+// tap.  The tile's 128 output pixels are consecutive in x, so the taps (ty, tx0 .. tx0 + 2) read the same BM + 2 input
+// pixels shifted by one row of the LDS image each: the patch is fetched, split and stored once per kernel row (a 3x3 layer:
+// 3 instead of 9 passes over the input through L2, a third of the barriers), and the MFMAs of the row's taps read it at
+// row offsets 0 / 1 / 2 — 16 bytes in the [k8][row][8] planes, which keeps ds_read_b128 aligned and conflict-free.  Taps
+// are consumed in list order, so every accumulator sees the MFMA sequence of the tap-per-stage kernel: bit-identical.
+template <int BM, int BN, int WM, int WN, int KC, bool REFLECT, bool SPLIT, bool RP = false>
 __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__ in, const __bf16 *__restrict__ wp,
                                                        const float *__restrict__ bias, float *__restrict__ out,
                                                        Geom g, Taps taps, unsigned in_bytes, unsigned w_bytes,
@@ -38,14 +45,18 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
     // cycles by SQ_LDS_BANK_CONFLICT).  ds_write_b128 goes by 8 contiguous lanes over a 128-B bank row: the plane
     // pads put the (rows x planes) / (columns x 2 planes) that a lane group stores on 8 distinct slots.
     constexpr int NK8 = KC / 8;
-    constexpr int APL = BM * 8 + (NK8 == 4 ? 16 : NK8 == 8 ? 8 : 32), BPL = BN * 8 + 32; // plane strides (bf16 elements)
+    constexpr int NTX = RP ? 3 : 1;          // taps per stage
+    constexpr int ALX = RP ? AL + 1 : AL;    // gather passes per stage (row patch: one more for the NTX - 1 extra pixels)
+    // plane strides (bf16 elements); the row patch's BM + 2 rows of 16 B are the same 2080 B as the padded BM rows of KC = 32
+    constexpr int APL = RP ? (BM + NTX - 1) * 8 : BM * 8 + (NK8 == 4 ? 16 : NK8 == 8 ? 8 : 32), BPL = BN * 8 + 32;
     static_assert(WM * WN == 4 && AL >= 1 && MB >= 1 && NB >= 1, "tile config");
+    static_assert(!RP || KC == 32, "row-patch stages are 32 channels deep");
 
     constexpr int NIMG = SPLIT ? 2 : 1;
     constexpr int A_IMG = NK8 * APL, B_IMG = NK8 * BPL; // one hi (or lo) image
     __shared__ __attribute__((aligned(16))) __bf16 As[NIMG * A_IMG];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[NIMG * B_IMG];
-    __shared__ long long out_off[BM];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[NTX * NIMG * B_IMG];
+    __shared__ __attribute__((aligned(16))) unsigned out_rel[BM];  // byte offset of a tile row's output pixel from the tile's first, ~0u: no such pixel
     __shared__ float sred[WM * BN];   // cross-wave fold of the per-tile statistics (Geom.stats)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -91,17 +102,14 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
         b_voff[i] = (unsigned)(((kc * g.ncols_pad + n0) * 16 + rem * 8) * 2);
         b_lds[i] = (kc * 2 + (rem & 1)) * BPL + (rem >> 1) * 8; // chunk = (column rem/2, k-half rem&1)
     }
-    if (tid < BM) {
-        const long long m = m0 + tid;
-        long long off = -1;
-        if (m < g.Mtot) {
-            const int n = (int)(m / GHW);
-            const int r = (int)(m - (long long)n * GHW);
-            const int gy = r / g.GW, gx = r - gy * g.GW;
-            off = (((long long)n * g.Hout + (gy * g.os + oy0)) * g.Wout + (gx * g.os + ox0)) * g.Cout;
-        }
-        out_off[tid] = off;
-    }
+    auto pix_off = [&](long long m) { // element offset of grid position m's output pixel
+        const int n = (int)(m / GHW);
+        const int r = (int)(m - (long long)n * GHW);
+        const int gy = r / g.GW, gx = r - gy * g.GW;
+        return (((long long)n * g.Hout + (gy * g.os + oy0)) * g.Wout + (gx * g.os + ox0)) * g.Cout;
+    };
+    const long long off0 = pix_off(m0);   // uniform; the rows of a tile lie less than 4 GiB behind it
+    if (tid < BM) out_rel[tid] = m0 + tid < g.Mtot ? (unsigned)((pix_off(m0 + tid) - off0) * 4) : ~0u;
 
     f32x16 acc[MB][NB];
 #pragma unroll
@@ -111,11 +119,59 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int S = ntap * (g.Cin / KC);
-    f32x8 ra[AL];
-    u32x4 rb[BL], rbl[BL]; // 8 bf16 each (hi, lo)
+    // row patch: the tile is pixels gx0 .. gx0 + BM - 1 of row gy0 of image img; stage = (channel chunk, tap group)
+    const int img = (int)(m0 / GHW), gy0 = (int)(m0 - (long long)img * GHW) / g.GW, gx0 = (int)(m0 - (long long)img * GHW) - gy0 * g.GW;
+    const int ngrp = RP ? (taps.ngrp >> (8 * ph)) & 0xff : 0;
+    const int S = (RP ? ngrp : ntap) * (g.Cin / KC);
+    f32x8 ra[ALX];
+    u32x4 rb[NTX][BL], rbl[NTX][BL]; // 8 bf16 each (hi, lo)
 
     auto load_stage = [&](int s) {
+        if constexpr (RP) {
+            const int cc = s / ngrp;
+            const int c0 = cc * KC;
+            const int gd = taps.gpk[ph * 16 + (s - cc * ngrp)]; // first tap | taps << 8 | smallest dx << 16
+            const int first = tbase + (gd & 0xff), nt = (gd >> 8) & 0xff, tx0 = (gd << 8) >> 24;
+            const int pk0 = taps.pk[first];
+            int iy = gy0 + ((pk0 << 24) >> 24);
+            bool rok = true;
+            if (REFLECT) {
+                iy = iy < 0 ? -iy : iy;
+                iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
+            } else {
+                rok = (unsigned)iy < (unsigned)g.Hin;
+            }
+            const int rowbase = (img * g.Hin + iy) * g.Win;
+#pragma unroll
+            for (int j = 0; j < ALX; ++j) {
+                int ix = gx0 + tx0 + rrow + RPP * j;
+                bool ok = rok && (j < AL || rrow < nt - 1);
+                if (REFLECT) {
+                    ix = ix < 0 ? -ix : ix;
+                    ix = ix >= g.Win ? 2 * (g.Win - 1) - ix : ix;
+                } else {
+                    ok = ok && (unsigned)ix < (unsigned)g.Win;
+                }
+                const unsigned off = (unsigned)((rowbase + ix) * g.Cin + c0 + 8 * u) * 4u;
+                const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off, ok), 0, 0);
+                const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off + 16u, ok), 0, 0);
+                const f32x4 flo = __builtin_bit_cast(f32x4, lo), fhi = __builtin_bit_cast(f32x4, hi);
+                ra[j] = (f32x8){flo[0], flo[1], flo[2], flo[3], fhi[0], fhi[1], fhi[2], fhi[3]};
+            }
+#pragma unroll
+            for (int q = 0; q < NTX; ++q)
+                if (q < nt) {
+                    const int tw = taps.pk[first + q] >> 16;
+                    const unsigned soff = (unsigned)(((tw * (g.Cin >> 4) + (c0 >> 4)) * g.ncols_pad) * 16) * 2u;
+#pragma unroll
+                    for (int i = 0; i < BL; ++i)
+                        if (tid + 256 * i < BCH) {
+                            rb[q][i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[i], soff, 0);
+                            if (SPLIT) rbl[q][i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[i], soff + w_lo_bytes, 0);
+                        }
+                }
+            return;
+        }
         const int cc = s / ntap;
         const int t = s - cc * ntap;
         const int c0 = cc * KC;
@@ -147,16 +203,22 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
 #pragma unroll
         for (int i = 0; i < BL; ++i)
             if (tid + 256 * i < BCH) {
-                rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[i], soff, 0);
-                if (SPLIT) rbl[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[i], soff + w_lo_bytes, 0);
+                rb[0][i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[i], soff, 0);
+                if (SPLIT) rbl[0][i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[i], soff + w_lo_bytes, 0);
             }
     };
 
     load_stage(0);
     for (int s = 0; s < S; ++s) {
+        int gfirst = 0, gnt = 1, gtx0 = 0;   // this stage's tap group (row patch)
+        if constexpr (RP) {
+            const int gd = taps.gpk[ph * 16 + s % ngrp];
+            gfirst = tbase + (gd & 0xff); gnt = (gd >> 8) & 0xff; gtx0 = (gd << 8) >> 24;
+        }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < AL; ++j) {
+        for (int j = 0; j < ALX; ++j) {
+            if (RP && j == AL && rrow >= NTX - 1) continue;
             const int a_at = u * APL + (rrow + RPP * j) * 8;
             const float v[8] = {ra[j][0], ra[j][1], ra[j][2], ra[j][3], ra[j][4], ra[j][5], ra[j][6], ra[j][7]};
             if (SPLIT) {
@@ -169,25 +231,35 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
             }
         }
 #pragma unroll
-        for (int i = 0; i < BL; ++i)
-            if (tid + 256 * i < BCH) {
-                *(u32x4 *)&Bs[b_lds[i]] = rb[i];
-                if (SPLIT) *(u32x4 *)&Bs[B_IMG + b_lds[i]] = rbl[i];
+        for (int q = 0; q < NTX; ++q)
+            if (q < gnt) {
+#pragma unroll
+                for (int i = 0; i < BL; ++i)
+                    if (tid + 256 * i < BCH) {
+                        *(u32x4 *)&Bs[q * NIMG * B_IMG + b_lds[i]] = rb[q][i];
+                        if (SPLIT) *(u32x4 *)&Bs[q * NIMG * B_IMG + B_IMG + b_lds[i]] = rbl[q][i];
+                    }
             }
         __syncthreads();
         if (s + 1 < S) load_stage(s + 1);
+        // (a run-time trip count on purpose: with `if (q < gnt)` bodies the accumulators are merged through VGPRs and every
+        // tap pays 2 x 32 v_accvgpr moves)
+#pragma unroll 1
+        for (int q = 0; q < gnt; ++q) {
+        // row patch: tap q of the group reads the patch (its dx - the group's smallest dx) rows further on
+        const int dxo = RP ? ((taps.pk[gfirst + q] << 16) >> 24) - gtx0 : 0;
 #pragma unroll
         for (int kc = 0; kc < NKC; ++kc) {
             bf16x8 a[MB], b[NB], al[MB], bl[NB];
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
-                const int at = (kc * 2 + (lane >> 5)) * APL + (wm * TM + i * 32 + (lane & 31)) * 8;
+                const int at = (kc * 2 + (lane >> 5)) * APL + (wm * TM + i * 32 + (lane & 31) + dxo) * 8;
                 a[i] = *(const bf16x8 *)&As[at];
                 if (SPLIT) al[i] = *(const bf16x8 *)&As[A_IMG + at];
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                const int bt = (kc * 2 + (lane >> 5)) * BPL + (wn * TN + j * 32 + (lane & 31)) * 8;
+                const int bt = q * NIMG * B_IMG + (kc * 2 + (lane >> 5)) * BPL + (wn * TN + j * 32 + (lane & 31)) * 8;
                 b[j] = *(const bf16x8 *)&Bs[bt];
                 if (SPLIT) bl[j] = *(const bf16x8 *)&Bs[B_IMG + bt];
             }
@@ -201,6 +273,7 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
                     }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
                 }
+        }
         }
     }
 
@@ -248,34 +321,100 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
             __syncthreads();
         }
     }
+    // Stores: 32 lanes x 4 B = one 128-byte line of an output pixel per half wave.  Branch-free: bias and activation in a
+    // pass over the accumulators, then buffer stores relative to the tile's first pixel whose masked lanes (no such row /
+    // column) carry an out-of-range offset — a predicated 64-bit store per element cost ~45 instructions and a branch.
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int co = n0 + wn * TN + j * 32 + (lane & 31);
-        const bool cok = co < g.Cout;
-        const float bv = (bias != nullptr && cok) ? bias[co] : 0.f;
+        const float bv = (bias != nullptr && co < g.Cout) ? bias[co] : 0.f;
+        if (g.act == ACG_ACT_NONE) {
 #pragma unroll
-        for (int i = 0; i < MB; ++i) {
+            for (int i = 0; i < MB; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const long long off = out_off[row];
-                if (cok && off >= 0) out[off + co] = acg_apply_act(acc[i][j][r] + bv, g.act);
-            }
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += bv;
+        } else if (g.act == ACG_ACT_RELU) {
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] + bv > 0.f ? acc[i][j][r] + bv : 0.f;
+        } else if (g.act == ACG_ACT_LRELU) {
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] + bv > 0.f ? acc[i][j][r] + bv : 0.2f * (acc[i][j][r] + bv);
+        } else {
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = acg_apply_act(acc[i][j][r] + bv, g.act);
         }
     }
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)(out + off0), 0, 0xFFFFFFF0u, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            // accumulator registers 4 r4 .. 4 r4 + 3 are tile rows 8 r4 + 4 (lane >> 5) + 0 .. 3
+            const u32x4 rel = *(const u32x4 *)&out_rel[wm * TM + i * 32 + 8 * r4 + 4 * (lane >> 5)];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int co = n0 + wn * TN + j * 32 + (lane & 31);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#ifdef ACG_ABL_NOSTORE   // diagnostic build: keep the arithmetic alive, store (almost) nothing
+                    const bool ok = rel[q] != ~0u && co < g.Cout && acc[i][j][4 * r4 + q] == 12345.678f;
+#else
+                    const bool ok = rel[q] != ~0u && co < g.Cout;
+#endif
+                    const float v = acc[i][j][4 * r4 + q]; // (a bit cast of the vector-element lvalue itself reads element 0)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rout, acg_masked_off(rel[q] + (unsigned)co * 4u, ok), 0, 0);
+                }
+            }
+        }
 }
 
-template <int KC, bool REFLECT, bool SPLIT>
+template <int KC, bool REFLECT, bool SPLIT, bool RP = false>
 static void launch_bf16_kc(int bn, dim3 grid, hipStream_t st, const float *in, const __bf16 *wp, const float *bias,
                            float *out, const Geom &g, const Taps &t, unsigned inb, unsigned wb, unsigned wlo)
 {
     dim3 block(256);
     if (bn == 128)
-        hipLaunchKernelGGL((igemm_conv_bf16<128, 128, 2, 2, KC, REFLECT, SPLIT>), grid, block, 0, st, in, wp, bias, out, g, t, inb, wb, wlo);
+        hipLaunchKernelGGL((igemm_conv_bf16<128, 128, 2, 2, KC, REFLECT, SPLIT, RP>), grid, block, 0, st, in, wp, bias, out, g, t, inb, wb, wlo);
     else if (bn == 64)
-        hipLaunchKernelGGL((igemm_conv_bf16<128, 64, 2, 2, KC, REFLECT, SPLIT>), grid, block, 0, st, in, wp, bias, out, g, t, inb, wb, wlo);
+        hipLaunchKernelGGL((igemm_conv_bf16<128, 64, 2, 2, KC, REFLECT, SPLIT, RP>), grid, block, 0, st, in, wp, bias, out, g, t, inb, wb, wlo);
     else
-        hipLaunchKernelGGL((igemm_conv_bf16<128, 32, 4, 1, KC, REFLECT, SPLIT>), grid, block, 0, st, in, wp, bias, out, g, t, inb, wb, wlo);
+        hipLaunchKernelGGL((igemm_conv_bf16<128, 32, 4, 1, KC, REFLECT, SPLIT, RP>), grid, block, 0, st, in, wp, bias, out, g, t, inb, wb, wlo);
+}
+
+// Row-patch stages (see the kernel): do the tap lists of this launch decompose into runs of <= 3 taps on one input row, and
+// is every tile 128 consecutive pixels of one grid row?  Fills t.gpk / t.ngrp.
+static bool rp_groups(const Geom &g, Taps &t)
+{
+    // (the four sub-pixel phases of a stride-2 data gradient have 1 / 2 / 2 / 4 taps: too little to share for the bigger
+    // LDS image and the lower occupancy — measured 0.48 -> 0.54 ms on the 128 -> 64 channel layers)
+    if (g.is != 1 || g.GW % 128 != 0 || g.Mtot % 128 != 0 || g.Cin % 32 != 0 || g.thin || g.nphase) return false;
+    t.ngrp = 0;
+    bool shared = false;
+    const int nph = g.nphase ? 4 : 1;
+    for (int ph = 0; ph < nph; ++ph) {
+        const int base = g.nphase ? 16 * ph : 0, ntap = g.nphase ? (g.ph_ntaps >> (8 * ph)) & 0xff : t.n;
+        int ng = 0;
+        for (int i = 0; i < ntap;) {
+            int j = i + 1, lo = t.dx[base + i], hi = lo;
+            while (j < ntap && j - i < 3 && t.dy[base + j] == t.dy[base + i]) {
+                const int d = t.dx[base + j], l2 = d < lo ? d : lo, h2 = d > hi ? d : hi;
+                if (h2 - l2 > 2) break;
+                lo = l2; hi = h2; ++j;
+            }
+            if (ng == 16 || i > 255 || lo < -128 || lo > 127) return false;
+            t.gpk[16 * ph + ng++] = i | ((j - i) << 8) | ((lo & 0xff) << 16);
+            i = j;
+        }
+        shared |= ng < ntap;
+        t.ngrp |= ng << (8 * ph);
+    }
+    return shared; // one tap per stage everywhere: nothing to share
 }
 
 // does this launch go to the wave-specialised bf16x3 kernel (conv_x3.hip)?  128-column tiles, 32-channel stages
@@ -320,6 +459,15 @@ int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, fl
     ACG_REQUIRE(g0.stats == nullptr || (((long long)g0.GH * g0.GW) % 128 == 0 && g0.act == ACG_ACT_NONE && g0.Mtot % 128 == 0),
                 "igemm_conv_bf16: per-tile statistics need whole 128-pixel tiles per image and no activation");
     ACG_REQUIRE(g0.fold_p == 0, "igemm_conv_bf16: the fold bypass is implemented by the wave-specialised kernel only");
+    static const bool no_rp = acg_debug_switch("ACG_NO_RP"); // A/B switch
+    Taps tr = t;
+    if (!no_rp && split && rp_groups(g, tr)) {
+        if (g.reflect) launch_bf16_kc<32, true, true, true>(bn, grid, st, in, w, bias, out, g, tr, inb, wb, wlo);
+        else launch_bf16_kc<32, false, true, true>(bn, grid, st, in, w, bias, out, g, tr, inb, wb, wlo);
+        ACG_CHECK_LAUNCH("igemm_conv_bf16 (row patch)");
+        acg_note_kernel("igemm_conv_bf16<128,%d,KC=32,REFLECT=%d,SPLIT=1,RP=1>", bn, g.reflect ? 1 : 0);
+        return ACG_OK;
+    }
     if (split) { // hi+lo images double the LDS: 32-channel stages keep 3-4 blocks per CU
         if (g.Cin % 32 == 0) BF16_DISPATCH(32, true);
         else BF16_DISPATCH(16, true);

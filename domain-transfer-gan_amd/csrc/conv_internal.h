@@ -13,6 +13,11 @@ struct Taps {
     // (16-bit array elements go through vector memory and leave the weight-slab offset in a VGPR).  Filled by
     // acg_taps_pack() in the launchers.
     int pk[64];
+    // row-patch stages of the generic bf16 tile (conv_bf16.hip, filled by its launcher): runs of up to 3 consecutive taps
+    // with one dy and dx values within a span of 3.  gpk[16 ph + i] = first tap (relative to the phase's first) | taps << 8 |
+    // (smallest dx & 0xff) << 16; ngrp = the group counts of the (up to four) phases, one byte each
+    int gpk[64];
+    int ngrp;
 };
 
 static inline Taps acg_taps_pack(const Taps &t)

@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override N of every shape")
     ap.add_argument("--mark", action="store_true")
     ap.add_argument("--json", default="")
+    ap.add_argument("--digest", action="store_true", help="seeded inputs; print a bit-pattern checksum of every output (A/B of two builds / switches)")
     a = ap.parse_args()
     dev = torch.device("cuda")
     ops.set_precision(a.precision)
@@ -56,6 +57,8 @@ def main():
         if a.only and not any(o in name for o in a.only.split(",")):
             continue
         N = a.batch or N
+        if a.digest:
+            torch.manual_seed(1234)
         d = ops.conv_desc(N, H, W, Ci, Co, K, s, p, mode, Cir, Cor)
         x = torch.randn((N, H, W, Ci), device=dev)           # conv-input side
         dy = torch.randn((N, d.Ho, d.Wo, Co), device=dev)    # conv-output side
@@ -102,6 +105,9 @@ def main():
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / a.iters
             kern = _lib.query("acg_last_kernel").decode()
+            if a.digest:
+                outs = {"fwd": (dx if tr else y,), "dgrad": (y if tr else dx,), "wgrad": (dw, db)}[what]
+                print("    digest %s %s: %s  [%s]" % (name, what, " ".join("%016x" % (int(o.contiguous().view(torch.int32).to(torch.int64).sum().item()) & (2 ** 64 - 1)) for o in outs), kern), flush=True)
             segs.append(dict(layer=name, what=what, ms=ms, iters=a.iters, flops=flops, algorithmic_bytes=algo,
                              stored_bytes=stored, last_kernel=kern))
             line += " | %s %7.3f ms %6.1f TF %5.2f TB/s" % (what, ms, flops / ms / 1e9, algo / ms / 1e9)

@@ -123,6 +123,10 @@ def run(N, H, W, C, time_it, iters):
             wait, work = raw[:, :4, 0], raw[:, :4, 1]
             print("%s consumer stamps: loop cycles per wave %.0f, barrier wait share %.1f %% (by wave %s)"
                   % (name, (wait + work).mean(), 100 * wait.sum() / (wait + work).sum(), np.round(100 * (wait / (wait + work)).mean(0), 1)))
+            ebuf = (ctypes.c_ulonglong * nwg)()
+            assert _lib.load().acg_debug_pre_epi(ebuf, nwg) == 0
+            epi = np.frombuffer(ebuf, dtype=np.uint64).astype(np.float64)
+            print("%s tile: set-up %.0f cycles (entry -> first stage), loop %.0f, epilogue %.0f" % (name, raw[:, :4, 2].mean(), (wait + work).mean(), epi.mean()))
             pr = raw[:, 4:, :]
             tot = pr.sum(-1).mean()
             print("%s producer stamps: loop cycles per wave %.0f: issuing %.1f %%, waiting for the pieces to land %.1f %%, at the barrier %.1f %%"
