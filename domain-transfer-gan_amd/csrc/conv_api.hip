@@ -75,7 +75,7 @@ __global__ void pack_weight_bf16_kernel(const float *__restrict__ w, int Or, int
 {
     const int KK = K * K;
     const long long nf = (long long)KK * (Ci / 16) * CoP * 16;
-    const long long nb = (long long)KK * (Co / 16) * CiP * 16;
+    const long long nb = (long long)(KK + (K == 3 ? 3 : 0)) * (Co / 16) * CiP * 16; // wb_slabs(K)
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nf + nb;
          i += (long long)gridDim.x * blockDim.x) {
         if (i < nf) {
@@ -98,7 +98,11 @@ __global__ void pack_weight_bf16_kernel(const float *__restrict__ w, int Or, int
             const int cb = (int)(r % (Co / 16)); r /= (Co / 16);
             const int tap = (int)r;
             const int co = cb * 16 + c16;
-            const float v = (co < Or && ci < Ir) ? w[((long long)co * Ir + ci) * KK + tap] : 0.f;
+            float v = 0.f;
+            if (co < Or && ci < Ir) {
+                const float *wv = w + ((long long)co * Ir + ci) * KK;
+                v = tap < KK ? wv[tap] : wv[tap - KK] + wv[6 + tap - KK]; // slab 9 + kw: kernel rows 0 and 2 together
+            }
             const __bf16 hi = (__bf16)v;
             wb[i - nf] = hi;
             if (split) wb[nb + i - nf] = (__bf16)(v - (float)hi);
@@ -252,7 +256,10 @@ static int thin_out_launch(const float *in, const float *wn, const float *bias, 
 }
 
 extern "C" size_t acg_packed_wf_elems(int K, int Ci, int Co) { return (size_t)K * K * (Ci / 8) * acg_ncols_pad(Co) * 8; }
-extern "C" size_t acg_packed_wb_elems(int K, int Ci, int Co) { return (size_t)K * K * (Co / 8) * acg_ncols_pad(Ci) * 8; }
+// K == 3: three more slabs behind the nine taps, 9 + kw = w[0][kw] + w[2][kw] (bf16 packings only): what the kernel row that
+// reads a mirrored row uses in the un-padded data gradient of a reflection-padded layer (Geom.unpad)
+static inline int wb_slabs(int K) { return K * K + (K == 3 ? 3 : 0); }
+extern "C" size_t acg_packed_wb_elems(int K, int Ci, int Co) { return (size_t)wb_slabs(K) * (Co / 8) * acg_ncols_pad(Ci) * 8; }
 
 extern "C" int acg_pack_conv_weight(const float *w, int Or, int Ir, int K, int Ci, int Co, float *wf, float *wb,
                                     void *stream)
@@ -671,6 +678,65 @@ static void fwd_geom(const acg_conv_desc *d, Geom *g, Taps *t, int act)
         }
 }
 
+// Column part of the reflect adjoint for the un-padded data gradient (Geom.unpad): pad column -1 mirrors onto column 1, pad
+// column W onto column W-2, i.e. dx[y][1] += sum_kh dy[y + 1 - kh][0] . w[kh][0] and dx[y][W-2] += sum_kh dy[y + 1 - kh][W-1] .
+// w[kh][2] (rows outside the map are zero; rows 1 and H-2 also receive the corner terms dy[0] . w[0][.] / dy[H-1] . w[2][.]
+// their own mirrored rows carry).  A (N H 2) x (3 C) x C GEMM, 0.4 % of the layer: one 32x32x16 MFMA tile per wave, both
+// operands read straight into fragment layout — a pre-split pixel's 8-channel group IS an A fragment, 8 consecutive output
+// channels of a packed-wb row ARE a B fragment — same bf16x3 products as the main kernel.
+// grid (N * H / 32, 2, CiP / 128) x 256 threads: 32 rows of one image, one side, wave w = dx channels 32w .. 32w+31 of 128.
+typedef __bf16 cf_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void dgrad_colfix_kernel(const char *__restrict__ dy, const __bf16 *__restrict__ wb,
+                                                           long long w_lo_elems, float *__restrict__ colfix, int H, int W,
+                                                           int C, int CiP, int Cdx)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tiles = H / 32, n = blockIdx.x / tiles, qy0 = (blockIdx.x - n * tiles) * 32, side = blockIdx.y;
+    const int lr = lane & 31, kg = lane >> 5;
+    const int qy = qy0 + lr, ci = blockIdx.z * 128 + wave * 32 + lr;
+    const int col = side ? W - 1 : 0, kw = side ? 2 : 0;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const cf_bf16x8 zero = {};
+    const int nch = C / 16;
+    // kernel rows 0..2, then the corner term of the tile that holds row 1 (kh 0, dy row 0) or row H-2 (kh 2, dy row H-1)
+    const int extra = qy0 == 0 ? 0 : (qy0 + 32 == H ? 2 : -1);
+    for (int step = 0; step < 3 + (extra >= 0 ? 1 : 0); ++step) {
+        const int kh = step < 3 ? step : extra;
+        int ry;
+        bool ok;
+        if (step < 3) { ry = qy + 1 - kh; ok = (unsigned)ry < (unsigned)H; }
+        else { ry = extra == 0 ? 0 : H - 1; ok = qy == (extra == 0 ? 1 : H - 2); }
+        const char *ap = dy + (((long long)n * H + (ok ? ry : 0)) * W + col) * C * 4 + kg * 32;
+        const __bf16 *bp = wb + ((long long)(kh * 3 + kw) * nch * CiP + ci) * 16 + kg * 8;
+        for (int c0 = 0; c0 < nch; c0 += 4) { // four 16-channel chunks per trip (C % 64 == 0), their loads issued together
+            cf_bf16x8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int cc = c0 + u;
+                ah[u] = zero; al[u] = zero;
+                if (ok) { ah[u] = *(const cf_bf16x8 *)(ap + cc * 64); al[u] = *(const cf_bf16x8 *)(ap + cc * 64 + 16); }
+                bh[u] = *(const cf_bf16x8 *)(bp + (long long)cc * CiP * 16);
+                bl[u] = *(const cf_bf16x8 *)(bp + w_lo_elems + (long long)cc * CiP * 16);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[u], bh[u], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], bl[u], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], bh[u], acc, 0, 0, 0);
+            }
+        }
+    }
+    if (ci < Cdx) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kg;
+            colfix[(((long long)n * H + qy0 + row) * 2 + side) * Cdx + ci] = acc[r];
+        }
+    }
+}
+
 // data gradient (and ConvTranspose forward): gathers from the conv-OUTPUT side tensor `src`
 // (N,Ho,Wo,Co) with packed wb, writes the conv-INPUT side tensor `dst` (N,Hi,Wi,Ci).
 // addend (optional): tensor of dst's shape added to the result; only the frame path below implements it
@@ -708,6 +774,26 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
         g.Hout = d->Hi + 2 * e; g.Wout = d->Wi + 2 * e; g.GH = g.Hout; g.GW = g.Wout;
         g.os = 1; g.oy0 = 0; g.ox0 = 0;
         g.Mtot = (long long)d->N * g.GH * g.GW;
+        // Pre-split operands, 3x3, pad 1, rows that are whole tiles: the un-padded grid (Geom.unpad) — 3 % fewer tiles than the
+        // padded grid, one row segment per tile, and the fold pass over the frame goes away
+        static const bool no_unpad = acg_debug_switch("ACG_NO_UNPAD");   // A/B switch
+        if (!no_unpad && refl && in_s16 && K == 3 && p == 1 && d->Wi % 128 == 0 && d->Hi % 32 == 0 && d->Hi >= 64 && dgrad_frame_ok(d, g)) {
+            g.Hout = d->Hi; g.Wout = d->Wi; g.GH = d->Hi; g.GW = d->Wi;
+            g.Mtot = (long long)d->N * g.GH * g.GW;
+            t.n = 0;
+            for (int kh = 0; kh < K; ++kh)
+                for (int kw = 0; kw < K; ++kw) { t.dy[t.n] = (short)(p - kh); t.dx[t.n] = (short)(p - kw); t.w[t.n] = (short)(kh * K + kw); t.n++; }
+            ACG_REQUIRE(acg_igemm_x3_pre_ok(g, t) && (relu_s16 == 0 || out_s16) && (out_s16 == 0 || addend == nullptr) &&
+                        (relu_src == nullptr || relu_s16 == out_s16) && d->Co % 64 == 0,
+                        "dgrad: unsupported pre-split combination (query acg_conv2d_s16_supported)");
+            const int CiP = acg_ncols_pad(d->Ci);
+            hipLaunchKernelGGL(dgrad_colfix_kernel, dim3(d->N * (d->Hi / 32), 2, CiP / 128), dim3(256), 0, st, (const char *)src,
+                               (const __bf16 *)wb, g.w_elems, (float *)ws, d->Hi, d->Wi, d->Co, CiP, d->Ci);
+            ACG_CHECK_LAUNCH("dgrad_colfix_kernel");
+            g.unpad = 1; g.colfix = (const float *)ws; g.out2 = dst; g.addend = addend; g.relu_src = relu_src; g.addend_mask = addend_mask;
+            g.out_s16 = out_s16; g.relu_s16 = relu_s16;
+            return acg_igemm_x3_pre_launch(src, wb, bias, dst, g, t, g.w_elems, st);
+        }
         t.n = 0;
         // zero pad: dy row = iy + p - kh ; reflect (padded grid): dy row = py - kh
         const int base = refl ? 0 : p;

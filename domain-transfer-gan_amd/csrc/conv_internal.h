@@ -56,6 +56,14 @@ struct Geom {
     // (x = hi + lo + O(2^-17 |x|); the same 4 bytes per element as fp32).  out_s16: the written tensor (out2 on the frame
     // path) takes that form; relu_s16: relu_src is stored that way (its sign = the sign of the hi halves).
     int out_s16 = 0, relu_s16 = 0;
+    // unpad (pre-split kernel only): data gradient of a ReflectionPad2d(1) 3x3 convolution computed on the UN-padded grid,
+    // every tile one grid row.  The adjoint of the mirror folds pad row -1 onto row 1 and pad row H onto row H-2: for the
+    // tiles of those two rows the kernel row that reads the mirrored dy row takes the packed slabs 9 + kw = w[0][kw] +
+    // w[2][kw] instead of its own (acg_packed_wb_elems), and the column part of the fold — two pixels per grid row — is
+    // a separate small GEMM (dgrad_colfix_kernel) whose result colfix[(image row * 2 + {left, right}) * Cout + c] is
+    // added to pixels 1 and W-2 before the side inputs.  No padded scratch tensor, no fold pass.
+    int unpad = 0;
+    const float *colfix = nullptr;
     // per-tile statistics for an InstanceNorm behind the convolution (acg_conv2d_fwd_stats): (mean, M2) of every output
     // channel over the 128 output pixels of a tile, written to stats[((img * stats_cpi + stats_chunk0 + tile) * 2 + {0,1}) *
     // Cout + c], tile = the tile's index within its image in THIS launch (stats_cpi = chunks per image over all launches

@@ -90,6 +90,7 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
                 const bool cx = ix >= 0 && ix < g.fold_W && !(ix >= 1 && ix <= p) && !(ix >= g.fold_W - 1 - p && ix <= g.fold_W - 2);
                 if (cy && cx) po = (unsigned)(((((long long)n * g.fold_H + iy) * g.fold_W + ix) * g.Cout) >> 2) | 0x80000000u;
             }
+            if (g.unpad) po |= 0x80000000u; // un-padded reflect data gradient: every pixel is final here (out2 == out)
         }
         pix_off[tid] = po;
     }
@@ -113,9 +114,19 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
         const int tap_v = taps.pk[lane < taps.n ? lane : 0];
         auto tap_pk = [&](int t) { return __builtin_amdgcn_readlane(tap_v, t); };
         int bt = 0, bc0 = 0; // tap and first input channel of the next B stage
+        // Geom.unpad: the tile of grid row 1 / H-2 reads the mirrored dy row through kernel row 2 / 0, whose slabs 6..8 /
+        // 0..2 become the summed slabs 9..11
+        int sub_lo = -100, sub_add = 0;
+        if (g.unpad) {
+            const int gy_t = (m0 / g.GW) % g.GH;
+            if (gy_t == 1) { sub_lo = 6; sub_add = 3; }
+            else if (gy_t == g.GH - 2) { sub_lo = 0; sub_add = 9; }
+        }
         auto dma_b = [&](int buf) { // 2 * BL pieces per thread: hi and lo image of stage (bt, bc0) into B buffer `buf`
             char *Bb = lds + A_BYTES + buf * BBUF;
-            const unsigned soff = (unsigned)((((tap_pk(bt) >> 16) * (g.Cin >> 4) + (bc0 >> 4)) * g.ncols_pad) * 16) * 2u;
+            int slab = tap_pk(bt) >> 16;
+            slab += (unsigned)(slab - sub_lo) < 3u ? sub_add : 0;
+            const unsigned soff = (unsigned)(((slab * (g.Cin >> 4) + (bc0 >> 4)) * g.ncols_pad) * 16) * 2u;
 #pragma unroll
             for (int i = 0; i < BL; ++i) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(Bb + b_lds[i]), 16, b_voff[i], soff, 0, 0);
@@ -352,6 +363,13 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
                 tile[(wm * TM + i * 16 + 4 * pl + r) * TS + cl] = acg_apply_act(acc[i][j][r] + bv, STATS ? (int)ACG_ACT_NONE : g.act);
     }
     __syncthreads();
+    if (g.colfix != nullptr) { // un-padded reflect data gradient: the mirrored pad columns land on pixels 1 and W-2
+        const int grow = m0 / g.GW, x0c = m0 - grow * g.GW;
+        const int sd = tid >> 7, c = tid & (BN - 1), row = sd == 0 ? 1 - x0c : g.GW - 2 - x0c;
+        if ((unsigned)row < (unsigned)BM && n0 + c < g.Cout)
+            tile[row * TS + c] += g.colfix[((size_t)grow * 2 + sd) * g.Cout + n0 + c];
+        __syncthreads();
+    }
     if constexpr (STATS) {
         // per-tile (mean, M2) of the 128 output pixels of every channel for the InstanceNorm that follows (conv_x3.hip)
         float *redf = &red[0][0][0]; // 256 floats
@@ -513,7 +531,9 @@ int acg_igemm_x3_pre_launch(const void *in, const void *wp, const float *bias, f
     ACG_REQUIRE(stats == nullptr || (((long long)g.GH * g.GW) % BM == 0 && g.act == ACG_ACT_NONE && !g.out_s16),
                 "igemm_conv_x3_pre: per-tile statistics need whole 128-pixel tiles per image, no activation, fp32 output");
     ACG_REQUIRE(!g.out_s16 || (g.addend == nullptr && g.Cout % 8 == 0), "igemm_conv_x3_pre: pre-split output takes no addend");
-    ACG_REQUIRE(g.relu_src == nullptr || g.fold_p > 0, "igemm_conv_x3_pre: the ReLU source needs the frame path");
+    ACG_REQUIRE(g.relu_src == nullptr || g.fold_p > 0 || g.unpad, "igemm_conv_x3_pre: the ReLU source needs the frame path");
+    ACG_REQUIRE(!g.unpad || (g.GW % BM == 0 && g.GH >= 4 && kdim == 3 && !g.reflect && g.fold_p == 0 && g.out2 == out && g.act == ACG_ACT_NONE),
+                "igemm_conv_x3_pre: the un-padded reflect data gradient needs whole-row tiles of a 3x3 layer");
     const unsigned inb = (unsigned)in_bytes, wb = (unsigned)w_bytes, wlo = (unsigned)(n_w_elems * 2);
     const Taps tp = acg_taps_pack(t);
 #define X3_PRE(R, S) hipLaunchKernelGGL((igemm_conv_x3_pre<R, S>), grid, dim3(512), 0, st, (const char *)in, (const __bf16 *)wp, bias, out, g, tp, inb, wb, wlo, stats, kdim, dxmin, kstep)

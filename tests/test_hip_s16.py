@@ -17,12 +17,18 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 def test_s16_kernels_equal_the_fp32_operand_kernels_bit_for_bit():
+    """Forward, weight gradient and the padded-grid data gradient: bit for bit.  Maps whose rows are whole 128-pixel tiles
+    take the un-padded data gradient (Geom.unpad: summed weight slabs for the two mirrored rows, the mirrored columns as a
+    separate small GEMM — modules.py:205-227's ReflectionPad2d(1) adjoint in another summation order): 2e-5 of the largest
+    element against the fp32-operand kernel, which test_conv2d_fwd_bwd holds to the oracle."""
     import s16_check
     from hip_util import precision
     with precision("bf16x3"):
         assert s16_check.run(2, 64, 64, 128, False, 0)      # two row segments per tile
         assert s16_check.run(1, 32, 32, 128, False, 0)      # four
-        assert s16_check.run(1, 128, 128, 128, False, 0)    # the config-3 trunk geometry
+        assert s16_check.run(1, 64, 128, 128, False, 0)     # un-padded data gradient: the smallest map (two column-term tiles)
+        assert s16_check.run(2, 128, 128, 128, False, 0)    # the config-3 trunk geometry
+        assert s16_check.run(1, 96, 256, 128, False, 0)     # two tiles per row
 
 
 def _gen(kind, n_blocks, seed):

@@ -29,10 +29,10 @@ def dec(x):
     return y
 
 
-def check(name, a, b, exact=True):
+def check(name, a, b, exact=True, tol=1e-5):
     d = (a - b).abs().max().item()
     ref = b.abs().max().item()
-    ok = d == 0.0 if exact else d <= 1e-5 * ref
+    ok = d == 0.0 if exact else d <= tol * ref
     print("%-44s max|diff| %.3e (ref max %.3e) %s" % (name, d, ref, "OK" if ok else "MISMATCH"), flush=True)
     return ok
 
@@ -84,17 +84,23 @@ def run(N, H, W, C, time_it, iters):
     def dg_s16():
         _lib.call("acg_conv2d_bwd_data_s16", D, P(dys), P(pk.wb), P(dx1), P(ws), nb_d, None, None, None, 0, st)
 
+    # whole-row tiles (W % 128 == 0): the pre-split data gradient runs on the un-padded grid with summed weight slabs for the
+    # mirrored rows and a separate column term — the same sums in another order, no longer bit-identical
+    unpad = W % 128 == 0 and H % 32 == 0 and H >= 64 and not os.environ.get("ACG_NO_UNPAD")
     dg_ref(); dg_s16()
-    ok &= check("dgrad (fp32 out)", dx1, dx0)
+    ok &= check("dgrad (fp32 out)", dx1, dx0, exact=not unpad, tol=2e-5)
     mask = None
     if (H * W * (C // 4)) % 8 == 0:
         mask = torch.randint(-2 ** 31, 2 ** 31 - 1, ((N * H * W * C + 31) // 32,), device=dev, dtype=torch.int32, generator=g)
     _lib.call("acg_conv2d_bwd_data_add", D, P(dy), P(pk.wb), P(skip), P(mask), P(dx0), P(ws), nb_d, st)
     _lib.call("acg_conv2d_bwd_data_s16", D, P(dys), P(pk.wb), P(dx1), P(ws), nb_d, P(skip), P(mask), None, 0, st)
-    ok &= check("dgrad + masked skip addend (fp32 out)", dx1, dx0)
+    ok &= check("dgrad + masked skip addend (fp32 out)", dx1, dx0, exact=not unpad, tol=2e-5)
     _lib.call("acg_conv2d_bwd_data_relu", D, P(dy), P(pk.wb), P(x), P(dx0), P(ws), nb_d, st)
     _lib.call("acg_conv2d_bwd_data_s16", D, P(dys), P(pk.wb), P(dx1), P(ws), nb_d, None, None, P(xs), 1, st)
-    ok &= check("dgrad * (x > 0) (S16 out) vs encode(ref)", dx1.view(torch.int32), enc(dx0).view(torch.int32))
+    if unpad:
+        ok &= check("dgrad * (x > 0) (S16 out) vs ref", dec(dx1), dx0, exact=False, tol=3e-5)
+    else:
+        ok &= check("dgrad * (x > 0) (S16 out) vs encode(ref)", dx1.view(torch.int32), enc(dx0).view(torch.int32))
 
     # weight gradient
     dw0, dw1 = torch.empty_like(w), torch.empty_like(w)
@@ -113,7 +119,7 @@ def run(N, H, W, C, time_it, iters):
     torch.cuda.synchronize()
     if os.environ.get("ACG_STAMPS") and N == 32 and hasattr(_lib.load(), "acg_debug_pre_stamps"):
         import numpy as np
-        for name, f, nwg in (("fwd", fwd_s16, 4096), ("dgrad", dg_s16, 4225)):
+        for name, f, nwg in (("fwd", fwd_s16, 4096), ("dgrad", dg_s16, 4096)):
             for _ in range(3):
                 f()
             torch.cuda.synchronize()
@@ -173,6 +179,7 @@ def main():
     a = ap.parse_args()
     ops.set_precision("bf16x3")
     ok = run(2, 64, 64, 128, False, 0)      # two segments per tile
+    ok &= run(1, 64, 128, 128, False, 0)    # un-padded data gradient, the smallest map
     ok &= run(1, 32, 32, 128, False, 0)     # four segments per tile
     ok &= run(2, 128, 128, 128, False, 0)   # the config-3 trunk geometry
     if a.time:
