@@ -40,6 +40,12 @@ class AdamGroup(ctypes.Structure):
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_size_t), ("sumsq", c_void_p)]
 
 
+class NormSumsDesc(ctypes.Structure):
+    """acg_norm_sums (include/acgan_hip.h)."""
+    _fields_ = [("x", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
+                ("gstride", c_int), ("sign_mask", c_void_p), ("act", c_int), ("part", c_void_p)]
+
+
 ADAM_MAX_GROUPS = 8
 _P = c_void_p
 _D = ctypes.POINTER(ConvDesc)
@@ -71,6 +77,8 @@ SIGNATURES = {
     "acg_conv2d_s16_supported": (c_int, [_D]),
     "acg_conv2d_fwd_s16": (c_int, [_D, _P, _P, _P, _P, c_int, _P, c_int, _P]),
     "acg_conv2d_bwd_data_s16": (c_int, [_D, _P, _P, _P, _P, c_size_t, _P, _P, _P, c_int, _P]),
+    "acg_conv2d_bwd_data_s16_sums_supported": (c_int, [_D]),
+    "acg_conv2d_bwd_data_s16_sums": (c_int, [_D, _P, _P, _P, _P, c_size_t, _P, _P, ctypes.POINTER(NormSumsDesc), _P]),
     "acg_conv2d_bwd_weight_s16": (c_int, [_D, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
     "acg_conv2d_bwd_weight_workspace_bytes": (c_size_t, [_D]),
     "acg_conv2d_bwd_weight": (c_int, [_D, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
@@ -92,6 +100,8 @@ SIGNATURES = {
     "acg_norm_apply": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_size_t, c_int, c_int, c_int, _P]),
     "acg_norm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_size_t, c_int, c_int,
                              c_int, c_int, _P, c_size_t, _P]),
+    "acg_norm_bwd_partials": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_size_t, c_int,
+                                      c_int, c_int, c_int, _P, c_int, _P, c_size_t, _P]),
     "acg_norm_bwd_sums": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_size_t, c_int, c_int, _P, c_size_t, _P]),
     "acg_norm_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_size_t, c_size_t, c_int, c_int, c_int, _P]),
     "acg_act_bwd": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
@@ -121,7 +131,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 110   # include/acgan_hip.h ACG_VERSION this binding was written against
+ABI_VERSION = 111   # include/acgan_hip.h ACG_VERSION this binding was written against
 
 
 class AcgError(RuntimeError):

@@ -747,10 +747,18 @@ static bool dgrad_frame_ok(const acg_conv_desc *d, const Geom &g)
            d->Hi > 4 * p + 1 && d->Wi > 4 * p + 1;
 }
 
+// the un-padded grid of the pre-split reflect data gradient (Geom.unpad): 3x3, pad 1, rows that are whole 128-pixel tiles
+static bool dgrad_unpad_ok(const acg_conv_desc *d)
+{
+    static const bool no_unpad = acg_debug_switch("ACG_NO_UNPAD");   // A/B switch
+    return !no_unpad && d->stride == 1 && d->pad_mode == ACG_PAD_REFLECT && d->K == 3 && d->pad == 1 && d->Wi % 128 == 0 &&
+           d->Hi % 32 == 0 && d->Hi >= 64 && d->Co % 64 == 0;
+}
+
 static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb, const float *bias, float *dst,
                        int act, void *ws, size_t ws_bytes, hipStream_t st, const float *addend = nullptr,
                        const float *relu_src = nullptr, const unsigned *addend_mask = nullptr, int in_s16 = 0, int out_s16 = 0,
-                       int relu_s16 = 0, float *stats = nullptr)
+                       int relu_s16 = 0, float *stats = nullptr, const acg_norm_sums *ns = nullptr)
 {
     Geom g; Taps t;
     g.Hin = d->Ho; g.Win = d->Wo; g.Cin = d->Co;
@@ -776,8 +784,7 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
         g.Mtot = (long long)d->N * g.GH * g.GW;
         // Pre-split operands, 3x3, pad 1, rows that are whole tiles: the un-padded grid (Geom.unpad) — 3 % fewer tiles than the
         // padded grid, one row segment per tile, and the fold pass over the frame goes away
-        static const bool no_unpad = acg_debug_switch("ACG_NO_UNPAD");   // A/B switch
-        if (!no_unpad && refl && in_s16 && K == 3 && p == 1 && d->Wi % 128 == 0 && d->Hi % 32 == 0 && d->Hi >= 64 && dgrad_frame_ok(d, g)) {
+        if (refl && in_s16 && dgrad_unpad_ok(d) && dgrad_frame_ok(d, g)) {
             g.Hout = d->Hi; g.Wout = d->Wi; g.GH = d->Hi; g.GW = d->Wi;
             g.Mtot = (long long)d->N * g.GH * g.GW;
             t.n = 0;
@@ -792,8 +799,14 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
             ACG_CHECK_LAUNCH("dgrad_colfix_kernel");
             g.unpad = 1; g.colfix = (const float *)ws; g.out2 = dst; g.addend = addend; g.relu_src = relu_src; g.addend_mask = addend_mask;
             g.out_s16 = out_s16; g.relu_s16 = relu_s16;
+            if (ns != nullptr) {
+                g.ns_x = ns->x; g.ns_mean = ns->mean; g.ns_rstd = ns->rstd; g.ns_gamma = ns->gamma; g.ns_beta = ns->beta;
+                g.ns_gstride = ns->gstride; g.ns_mask = ns->sign_mask; g.ns_act = ns->act; g.ns_part = ns->part;
+                ACG_REQUIRE(ns->part != nullptr && (ns->gstride == 0 || ns->gstride == d->Ci), "dgrad: bad acg_norm_sums");
+            }
             return acg_igemm_x3_pre_launch(src, wb, bias, dst, g, t, g.w_elems, st);
         }
+        ACG_REQUIRE(ns == nullptr, "dgrad: the norm sums need the un-padded pre-split path (query acg_conv2d_bwd_data_s16_sums_supported)");
         t.n = 0;
         // zero pad: dy row = iy + p - kh ; reflect (padded grid): dy row = py - kh
         const int base = refl ? 0 : p;
@@ -1063,6 +1076,25 @@ extern "C" int acg_conv2d_bwd_data_s16(const acg_conv_desc *d, const void *dy, c
                 "acg_conv2d_bwd_data_s16: the sign bitmask needs an addend and Hi*Wi*Ci/4 %% 8 == 0");
     return dgrad_igemm(d, (const float *)dy, wb, nullptr, (float *)dx, ACG_ACT_NONE, ws, ws_bytes, (hipStream_t)stream, addend,
                        (const float *)relu_src, addend_mask, 1, out_s16, relu_src != nullptr ? 1 : 0);
+}
+
+extern "C" int acg_conv2d_bwd_data_s16_sums_supported(const acg_conv_desc *d)
+{
+    return acg_conv2d_s16_supported(d) && dgrad_unpad_ok(d) && d->Ci % 4 == 0 && ((long long)d->Hi * d->Wi) % 128 == 0 ? 1 : 0;
+}
+
+extern "C" int acg_conv2d_bwd_data_s16_sums(const acg_conv_desc *d, const void *dy, const float *wb, float *dx, void *ws,
+                                            size_t ws_bytes, const float *addend, const unsigned *addend_mask,
+                                            const acg_norm_sums *ns, void *stream)
+{
+    int rc = check_desc(d, "acg_conv2d_bwd_data_s16_sums");
+    if (rc) return rc;
+    ACG_REQUIRE(ns != nullptr && acg_conv2d_bwd_data_s16_sums_supported(d), "acg_conv2d_bwd_data_s16_sums: unsupported shape or mode");
+    ACG_REQUIRE(addend_mask == nullptr || (addend != nullptr && ((long long)d->Hi * d->Wi * (d->Ci / 4)) % 8 == 0),
+                "acg_conv2d_bwd_data_s16_sums: the sign bitmask needs an addend and Hi*Wi*Ci/4 %% 8 == 0");
+    ACG_REQUIRE(ns->sign_mask == nullptr || ((long long)d->Hi * d->Wi * (d->Ci / 4)) % 8 == 0, "acg_conv2d_bwd_data_s16_sums: bitmask layout");
+    return dgrad_igemm(d, (const float *)dy, wb, nullptr, dx, ACG_ACT_NONE, ws, ws_bytes, (hipStream_t)stream, addend, nullptr,
+                       addend_mask, 1, 0, 0, nullptr, ns);
 }
 
 // x and dy pre-split; dw / db fp32 as in acg_conv2d_bwd_weight (db = column sums of dy, produced by the same launch)

@@ -64,6 +64,11 @@ struct Geom {
     // added to pixels 1 and W-2 before the side inputs.  No padded scratch tensor, no fold pass.
     int unpad = 0;
     const float *colfix = nullptr;
+    // unpad only (acg_norm_sums): the tile's share of the backward sums of the norm whose output gradient this launch writes
+    const float *ns_x = nullptr, *ns_mean = nullptr, *ns_rstd = nullptr, *ns_gamma = nullptr, *ns_beta = nullptr;
+    const unsigned *ns_mask = nullptr;
+    float *ns_part = nullptr;
+    int ns_gstride = 0, ns_act = 0;
     // per-tile statistics for an InstanceNorm behind the convolution (acg_conv2d_fwd_stats): (mean, M2) of every output
     // channel over the 128 output pixels of a tile, written to stats[((img * stats_cpi + stats_chunk0 + tile) * 2 + {0,1}) *
     // Cout + c], tile = the tile's index within its image in THIS launch (stats_cpi = chunks per image over all launches

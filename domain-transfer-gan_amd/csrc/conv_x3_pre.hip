@@ -349,7 +349,7 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
     // Epilogue through LDS: the tile (accumulator + bias, activation) is staged in the LDS the main loop no longer needs
     // and leaves in coalesced rows.
     constexpr int TS = BN; // row stride (floats)
-    static_assert(BM * TS * 4 <= LDS_BYTES, "the staged tile must fit the LDS buffers");
+    static_assert(BM * TS * 4 + 2 * 8 * BN * 4 <= LDS_BYTES, "the staged tile (and the scratch of the sums pass) must fit the LDS buffers");
     float *tile = (float *)lds;
     __syncthreads(); // every consumer wave is done with the last LDS buffer (the producers have exited)
 #pragma unroll
@@ -370,6 +370,58 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
             tile[row * TS + c] += g.colfix[((size_t)grow * 2 + sd) * g.Cout + n0 + c];
         __syncthreads();
     }
+    // Geom.ns_part: the tile is one 128-pixel chunk of the gradient w.r.t. a norm's output — its share of that norm's backward
+    // sums (norm.hip norm_bwd_partial: gy = dy * act'(y), S1 = sum gy, S2 = sum gy * xhat) leaves with it, read from the
+    // staged tile once it holds the FINAL values.  Thread = 4 channels x 16 rows, the norm's input rows fetched eight at a time.
+    auto emit_sums = [&]() {
+        __syncthreads();
+        const int cq = tid & 31, rg = tid >> 5, c = n0 + cq * 4;
+        const int img = m0 / GHW, chunk = (m0 - img * GHW) / BM;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+        if (c < g.Cout) {
+            const f32x4 mu = *(const f32x4 *)(g.ns_mean + (size_t)img * g.Cout + c), rs = *(const f32x4 *)(g.ns_rstd + (size_t)img * g.Cout + c);
+            const bool remask = g.ns_act != ACG_ACT_NONE && g.ns_mask == nullptr;
+            f32x4 ga = s1, be = s1;
+            if (remask) { ga = *(const f32x4 *)(g.ns_gamma + (size_t)img * g.ns_gstride + c); be = *(const f32x4 *)(g.ns_beta + (size_t)img * g.ns_gstride + c); }
+            const unsigned *mk = g.ns_mask != nullptr ? g.ns_mask : (const unsigned *)g.ns_x;
+#pragma unroll 1
+            for (int rb = 0; rb < 16; rb += 8) {
+                f32x4 xv[8];
+                unsigned nb[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const size_t o = (size_t)(m0 + rg * 16 + rb + u) * g.Cout + c;
+                    xv[u] = *(const f32x4 *)(g.ns_x + o);
+                    const size_t f = o >> 2;
+                    nb[u] = (mk[f >> 3] >> (4 * (int)(f & 7))) & 15u;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    f32x4 gy = *(const f32x4 *)&tile[(rg * 16 + rb + u) * TS + cq * 4];
+                    const f32x4 xh = (xv[u] - mu) * rs;
+                    if (g.ns_act != ACG_ACT_NONE) {
+                        const f32x4 yy = xh * ga + be; // same expression as norm_apply_kernel: its sign is the mask
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) gy[q] = (remask ? yy[q] > 0.f : ((nb[u] >> q) & 1u) != 0u) ? gy[q] : 0.f;
+                    }
+                    s1 += gy;
+                    s2 += gy * xh;
+                }
+            }
+        }
+        float *sc = (float *)(lds + BM * TS * 4); // [2][8 row groups][BN]
+        *(f32x4 *)&sc[(0 * 8 + rg) * BN + cq * 4] = s1;
+        *(f32x4 *)&sc[(1 * 8 + rg) * BN + cq * 4] = s2;
+        __syncthreads();
+        if (tid < 64) {
+            const int k = tid >> 5, cc = tid & 31;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 8; ++r) a += *(const f32x4 *)&sc[(k * 8 + r) * BN + cc * 4];
+            if (n0 + cc * 4 < g.Cout)
+                *(f32x4 *)(g.ns_part + ((size_t)(img * (GHW / BM) + chunk) * 2 + k) * g.Cout + n0 + cc * 4) = a;
+        }
+    };
     if constexpr (STATS) {
         // per-tile (mean, M2) of the 128 output pixels of every channel for the InstanceNorm that follows (conv_x3.hip)
         float *redf = &red[0][0][0]; // 256 floats
@@ -438,6 +490,7 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
             if (po != NO_PIX && n0 + c4 * 4 < g.Cout)
                 *(f32x4 *)(((po >> 31) ? base1 : base0) + (size_t)(po & 0x7fffffffu) * 16 + (size_t)(n0 + c4 * 4) * 4) = *(const f32x4 *)&tile[row * TS + c4 * 4];
         }
+        if (g.ns_part != nullptr) emit_sums();
         return;
     }
     // Data-gradient epilogue with fp32 side inputs (skip gradient and its sign bitmask; fp32 ReLU source): four rows at a
@@ -481,8 +534,13 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
                 for (int q = 0; q < 4; ++q) v[u][q] += (nb[u] >> q) & 1u ? av[u][q] : 0.f;
             }
             if (po[u] != NO_PIX) *(f32x4 *)(((po[u] >> 31) ? base1 : base0) + bo[u]) = v[u];
+            if (g.ns_part != nullptr) { // the final value back into the staged tile for the sums pass
+                const int idx = tid + 256 * (kb + u), row = idx / (BN / 4), c4 = idx - row * (BN / 4);
+                *(f32x4 *)&tile[row * TS + c4 * 4] = v[u];
+            }
         }
     }
+    if (g.ns_part != nullptr) emit_sums();
 }
 
 // Row-patch geometry the pre-split kernel needs: K x K tap lists in kernel-row order (forward: dx ascending, stride-1 data
@@ -532,6 +590,10 @@ int acg_igemm_x3_pre_launch(const void *in, const void *wp, const float *bias, f
                 "igemm_conv_x3_pre: per-tile statistics need whole 128-pixel tiles per image, no activation, fp32 output");
     ACG_REQUIRE(!g.out_s16 || (g.addend == nullptr && g.Cout % 8 == 0), "igemm_conv_x3_pre: pre-split output takes no addend");
     ACG_REQUIRE(g.relu_src == nullptr || g.fold_p > 0 || g.unpad, "igemm_conv_x3_pre: the ReLU source needs the frame path");
+    ACG_REQUIRE(g.ns_part == nullptr || (g.unpad && !g.out_s16 && g.Cout % 4 == 0 && (g.ns_act == ACG_ACT_NONE || g.ns_act == ACG_ACT_RELU) &&
+                                       g.ns_x != nullptr && g.ns_mean != nullptr && g.ns_rstd != nullptr &&
+                                       (g.ns_act == ACG_ACT_NONE || g.ns_mask != nullptr || (g.ns_gamma != nullptr && g.ns_beta != nullptr))),
+                "igemm_conv_x3_pre: the norm sums ride on the un-padded fp32 data gradient (act NONE / RELU)");
     ACG_REQUIRE(!g.unpad || (g.GW % BM == 0 && g.GH >= 4 && kdim == 3 && !g.reflect && g.fold_p == 0 && g.out2 == out && g.act == ACG_ACT_NONE),
                 "igemm_conv_x3_pre: the un-padded reflect data gradient needs whole-row tiles of a 3x3 layer");
     const unsigned inb = (unsigned)in_bytes, wb = (unsigned)w_bytes, wlo = (unsigned)(n_w_elems * 2);

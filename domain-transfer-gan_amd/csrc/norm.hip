@@ -663,11 +663,36 @@ extern "C" int acg_norm_bwd_apply(const float *dy, const float *y, const float *
     return ACG_OK;
 }
 
+static int norm_bwd_impl(const float *dy, const float *y, const unsigned *mask, const float *x, const float *mean,
+                         const float *rstd, const float *gamma, const float *beta, int gstride, float *dx, float *dres,
+                         float *dgamma, float *dbeta, int nparam, int accumulate, int G, size_t P, int C, int act, int unbiased,
+                         int dx_s16, const float *part_in, int nch_in, void *ws, size_t ws_bytes, void *stream);
+
 extern "C" int acg_norm_bwd(const float *dy, const float *y, const unsigned *mask, const float *x, const float *mean,
                             const float *rstd,
                             const float *gamma, const float *beta, int gstride, float *dx, float *dres, float *dgamma,
                             float *dbeta, int nparam, int accumulate, int G, size_t P, int C, int act, int unbiased,
                             int dx_s16, void *ws, size_t ws_bytes, void *stream)
+{
+    return norm_bwd_impl(dy, y, mask, x, mean, rstd, gamma, beta, gstride, dx, dres, dgamma, dbeta, nparam, accumulate, G, P, C,
+                         act, unbiased, dx_s16, nullptr, 0, ws, ws_bytes, stream);
+}
+
+extern "C" int acg_norm_bwd_partials(const float *dy, const float *y, const unsigned *mask, const float *x, const float *mean,
+                                     const float *rstd, const float *gamma, const float *beta, int gstride, float *dx,
+                                     float *dres, float *dgamma, float *dbeta, int nparam, int accumulate, int G, size_t P,
+                                     int C, int act, int unbiased, int dx_s16, const float *part, int nchunks, void *ws,
+                                     size_t ws_bytes, void *stream)
+{
+    ACG_REQUIRE(part != nullptr && nchunks > 0, "acg_norm_bwd_partials: no partial sums");
+    return norm_bwd_impl(dy, y, mask, x, mean, rstd, gamma, beta, gstride, dx, dres, dgamma, dbeta, nparam, accumulate, G, P, C,
+                         act, unbiased, dx_s16, part, nchunks, ws, ws_bytes, stream);
+}
+
+static int norm_bwd_impl(const float *dy, const float *y, const unsigned *mask, const float *x, const float *mean,
+                         const float *rstd, const float *gamma, const float *beta, int gstride, float *dx, float *dres,
+                         float *dgamma, float *dbeta, int nparam, int accumulate, int G, size_t P, int C, int act, int unbiased,
+                         int dx_s16, const float *part_in, int nch_in, void *ws, size_t ws_bytes, void *stream)
 {
     int rc = check_norm(G, P, C, "acg_norm_bwd");
     if (rc) return rc;
@@ -688,9 +713,10 @@ extern "C" int acg_norm_bwd(const float *dy, const float *y, const unsigned *mas
     ACG_REQUIRE(act == ACG_ACT_NONE || y != nullptr || mask != nullptr || beta != nullptr,
                 "acg_norm_bwd: y, the sign bitmask or beta required for the activation mask");
     ACG_REQUIRE(mask == nullptr || ((long long)P * (C / 4)) % 8 == 0, "acg_norm_bwd: bitmask layout needs P*C/4 %% 8 == 0");
-    launch_norm_bwd_partial(dim3(nch, G), st, dy, y, x, mean, rstd, gamma, beta, gstride, (long long)P, C, nch, act, part, mask);
-    hipLaunchKernelGGL(norm_bwd_final, dim3(G * acg_cdiv(C, FIN_CH)), dim3(256), 0, st, (const float *)part, G, C,
-                       nch, sums, gstride ? dgamma : (float *)nullptr, gstride ? dbeta : (float *)nullptr);
+    if (part_in == nullptr)
+        launch_norm_bwd_partial(dim3(nch, G), st, dy, y, x, mean, rstd, gamma, beta, gstride, (long long)P, C, nch, act, part, mask);
+    hipLaunchKernelGGL(norm_bwd_final, dim3(G * acg_cdiv(C, FIN_CH)), dim3(256), 0, st, part_in != nullptr ? part_in : (const float *)part,
+                       G, C, part_in != nullptr ? nch_in : nch, sums, gstride ? dgamma : (float *)nullptr, gstride ? dbeta : (float *)nullptr);
     const bool params = gstride == 0 && nparam > 0 && (dgamma != nullptr || dbeta != nullptr);
     // unbiased == 2: statistics are constants (BatchNorm eval mode) -> dx = gamma * rstd * gy
     const float invP = unbiased == 2 ? 0.f : 1.f / (float)P;

@@ -74,13 +74,13 @@ class Conv2d(nn.Conv2d, _Cached):
         return self._cached(lambda: ops.PackedConv(self.weight, self.bias, cpad(self.in_channels), cpad(self.out_channels)))
 
     def forward_nhwc(self, x, act=ACT_NONE, reflect_pad=0, want_stats=None, want_identity=False, link_out=None,
-                     link_in=None, skip_grad=None, s16=None):
+                     link_in=None, skip_grad=None, s16=None, norm_sums=None):
         if reflect_pad:
             pad, mode = reflect_pad, PAD_REFLECT
         else:
             pad, mode = self.padding[0], PAD_ZERO
         out = ops.Conv2dFn.apply(x, self.weight, self.bias, self.packed(), self.stride[0], pad, mode, act, want_stats,
-                                 want_identity, link_out, link_in, skip_grad, s16)
+                                 want_identity, link_out, link_in, skip_grad, s16, norm_sums)
         if s16 is not None and s16.x:   # tag what left the convolution pre-split: its output (conv + ReLU) and the alias of x
             if want_identity:
                 ops.tag_s16(out[1])
@@ -230,10 +230,10 @@ class InstanceNorm(nn.Module, _Cached):
         dev = self.scale.device
         return torch.ones(C, device=dev), torch.zeros(C, device=dev)
 
-    def forward_act(self, x, act=ACT_NONE, res=None, lazy_dres=None, stats=None, s16_out=False, s16_dx=False):
+    def forward_act(self, x, act=ACT_NONE, res=None, lazy_dres=None, stats=None, s16_out=False, s16_dx=False, sums=None):
         g, b = self._gb()
         y = ops.NormAct.apply(x, self.scale, self.shift, res, "in", act, self.eps, g, b, None, None, 0.0, lazy_dres, stats,
-                              s16_out, s16_dx, res is not None and ops.is_s16(res))
+                              s16_out, s16_dx, res is not None and ops.is_s16(res), sums)
         return ops.tag_s16(y) if s16_out else y
 
     def forward(self, input):
@@ -256,11 +256,12 @@ class CondInstanceNorm(TwoInputModule):
         self.shift_conv = nn.Sequential(Conv2d(z_dim, x_dim, kernel_size=1, padding=0, bias=True), nn.ReLU(True))
         self.scale_conv = nn.Sequential(Conv2d(z_dim, x_dim, kernel_size=1, padding=0, bias=True), nn.ReLU(True))
 
-    def forward_act(self, x, z, act=ACT_NONE, stats=None, s16_out=False, s16_dx=False):
+    def forward_act(self, x, z, act=ACT_NONE, stats=None, s16_out=False, s16_dx=False, sums=None):
         Cp = x.shape[-1]
         sh = ops.LinearFn.apply(z, self.shift_conv[0].weight, self.shift_conv[0].bias, ACT_RELU, Cp)
         sc = ops.LinearFn.apply(z, self.scale_conv[0].weight, self.scale_conv[0].bias, ACT_RELU, Cp)
-        y = ops.NormAct.apply(x, sc, sh, None, "cin", act, self.eps, None, None, None, None, 0.0, None, stats, s16_out, s16_dx)
+        y = ops.NormAct.apply(x, sc, sh, None, "cin", act, self.eps, None, None, None, None, 0.0, None, stats, s16_out, s16_dx,
+                              False, sums)
         return ops.tag_s16(y) if s16_out else y
 
     def forward(self, input, noise):
@@ -299,6 +300,10 @@ def run_sequence(mods, x, C, z=None, res=None):
     # layer behind the last block gets it decoded.  s16 = this list is the inside of such a block.
     s16 = res is not None and ops.is_s16(x)
     nconv = 0
+    # ops.NormSums: a norm whose pre-split output goes to ONE trunk convolution (inside a block: the next convolution of the
+    # list; a block's output or the norm in front of the first block: the next block's first convolution, whose data gradient
+    # already includes the skip gradient) shares a slot with it — the slot travels on the tensor between blocks
+    ns_prev = getattr(x, "_acg_ns", None) if s16 else None
     while i < n:
         m = mods[i]
         if isinstance(m, nn.ReflectionPad2d):
@@ -361,7 +366,9 @@ def run_sequence(mods, x, C, z=None, res=None):
                 if nconv == 0 and not skip_here:
                     raise NotImplementedError("pre-split trunk: the block's first layer must be its first convolution")
             nconv += 1
-            x = conv.forward_nhwc(x, cact, reflect, stats, skip_here, link_out, link_in, skip_grad if skip_here else None, plan)
+            ns_conv, ns_prev = (ns_prev if (plan is not None and (skip_here or nconv > 1)) else None), None
+            x = conv.forward_nhwc(x, cact, reflect, stats, skip_here, link_out, link_in, skip_grad if skip_here else None, plan,
+                                  ns_conv)
             if skip_here:  # the skip connection continues from the conv's identity output: its gradient is added
                 x, res = x  # inside that conv's data-gradient epilogue
                 skip_routed = True
@@ -382,15 +389,21 @@ def run_sequence(mods, x, C, z=None, res=None):
                     raise NotImplementedError("residual after CondInstanceNorm")
                 if s16 and act != ACT_RELU:
                     raise NotImplementedError("pre-split trunk: CondInstanceNorm without ReLU")
-                x = norm.forward_act(x, z, act, stats.part if stats is not None else None, emit, s16)
+                ns_prev = ops.NormSums() if emit else None
+                x = norm.forward_act(x, z, act, stats.part if stats is not None else None, emit, s16, ns_prev)
+                if ns_prev is not None:
+                    x._acg_ns = ns_prev
             elif isinstance(norm, InstanceNorm):
                 # skip_routed: `res` is the identity output of the block's first convolution, i.e. its gradient goes to that
                 # convolution's data-gradient epilogue and nowhere else -> it may stay un-materialised (ops.NormAct lazy_dres)
                 if s16 and not (fuse_res and skip_routed):
                     raise NotImplementedError("pre-split trunk: InstanceNorm that is not the block output")
+                ns_prev = ops.NormSums() if emit else None
                 x = norm.forward_act(x, ACT_RELU if fuse_res else act, res if fuse_res else None,
                                      skip_grad if (fuse_res and skip_routed) else None, stats.part if stats is not None else None,
-                                     emit, s16)
+                                     emit, s16, ns_prev)
+                if ns_prev is not None:
+                    x._acg_ns = ns_prev
             else:
                 if fuse_res:
                     raise NotImplementedError("residual after BatchNorm")

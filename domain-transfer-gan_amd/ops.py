@@ -305,6 +305,34 @@ def _grads_done(*params):
 LAZY_DRES = not _debug_switch("ACGAN_NO_LAZY_DRES")   # A/B switch (SkipGrad)
 
 
+class NormSums(object):
+    """Slot shared by a (Cond)InstanceNorm and THE convolution that consumes its output (modules.run_sequence): the
+    convolution's data gradient is the gradient w.r.t. the norm's output, and where its kernel supports it
+    (acg_conv2d_bwd_data_s16_sums) the epilogue leaves the first pass of the norm's backward — per-tile sums of gy and
+    gy * xhat — in `part`, so the norm's backward skips its own pass over dy and x.  The norm fills what the kernel needs at
+    forward time; `dx` remembers the tensor the sums belong to: a gradient that reaches the norm as anything else (another
+    consumer of the norm's output, a hook) makes the norm recompute them."""
+
+    def __init__(self):
+        self.clear()
+
+    def clear(self):
+        self.x = self.mean = self.rstd = self.gp = self.bp = self.mask = None
+        self.gstride = self.act = 0
+        self.part = self.dx = None
+
+    def desc(self, part):
+        d = _lib.NormSumsDesc()
+        d.x, d.mean, d.rstd = _ptr(self.x), _ptr(self.mean), _ptr(self.rstd)
+        d.gamma, d.beta, d.gstride = _ptr(self.gp), _ptr(self.bp), self.gstride
+        d.sign_mask, d.act, d.part = _ptr(self.mask), self.act, _ptr(part)
+        return d
+
+
+NORM_SUMS = not _debug_switch("ACGAN_NO_NORM_SUMS")   # A/B switch
+NORM_SUMS_USED = 0   # norm backward passes that took their sums from a data-gradient epilogue (tests read it)
+
+
 class ReluLink(object):
     """Hand-off between the two convolutions of a pad-conv-ReLU-pad-conv chain (ResnetBlock, modules.py:211-227): the
     SECOND convolution's data-gradient epilogue can mask its result with the sign of its own input (= the first one's ReLU
@@ -391,7 +419,7 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, packed, stride, pad, pad_mode, act, want_stats=None, want_identity=False,
-                link_out=None, link_in=None, skip_grad=None, s16=None):
+                link_out=None, link_in=None, skip_grad=None, s16=None, norm_sums=None):
         x = x.contiguous()
         _check(x)
         N, Hi, Wi, Ci = x.shape
@@ -424,6 +452,7 @@ class Conv2dFn(torch.autograd.Function):
         ctx.link_out, ctx.link_in = (link_out if act == ACT_RELU else None), link_in
         ctx.skip_grad = skip_grad
         ctx.s16 = s16 if (s16 is not None and s16.x) else None
+        ctx.norm_sums = norm_sums if (NORM_SUMS and ctx.s16 is not None) else None
         ctx.save_for_backward(x, y if (act != ACT_NONE and ctx.s16 is None) else None)
         if want_identity:
             return y, x.view_as(x)
@@ -490,7 +519,7 @@ class Conv2dFn(torch.autograd.Function):
             if direct is not None:
                 dw = db = None
                 _grads_done(ctx.wparam, ctx.bparam)
-        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def _conv_backward_s16(ctx, x, dy, dskip):
@@ -521,8 +550,18 @@ def _conv_backward_s16(ctx, x, dy, dskip):
                 dskip = dskip.contiguous()
                 if ctx.skip_grad is not None:
                     dskip, smask = ctx.skip_grad.take(dskip)
-            _lib.call("acg_conv2d_bwd_data_s16", ctypes.byref(d), _ptr(dy), _ptr(pk.wb), _ptr(dx), _ptr(ws), nb, _ptr(dskip),
-                      _ptr(smask), None, 0, st)
+            ns = ctx.norm_sums
+            if ns is not None and ns.x is not None and tuple(ns.x.shape) == tuple(dx.shape) and \
+                    _lib.query("acg_conv2d_bwd_data_s16_sums_supported", ctypes.byref(d)):
+                # dx is the gradient w.r.t. the output of the norm in front: its backward sums leave with the tiles
+                part = torch.empty((d.N, (d.Hi * d.Wi) // STATS_ROWS, 2, d.Ci), device=dx.device, dtype=torch.float32)
+                desc = ns.desc(part)
+                _lib.call("acg_conv2d_bwd_data_s16_sums", ctypes.byref(d), _ptr(dy), _ptr(pk.wb), _ptr(dx), _ptr(ws), nb, _ptr(dskip),
+                          _ptr(smask), ctypes.byref(desc), st)
+                ns.part, ns.dx = part, dx
+            else:
+                _lib.call("acg_conv2d_bwd_data_s16", ctypes.byref(d), _ptr(dy), _ptr(pk.wb), _ptr(dx), _ptr(ws), nb, _ptr(dskip),
+                          _ptr(smask), None, 0, st)
         span.done()
     if ctx.needs_input_grad[1]:
         direct = _direct_grad(ctx.wparam, ctx.bparam)
@@ -542,7 +581,7 @@ def _conv_backward_s16(ctx, x, dy, dskip):
             _grads_done(ctx.wparam, ctx.bparam)
     else:
         dw = db = None
-    return (dx, dw, db) + (None,) * 11
+    return (dx, dw, db) + (None,) * 12
 
 
 Conv2dFn._backward_s16 = staticmethod(_conv_backward_s16)
@@ -630,8 +669,8 @@ class NormAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, res, kind, act, eps, gamma_p, beta_p, run_mean, run_var, momentum, lazy_dres=None,
-                stats=None, s16_out=False, s16_dx=False, s16_res=False):
-        """lazy_dres: a SkipGrad slot (the caller guarantees that the gradient w.r.t. `res` goes only to the Conv2dFn holding
+                stats=None, s16_out=False, s16_dx=False, s16_res=False, sums=None):
+        """sums: a NormSums slot shared with the consumer of y, or None.  lazy_dres: a SkipGrad slot (the caller guarantees that the gradient w.r.t. `res` goes only to the Conv2dFn holding
         the same slot) or None.  stats: per-tile (mean, M2) partials a convolution epilogue produced (ConvStats.part)."""
         x = x.contiguous()
         _check(x)
@@ -681,6 +720,11 @@ class NormAct(torch.autograd.Function):
         _lib.call("acg_norm_apply", _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gp), _ptr(bp), gstride, _ptr(res), _ptr(y), _ptr(mask),
                   G, P, C, act, fmt, st)
         ctx.s16_dx = bool(s16_dx)
+        ctx.sums = None
+        if sums is not None and NORM_SUMS and kind in ("in", "cin") and x.dim() == 4 and act in (ACT_NONE, ACT_RELU) and \
+                (act == ACT_NONE or mask is not None or not need_y) and any(ctx.needs_input_grad):
+            sums.x, sums.mean, sums.rstd, sums.gp, sums.bp, sums.gstride, sums.mask, sums.act = x, mean, rstd, gp, bp, gstride, mask, act
+            ctx.sums = sums
         ctx.cfg = (kind, act, G, P, C, unbiased, gstride, res is not None, gamma.shape)
         ctx.gparam, ctx.bparam = (gamma, beta) if kind != "cin" else (None, None)
         ctx.lazy_dres = lazy_dres if (lazy_dres is not None and LAZY_DRES and mask is not None) else None
@@ -705,9 +749,23 @@ class NormAct(torch.autograd.Function):
             dbeta = torch.empty(npar, device=x.device, dtype=torch.float32)
         nb = _lib.query("acg_norm_workspace_bytes", G, P, C)
         ws = workspace(nb)
-        _lib.call("acg_norm_bwd", _ptr(dy), _ptr(y), _ptr(mask), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gp), _ptr(bp), gstride, _ptr(dx),
-                  _ptr(dres), _ptr(dgamma), _ptr(dbeta), 0 if gstride else gshape[0], 1 if direct is not None else 0, G, P, C,
-                  act, unbiased, 1 if ctx.s16_dx else 0, _ptr(ws), nb, _stream())
+        part = None
+        if ctx.sums is not None:   # the consumer's data gradient already summed gy and gy * xhat per tile — of THIS dy?
+            s = ctx.sums
+            if s.part is not None and s.dx is not None and s.dx.data_ptr() == dy.data_ptr() and s.dx.shape == dy.shape:
+                part = s.part
+            s.clear()
+        if part is not None:
+            global NORM_SUMS_USED
+            NORM_SUMS_USED += 1
+            _lib.call("acg_norm_bwd_partials", _ptr(dy), _ptr(y), _ptr(mask), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gp), _ptr(bp),
+                      gstride, _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), 0 if gstride else gshape[0],
+                      1 if direct is not None else 0, G, P, C, act, unbiased, 1 if ctx.s16_dx else 0, _ptr(part), part.shape[1],
+                      _ptr(ws), nb, _stream())
+        else:
+            _lib.call("acg_norm_bwd", _ptr(dy), _ptr(y), _ptr(mask), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gp), _ptr(bp), gstride, _ptr(dx),
+                      _ptr(dres), _ptr(dgamma), _ptr(dbeta), 0 if gstride else gshape[0], 1 if direct is not None else 0, G, P, C,
+                      act, unbiased, 1 if ctx.s16_dx else 0, _ptr(ws), nb, _stream())
         if kind == "cin":
             dg, db = dgamma.view(G, C), dbeta.view(G, C)
         elif direct is not None:
@@ -720,7 +778,7 @@ class NormAct(torch.autograd.Function):
         elif ctx.lazy_dres is not None:
             ctx.lazy_dres.mask, ctx.lazy_dres.dy = mask, dy
             dres = dy
-        return dx, dg, db, dres, None, None, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dg, db, dres, None, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 class SyncBatchNormAct(torch.autograd.Function):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ACG_VERSION 110
+#define ACG_VERSION 111
 
 typedef enum {
     ACG_OK = 0,
@@ -142,6 +142,24 @@ int acg_conv2d_fwd_s16(const acg_conv_desc *d, const void *x_s16, const float *w
 int acg_conv2d_bwd_data_s16(const acg_conv_desc *d, const void *dy_s16, const float *wb, void *dx, void *ws, size_t ws_bytes,
                             const float *addend, const unsigned *addend_sign_mask, const void *relu_src_s16, int out_s16,
                             void *stream);
+/* ... that also produces the first pass of the backward of the (Cond)InstanceNorm whose OUTPUT gradient dx is
+ * (modules.py:83-97, 121-131: y = act(norm(x) * gamma + beta [+ res]); fp32 dx only): per 128-pixel tile of dx the sums
+ * part[((n * (Hi*Wi/128) + tile) * 2 + {0, 1}) * Ci + c] = (sum gy, sum gy * xhat), gy = dx * act'(y), xhat = (x - mean) *
+ * rstd — what acg_norm_bwd computes in a pass of its own over dx and x; hand them to acg_norm_bwd_partials.  The activation
+ * mask comes from sign_mask (the bitmask acg_norm_apply stored) or, when that is NULL, is recomputed from x with gamma /
+ * beta (gstride 0 or Ci); act NONE or RELU. */
+typedef struct acg_norm_sums {
+    const float *x, *mean, *rstd;     /* the norm's input (N,Hi,Wi,Ci) and its statistics [N*Ci] */
+    const float *gamma, *beta;        /* read only when act != NONE and sign_mask == NULL */
+    int gstride;
+    const unsigned *sign_mask;
+    int act;
+    float *part;
+} acg_norm_sums;
+int acg_conv2d_bwd_data_s16_sums_supported(const acg_conv_desc *d);
+int acg_conv2d_bwd_data_s16_sums(const acg_conv_desc *d, const void *dy_s16, const float *wb, float *dx, void *ws,
+                                 size_t ws_bytes, const float *addend, const unsigned *addend_sign_mask,
+                                 const acg_norm_sums *ns, void *stream);
 /* x and dy S16; dw / db as acg_conv2d_bwd_weight */
 int acg_conv2d_bwd_weight_s16(const acg_conv_desc *d, const void *x_s16, const void *dy_s16, float *dw, float *db, int Or,
                               int Ir, void *ws, size_t ws_bytes, int accumulate, void *stream);
@@ -206,6 +224,13 @@ int acg_norm_bwd(const float *dy, const float *y, const unsigned *sign_mask, con
                  int nparam, int accumulate, int G, size_t P, int C, int act, int unbiased, int dx_s16, void *workspace,
                  size_t ws_bytes, void *stream);
 /* dx_s16 != 0: dx is written pre-split (S16) for the convolution gradients that consume it (ReLU, no dres, C % 8 == 0) */
+/* the same with the first pass already done: part[((g * nchunks + chunk) * 2 + {0, 1}) * C + c] partial sums over any
+ * partition of the P rows into nchunks chunks (acg_conv2d_bwd_data_s16_sums: 128-pixel tiles) */
+int acg_norm_bwd_partials(const float *dy, const float *y, const unsigned *sign_mask, const float *x, const float *mean,
+                          const float *rstd, const float *gamma, const float *beta, int gstride, float *dx, float *dres,
+                          float *dgamma, float *dbeta, int nparam, int accumulate, int G, size_t P, int C, int act,
+                          int unbiased, int dx_s16, const float *part, int nchunks, void *workspace, size_t ws_bytes,
+                          void *stream);
 
 /* the two halves of acg_norm_bwd, for SyncBN: local sums[(g*2+{0,1})*C+c] = (sum gy, sum gy*xhat), then — after the
  * caller has all-reduced them — the apply pass with the GLOBAL pixel count Ptot. */

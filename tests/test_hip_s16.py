@@ -96,6 +96,46 @@ def test_generator_with_presplit_trunk_matches_fp32_storage(kind):
     print("worst parameter gradient vs exact fp32, pre-split: %.2e" % worst)
 
 
+@pytest.mark.parametrize("kind", ["plain", "cin"])
+def test_norm_backward_sums_from_the_data_gradient_epilogue(kind):
+    """256 x 256 input -> 128 x 128 x 128 trunk: whole-row tiles, so the trunk's data gradients run on the un-padded grid and
+    emit the backward sums of the norm in front of them (ops.NormSums, acg_conv2d_bwd_data_s16_sums).  Same generator, same
+    input, with and without that fusion: the sums are the same numbers added in another order (modules.py:83-97, 121-131)."""
+    from dtgan_amd import ops
+    from hip_util import precision
+    torch.manual_seed(3)
+    xin = torch.randn(1, 3, 256, 256, device="cuda")
+    z = torch.randn(1, 8, 1, 1, device="cuda")
+    res = {}
+    with precision("bf16x3"):
+        for fused in (True, False):
+            net = _gen(kind, 3, 5)
+            x = xin.clone().requires_grad_(True)
+            old, ops.NORM_SUMS = ops.NORM_SUMS, fused
+            used0 = ops.NORM_SUMS_USED
+            try:
+                y = net(x, z) if kind == "cin" else net(x)
+                (y * torch.linspace(-1, 1, y.numel(), device="cuda").view_as(y)).sum().backward()
+            finally:
+                ops.NORM_SUMS = old
+            used = ops.NORM_SUMS_USED - used0
+            # the norm in front of the first block + per block: its output norm (all but the last block's) and, in a
+            # CINResnetBlock, the conditional norm between its two convolutions
+            assert used == ((1 + 2 + 3 if kind == "cin" else 1 + 2) if fused else 0), used
+            res[fused] = (y.detach(), x.grad.detach(), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
+    ya, ga, pa = res[True]
+    yb, gb, pb = res[False]
+    assert torch.equal(ya, yb)
+    assert (ga - gb).abs().max().item() <= 2e-5 * gb.abs().max().item()
+    for k in pb:
+        # (a convolution bias in front of a norm has the exact gradient 0: what both runs hold there is the rounding noise of
+        # its layer's sums, measured against the weight gradient of the same layer)
+        noise = 0.0
+        if k.endswith(".bias") and k.replace(".bias", ".weight") in pb:
+            noise = 1e-4 * pb[k.replace(".bias", ".weight")].abs().max().item()
+        assert (pa[k] - pb[k]).abs().max().item() <= 2e-5 * pb[k].abs().max().item() + noise + 1e-12, k
+
+
 def test_presplit_trunk_in_eval_and_no_grad():
     from dtgan_amd import ops
     from hip_util import precision, rel

@@ -11,6 +11,6 @@ if [ $rc -gt 1 ]; then echo "pytest rc=$rc: stopping"; exit $rc; fi
 if [ $rc -ne 0 ]; then exit $rc; fi
 fi
 for i in 1 2; do
-env ACG_DEBUG_SWITCHES=1 $SW=1 timeout -k 10 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$SW=1', d['ms_per_step'])" || exit 1
+env ACG_DEBUG_SWITCHES=1 ACGAN_DEBUG_SWITCHES=1 $SW=1 timeout -k 10 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$SW=1', d['ms_per_step'])" || exit 1
 timeout -k 10 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('default', d['ms_per_step'])" || exit 1
 done
