@@ -699,34 +699,43 @@ __global__ __launch_bounds__(256) void dgrad_colfix_kernel(const char *__restric
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const cf_bf16x8 zero = {};
-    const int nch = C / 16;
-    // kernel rows 0..2, then the corner term of the tile that holds row 1 (kh 0, dy row 0) or row H-2 (kh 2, dy row H-1)
+    // kernel rows 0..2, then the corner term of the tile that holds row 1 (kh 0, dy row 0) or row H-2 (kh 2, dy row H-1).
+    // A step is 128 channels = eight 16-channel chunks whose 32 fragment loads are issued together, the next step's before this
+    // step's MFMAs (one wave per SIMD: registers are free, memory latency is the whole cost of this kernel).
     const int extra = qy0 == 0 ? 0 : (qy0 + 32 == H ? 2 : -1);
-    for (int step = 0; step < 3 + (extra >= 0 ? 1 : 0); ++step) {
+    const int nsteps = (3 + (extra >= 0 ? 1 : 0)) * (C / 128);
+    cf_bf16x8 ah[2][8], al[2][8], bh[2][8], bl[2][8];
+    auto load = [&](int s, int b) {
+        const int step = s / (C / 128), c128 = s - step * (C / 128);
         const int kh = step < 3 ? step : extra;
         int ry;
         bool ok;
         if (step < 3) { ry = qy + 1 - kh; ok = (unsigned)ry < (unsigned)H; }
         else { ry = extra == 0 ? 0 : H - 1; ok = qy == (extra == 0 ? 1 : H - 2); }
-        const char *ap = dy + (((long long)n * H + (ok ? ry : 0)) * W + col) * C * 4 + kg * 32;
-        const __bf16 *bp = wb + ((long long)(kh * 3 + kw) * nch * CiP + ci) * 16 + kg * 8;
-        for (int c0 = 0; c0 < nch; c0 += 4) { // four 16-channel chunks per trip (C % 64 == 0), their loads issued together
-            cf_bf16x8 ah[4], al[4], bh[4], bl[4];
+        const char *ap = dy + (((long long)n * H + (ok ? ry : 0)) * W + col) * C * 4 + c128 * 512 + kg * 32;
+        const __bf16 *bp = wb + (((long long)(kh * 3 + kw) * (C / 16) + c128 * 8) * CiP + ci) * 16 + kg * 8;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int cc = c0 + u;
-                ah[u] = zero; al[u] = zero;
-                if (ok) { ah[u] = *(const cf_bf16x8 *)(ap + cc * 64); al[u] = *(const cf_bf16x8 *)(ap + cc * 64 + 16); }
-                bh[u] = *(const cf_bf16x8 *)(bp + (long long)cc * CiP * 16);
-                bl[u] = *(const cf_bf16x8 *)(bp + w_lo_elems + (long long)cc * CiP * 16);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[u], bh[u], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], bl[u], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], bh[u], acc, 0, 0, 0);
-            }
+        for (int u = 0; u < 8; ++u) {
+            ah[b][u] = zero; al[b][u] = zero;
+            if (ok) { ah[b][u] = *(const cf_bf16x8 *)(ap + u * 64); al[b][u] = *(const cf_bf16x8 *)(ap + u * 64 + 16); }
+            bh[b][u] = *(const cf_bf16x8 *)(bp + (long long)u * CiP * 16);
+            bl[b][u] = *(const cf_bf16x8 *)(bp + w_lo_elems + (long long)u * CiP * 16);
         }
+    };
+    auto mma = [&](int b) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[b][u], bh[b][u], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[b][u], bl[b][u], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[b][u], bh[b][u], acc, 0, 0, 0);
+        }
+    };
+    load(0, 0);
+    for (int s = 0; s < nsteps; s += 2) {   // two steps per trip: the buffer index stays a compile-time constant
+        if (s + 1 < nsteps) load(s + 1, 1);
+        mma(0);
+        if (s + 2 < nsteps) load(s + 2, 0);
+        if (s + 1 < nsteps) mma(1);
     }
     if (ci < Cdx) {
 #pragma unroll
@@ -752,7 +761,7 @@ static bool dgrad_unpad_ok(const acg_conv_desc *d)
 {
     static const bool no_unpad = acg_debug_switch("ACG_NO_UNPAD");   // A/B switch
     return !no_unpad && d->stride == 1 && d->pad_mode == ACG_PAD_REFLECT && d->K == 3 && d->pad == 1 && d->Wi % 128 == 0 &&
-           d->Hi % 32 == 0 && d->Hi >= 64 && d->Co % 64 == 0;
+           d->Hi % 32 == 0 && d->Hi >= 64 && d->Co % 128 == 0;
 }
 
 static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb, const float *bias, float *dst,
@@ -791,7 +800,7 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
             for (int kh = 0; kh < K; ++kh)
                 for (int kw = 0; kw < K; ++kw) { t.dy[t.n] = (short)(p - kh); t.dx[t.n] = (short)(p - kw); t.w[t.n] = (short)(kh * K + kw); t.n++; }
             ACG_REQUIRE(acg_igemm_x3_pre_ok(g, t) && (relu_s16 == 0 || out_s16) && (out_s16 == 0 || addend == nullptr) &&
-                        (relu_src == nullptr || relu_s16 == out_s16) && d->Co % 64 == 0,
+                        (relu_src == nullptr || relu_s16 == out_s16) && d->Co % 128 == 0,
                         "dgrad: unsupported pre-split combination (query acg_conv2d_s16_supported)");
             const int CiP = acg_ncols_pad(d->Ci);
             hipLaunchKernelGGL(dgrad_colfix_kernel, dim3(d->N * (d->Hi / 32), 2, CiP / 128), dim3(256), 0, st, (const char *)src,

@@ -349,7 +349,7 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
     // Epilogue through LDS: the tile (accumulator + bias, activation) is staged in the LDS the main loop no longer needs
     // and leaves in coalesced rows.
     constexpr int TS = BN; // row stride (floats)
-    static_assert(BM * TS * 4 + 2 * 8 * BN * 4 <= LDS_BYTES, "the staged tile (and the scratch of the sums pass) must fit the LDS buffers");
+    static_assert(BM * TS * 4 <= LDS_BYTES, "the staged tile must fit the LDS buffers");
     float *tile = (float *)lds;
     __syncthreads(); // every consumer wave is done with the last LDS buffer (the producers have exited)
 #pragma unroll
@@ -370,58 +370,6 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
             tile[row * TS + c] += g.colfix[((size_t)grow * 2 + sd) * g.Cout + n0 + c];
         __syncthreads();
     }
-    // Geom.ns_part: the tile is one 128-pixel chunk of the gradient w.r.t. a norm's output — its share of that norm's backward
-    // sums (norm.hip norm_bwd_partial: gy = dy * act'(y), S1 = sum gy, S2 = sum gy * xhat) leaves with it, read from the
-    // staged tile once it holds the FINAL values.  Thread = 4 channels x 16 rows, the norm's input rows fetched eight at a time.
-    auto emit_sums = [&]() {
-        __syncthreads();
-        const int cq = tid & 31, rg = tid >> 5, c = n0 + cq * 4;
-        const int img = m0 / GHW, chunk = (m0 - img * GHW) / BM;
-        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
-        if (c < g.Cout) {
-            const f32x4 mu = *(const f32x4 *)(g.ns_mean + (size_t)img * g.Cout + c), rs = *(const f32x4 *)(g.ns_rstd + (size_t)img * g.Cout + c);
-            const bool remask = g.ns_act != ACG_ACT_NONE && g.ns_mask == nullptr;
-            f32x4 ga = s1, be = s1;
-            if (remask) { ga = *(const f32x4 *)(g.ns_gamma + (size_t)img * g.ns_gstride + c); be = *(const f32x4 *)(g.ns_beta + (size_t)img * g.ns_gstride + c); }
-            const unsigned *mk = g.ns_mask != nullptr ? g.ns_mask : (const unsigned *)g.ns_x;
-#pragma unroll 1
-            for (int rb = 0; rb < 16; rb += 8) {
-                f32x4 xv[8];
-                unsigned nb[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const size_t o = (size_t)(m0 + rg * 16 + rb + u) * g.Cout + c;
-                    xv[u] = *(const f32x4 *)(g.ns_x + o);
-                    const size_t f = o >> 2;
-                    nb[u] = (mk[f >> 3] >> (4 * (int)(f & 7))) & 15u;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    f32x4 gy = *(const f32x4 *)&tile[(rg * 16 + rb + u) * TS + cq * 4];
-                    const f32x4 xh = (xv[u] - mu) * rs;
-                    if (g.ns_act != ACG_ACT_NONE) {
-                        const f32x4 yy = xh * ga + be; // same expression as norm_apply_kernel: its sign is the mask
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) gy[q] = (remask ? yy[q] > 0.f : ((nb[u] >> q) & 1u) != 0u) ? gy[q] : 0.f;
-                    }
-                    s1 += gy;
-                    s2 += gy * xh;
-                }
-            }
-        }
-        float *sc = (float *)(lds + BM * TS * 4); // [2][8 row groups][BN]
-        *(f32x4 *)&sc[(0 * 8 + rg) * BN + cq * 4] = s1;
-        *(f32x4 *)&sc[(1 * 8 + rg) * BN + cq * 4] = s2;
-        __syncthreads();
-        if (tid < 64) {
-            const int k = tid >> 5, cc = tid & 31;
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < 8; ++r) a += *(const f32x4 *)&sc[(k * 8 + r) * BN + cc * 4];
-            if (n0 + cc * 4 < g.Cout)
-                *(f32x4 *)(g.ns_part + ((size_t)(img * (GHW / BM) + chunk) * 2 + k) * g.Cout + n0 + cc * 4) = a;
-        }
-    };
     if constexpr (STATS) {
         // per-tile (mean, M2) of the 128 output pixels of every channel for the InstanceNorm that follows (conv_x3.hip)
         float *redf = &red[0][0][0]; // 256 floats
@@ -482,7 +430,7 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
         }
         return;
     }
-    if (g.addend == nullptr && g.relu_src == nullptr) {
+    if (g.addend == nullptr && g.relu_src == nullptr && g.ns_part == nullptr) {
 #pragma unroll 4
         for (int k = 0; k < BM * (BN / 4) / 256; ++k) { // 16 float4 per thread, consecutive lanes on consecutive channels
             const int idx = tid + 256 * k, row = idx / (BN / 4), c4 = idx - row * (BN / 4);
@@ -490,57 +438,99 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
             if (po != NO_PIX && n0 + c4 * 4 < g.Cout)
                 *(f32x4 *)(((po >> 31) ? base1 : base0) + (size_t)(po & 0x7fffffffu) * 16 + (size_t)(n0 + c4 * 4) * 4) = *(const f32x4 *)&tile[row * TS + c4 * 4];
         }
-        if (g.ns_part != nullptr) emit_sums();
         return;
     }
     // Data-gradient epilogue with fp32 side inputs (skip gradient and its sign bitmask; fp32 ReLU source): four rows at a
     // time, every side load issued before the first is used; rows without a side input read a dummy address instead of
-    // branching (conv_x3.hip)
+    // branching (conv_x3.hip).
+    // Geom.ns_part: the tile is one 128-pixel chunk of the gradient w.r.t. a norm's output, and its share of that norm's
+    // backward sums (norm.hip norm_bwd_partial: gy = dy * act'(y), S1 = sum gy, S2 = sum gy * xhat) leaves with it: the
+    // norm's input rides along as one more side stream (same addresses as the output), a thread sums its 16 rows of 4
+    // channels in registers and the 8 row groups meet in LDS behind the loop.
     const char *dummy = in;
     const unsigned *amask = g.addend_mask != nullptr ? g.addend_mask : (const unsigned *)in;
+    const bool sums = g.ns_part != nullptr;
+    const unsigned *nmask = sums && g.ns_mask != nullptr ? g.ns_mask : (const unsigned *)in;
+    const bool remask = sums && g.ns_act != ACG_ACT_NONE && g.ns_mask == nullptr;
+    const int cq = tid & 31, img = m0 / GHW;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, mu = s1, rs = s1, ga = s1, be = s1;
+    if (sums && n0 + cq * 4 < g.Cout) {
+        mu = *(const f32x4 *)(g.ns_mean + (size_t)img * g.Cout + n0 + cq * 4);
+        rs = *(const f32x4 *)(g.ns_rstd + (size_t)img * g.Cout + n0 + cq * 4);
+        if (remask) {
+            ga = *(const f32x4 *)(g.ns_gamma + (size_t)img * g.ns_gstride + n0 + cq * 4);
+            be = *(const f32x4 *)(g.ns_beta + (size_t)img * g.ns_gstride + n0 + cq * 4);
+        }
+    }
     constexpr int EB = 4;
 #pragma unroll 1
     for (int kb = 0; kb < BM * (BN / 4) / 256; kb += EB) {
-        unsigned po[EB], nb[EB];
-        size_t bo[EB];
-        f32x4 v[EB], mv[EB], av[EB];
-        bool side[EB];
+        unsigned po[EB], nb[EB], xb[EB];
+        f32x4 v[EB], mv[EB], av[EB], xv[EB];
+        // (byte offsets and flags are recomputed from po where they are used: kept in arrays they cost the registers that
+        // separate this kernel from spilling)
+        auto boff = [&](unsigned p) { return (size_t)(p & 0x7fffffffu) * 16 + (size_t)(n0 + cq * 4) * 4; };
 #pragma unroll
         for (int u = 0; u < EB; ++u) {
-            const int idx = tid + 256 * (kb + u), row = idx / (BN / 4), c4 = idx - row * (BN / 4);
+            const int row = (tid >> 5) + 8 * (kb + u);   // idx = tid + 256 (kb + u): row idx / 32, channel group idx % 32 = cq
             po[u] = pix_off[row];
-            side[u] = po[u] != NO_PIX && (po[u] >> 31);
-            bo[u] = (size_t)(po[u] & 0x7fffffffu) * 16 + (size_t)(n0 + c4 * 4) * 4;
-            if (n0 + c4 * 4 >= g.Cout) po[u] = NO_PIX;
-            v[u] = *(const f32x4 *)&tile[row * TS + c4 * 4];
+            v[u] = *(const f32x4 *)&tile[row * TS + cq * 4];
         }
 #pragma unroll
         for (int u = 0; u < EB; ++u) {
-            const bool hm = side[u] && g.relu_src != nullptr, ha = side[u] && g.addend != nullptr;
-            mv[u] = *(const f32x4 *)(hm ? (const char *)g.relu_src + bo[u] : dummy);
-            av[u] = *(const f32x4 *)(ha ? (const char *)g.addend + bo[u] : dummy);
-            const size_t f = ha ? bo[u] >> 4 : 0;   // float4 index of these 4 elements
+            const bool sd = po[u] != NO_PIX && (po[u] >> 31);
+            const bool hm = sd && g.relu_src != nullptr, ha = sd && g.addend != nullptr, hx = sd && sums;
+            const size_t bo = boff(po[u]);
+            mv[u] = *(const f32x4 *)(hm ? (const char *)g.relu_src + bo : dummy);
+            av[u] = *(const f32x4 *)(ha ? (const char *)g.addend + bo : dummy);
+            xv[u] = *(const f32x4 *)(hx ? (const char *)g.ns_x + bo : dummy);
+            const size_t f = ha ? bo >> 4 : 0;   // float4 index of these 4 elements
             nb[u] = (amask[f >> 3] >> (4 * (int)(f & 7))) & 15u;
+            const size_t fx = hx ? bo >> 4 : 0;
+            xb[u] = (nmask[fx >> 3] >> (4 * (int)(fx & 7))) & 15u;
         }
 #pragma unroll
         for (int u = 0; u < EB; ++u) {
-            if (side[u] && g.relu_src != nullptr) {
+            const bool sd = po[u] != NO_PIX && (po[u] >> 31), live = po[u] != NO_PIX && n0 + cq * 4 < g.Cout;
+            if (sd && g.relu_src != nullptr) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[u][q] = mv[u][q] > 0.f ? v[u][q] : 0.f;
             }
-            if (side[u] && g.addend != nullptr) {
+            if (sd && g.addend != nullptr) {
                 if (g.addend_mask == nullptr) nb[u] = 15u;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[u][q] += (nb[u] >> q) & 1u ? av[u][q] : 0.f;
             }
-            if (po[u] != NO_PIX) *(f32x4 *)(((po[u] >> 31) ? base1 : base0) + bo[u]) = v[u];
-            if (g.ns_part != nullptr) { // the final value back into the staged tile for the sums pass
-                const int idx = tid + 256 * (kb + u), row = idx / (BN / 4), c4 = idx - row * (BN / 4);
-                *(f32x4 *)&tile[row * TS + c4 * 4] = v[u];
+            if (live) *(f32x4 *)(((po[u] >> 31) ? base1 : base0) + boff(po[u])) = v[u];
+            if (sums && live) {
+                f32x4 gy = v[u];
+                const f32x4 xh = (xv[u] - mu) * rs;
+                if (g.ns_act != ACG_ACT_NONE) {
+                    const f32x4 yy = xh * ga + be; // same expression as norm_apply_kernel: its sign is the mask
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) gy[q] = (remask ? yy[q] > 0.f : ((xb[u] >> q) & 1u) != 0u) ? gy[q] : 0.f;
+                }
+                s1 += gy;
+                s2 += gy * xh;
             }
         }
     }
-    if (g.ns_part != nullptr) emit_sums();
+    if (sums) { // thread (cq, tid >> 5) holds rows (tid >> 5) + 8 j of channels 4 cq .. 4 cq + 3
+        __syncthreads(); // every thread is done reading the staged tile: its LDS becomes the scratch [2][8 row groups][BN]
+        float *sc = (float *)lds;
+        const int rg = tid >> 5;
+        *(f32x4 *)&sc[(0 * 8 + rg) * BN + cq * 4] = s1;
+        *(f32x4 *)&sc[(1 * 8 + rg) * BN + cq * 4] = s2;
+        __syncthreads();
+        if (tid < 64) {
+            const int k = tid >> 5, cc = tid & 31, chunk = (m0 - img * GHW) / BM;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 8; ++r) a += *(const f32x4 *)&sc[(k * 8 + r) * BN + cc * 4];
+            if (n0 + cc * 4 < g.Cout)
+                *(f32x4 *)(g.ns_part + ((size_t)(img * (GHW / BM) + chunk) * 2 + k) * g.Cout + n0 + cc * 4) = a;
+        }
+    }
 }
 
 // Row-patch geometry the pre-split kernel needs: K x K tap lists in kernel-row order (forward: dx ascending, stride-1 data

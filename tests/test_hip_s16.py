@@ -129,10 +129,10 @@ def test_norm_backward_sums_from_the_data_gradient_epilogue(kind):
     assert (ga - gb).abs().max().item() <= 2e-5 * gb.abs().max().item()
     for k in pb:
         # (a convolution bias in front of a norm has the exact gradient 0: what both runs hold there is the rounding noise of
-        # its layer's sums, measured against the weight gradient of the same layer)
+        # sums over 16 k pixels, allowed for against the weight gradient of the same layer)
         noise = 0.0
         if k.endswith(".bias") and k.replace(".bias", ".weight") in pb:
-            noise = 1e-4 * pb[k.replace(".bias", ".weight")].abs().max().item()
+            noise = 5e-4 * pb[k.replace(".bias", ".weight")].abs().max().item()
         assert (pa[k] - pb[k]).abs().max().item() <= 2e-5 * pb[k].abs().max().item() + noise + 1e-12, k
 
 
