@@ -40,6 +40,14 @@ class AdamGroup(ctypes.Structure):
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_size_t), ("sumsq", c_void_p)]
 
 
+MAX_SEGMENTS = 96
+
+
+class Segments(ctypes.Structure):
+    """acg_segments (include/acgan_hip.h)."""
+    _fields_ = [("dst", c_void_p * MAX_SEGMENTS), ("off", c_int * MAX_SEGMENTS), ("len", c_int * MAX_SEGMENTS), ("n", c_int)]
+
+
 class NormSumsDesc(ctypes.Structure):
     """acg_norm_sums (include/acgan_hip.h)."""
     _fields_ = [("x", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
@@ -110,6 +118,7 @@ SIGNATURES = {
     "acg_latent_mlp_supported": (c_int, [c_int, c_int, c_int]),
     "acg_latent_mlp_fwd": (c_int, [_MP, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P]),
     "acg_latent_mlp_bwd": (c_int, [_MP, _MG, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
+    "acg_segments_accumulate": (c_int, [_P, ctypes.POINTER(Segments), c_int, _P]),
     "acg_spatial_mean_fwd": (c_int, [_P, _P, c_int, c_size_t, c_int, _P]),
     "acg_spatial_mean_bwd": (c_int, [_P, _P, c_int, c_size_t, c_int, _P]),
     "acg_reduce_workspace_bytes": (c_size_t, [c_size_t]),

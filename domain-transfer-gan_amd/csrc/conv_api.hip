@@ -811,7 +811,7 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
             if (ns != nullptr) {
                 g.ns_x = ns->x; g.ns_mean = ns->mean; g.ns_rstd = ns->rstd; g.ns_gamma = ns->gamma; g.ns_beta = ns->beta;
                 g.ns_gstride = ns->gstride; g.ns_mask = ns->sign_mask; g.ns_act = ns->act; g.ns_part = ns->part;
-                ACG_REQUIRE(ns->part != nullptr && (ns->gstride == 0 || ns->gstride == d->Ci), "dgrad: bad acg_norm_sums");
+                ACG_REQUIRE(ns->part != nullptr && (ns->gstride == 0 || (ns->gstride >= d->Ci && ns->gstride % 4 == 0)), "dgrad: bad acg_norm_sums");
             }
             return acg_igemm_x3_pre_launch(src, wb, bias, dst, g, t, g.w_elems, st);
         }

@@ -50,7 +50,9 @@ extern "C" int acg_debug_pre_stamps(unsigned long long *host, size_t n)
 }
 #endif
 
-template <bool REFLECT, bool STATS>
+// SUMS: the launch also emits the backward sums of the norm in front of it (Geom.ns_part) — a separate instantiation so that
+// kernel traces tell the two apart and the plain epilogue carries none of it
+template <bool REFLECT, bool STATS, bool SUMS = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
                   float *__restrict__ out, Geom g, Taps taps, unsigned in_bytes, unsigned w_bytes, unsigned w_lo_bytes,
@@ -430,7 +432,7 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
         }
         return;
     }
-    if (g.addend == nullptr && g.relu_src == nullptr && g.ns_part == nullptr) {
+    if (g.addend == nullptr && g.relu_src == nullptr && !SUMS) {
 #pragma unroll 4
         for (int k = 0; k < BM * (BN / 4) / 256; ++k) { // 16 float4 per thread, consecutive lanes on consecutive channels
             const int idx = tid + 256 * k, row = idx / (BN / 4), c4 = idx - row * (BN / 4);
@@ -449,7 +451,7 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
     // channels in registers and the 8 row groups meet in LDS behind the loop.
     const char *dummy = in;
     const unsigned *amask = g.addend_mask != nullptr ? g.addend_mask : (const unsigned *)in;
-    const bool sums = g.ns_part != nullptr;
+    constexpr bool sums = SUMS;
     const unsigned *nmask = sums && g.ns_mask != nullptr ? g.ns_mask : (const unsigned *)in;
     const bool remask = sums && g.ns_act != ACG_ACT_NONE && g.ns_mask == nullptr;
     const int cq = tid & 31, img = m0 / GHW;
@@ -588,11 +590,13 @@ int acg_igemm_x3_pre_launch(const void *in, const void *wp, const float *bias, f
                 "igemm_conv_x3_pre: the un-padded reflect data gradient needs whole-row tiles of a 3x3 layer");
     const unsigned inb = (unsigned)in_bytes, wb = (unsigned)w_bytes, wlo = (unsigned)(n_w_elems * 2);
     const Taps tp = acg_taps_pack(t);
-#define X3_PRE(R, S) hipLaunchKernelGGL((igemm_conv_x3_pre<R, S>), grid, dim3(512), 0, st, (const char *)in, (const __bf16 *)wp, bias, out, g, tp, inb, wb, wlo, stats, kdim, dxmin, kstep)
-    if (g.reflect) { if (stats) X3_PRE(true, true); else X3_PRE(true, false); }
-    else { if (stats) X3_PRE(false, true); else X3_PRE(false, false); }
+#define X3_PRE(R, S, U) hipLaunchKernelGGL((igemm_conv_x3_pre<R, S, U>), grid, dim3(512), 0, st, (const char *)in, (const __bf16 *)wp, bias, out, g, tp, inb, wb, wlo, stats, kdim, dxmin, kstep)
+    ACG_REQUIRE(g.ns_part == nullptr || (!g.reflect && stats == nullptr), "igemm_conv_x3_pre: norm sums on a forward launch");
+    if (g.reflect) { if (stats) X3_PRE(true, true, false); else X3_PRE(true, false, false); }
+    else if (g.ns_part != nullptr) X3_PRE(false, false, true);
+    else { if (stats) X3_PRE(false, true, false); else X3_PRE(false, false, false); }
 #undef X3_PRE
     ACG_CHECK_LAUNCH("igemm_conv_x3_pre");
-    acg_note_kernel("igemm_conv_x3_pre<REFLECT=%d,STATS=%d>", g.reflect ? 1 : 0, stats ? 1 : 0);
+    acg_note_kernel("igemm_conv_x3_pre<REFLECT=%d,STATS=%d%s>", g.reflect ? 1 : 0, stats ? 1 : 0, g.ns_part != nullptr ? ",SUMS=1" : "");
     return ACG_OK;
 }

@@ -337,6 +337,31 @@ extern "C" int acg_linear_bwd(const float *dy, const float *y, const float *x, c
     return ACG_OK;
 }
 
+// ---------------------------------------------------------------- one launch for many small copies / accumulations
+// dst[s][i] (+)= src[off[s] + i]: the per-layer slices of a concatenated gradient into the layers' own .grad tensors
+__global__ void segments_accumulate_kernel(const float *__restrict__ src, acg_segments sg, int accumulate)
+{
+    const int s = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sg.len[s]) return;
+    float *d = (float *)sg.dst[s];
+    const float v = src[(long long)sg.off[s] + i];
+    d[i] = accumulate ? d[i] + v : v;
+}
+extern "C" int acg_segments_accumulate(const float *src, const acg_segments *segs, int accumulate, void *stream)
+{
+    ACG_REQUIRE(segs != nullptr && segs->n >= 0 && segs->n <= ACG_MAX_SEGMENTS, "acg_segments_accumulate: bad segment count");
+    int mx = 0;
+    for (int s = 0; s < segs->n; ++s) {
+        ACG_REQUIRE(segs->dst[s] != nullptr && segs->len[s] >= 0 && segs->off[s] >= 0, "acg_segments_accumulate: bad segment %d", s);
+        mx = segs->len[s] > mx ? segs->len[s] : mx;
+    }
+    if (segs->n == 0 || mx == 0) return ACG_OK;
+    hipLaunchKernelGGL(segments_accumulate_kernel, dim3(acg_cdiv(mx, 256), segs->n), dim3(256), 0, (hipStream_t)stream, src, *segs,
+                       accumulate);
+    ACG_CHECK_LAUNCH("segments_accumulate_kernel");
+    return ACG_OK;
+}
+
 // ---------------------------------------------------------------- spatial mean [N][P][Cp] -> [N][Cp]
 __global__ void spatial_mean_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, long long P, int Cp)
 {

@@ -193,7 +193,7 @@ class TwoInputSequential(nn.Sequential, TwoInputModule):
 
     def forward(self, input1, input2):
         x = ops.ToNHWC.apply(input1)
-        y, C = run_sequence(list(self._modules.values()), x, input1.shape[1], as_latent(input2))
+        y, C = run_sequence(list(self._modules.values()), x, input1.shape[1], cond_bank(self, as_latent(input2)))
         return ops.ToNCHW.apply(y, C)
 
 
@@ -258,8 +258,12 @@ class CondInstanceNorm(TwoInputModule):
 
     def forward_act(self, x, z, act=ACT_NONE, stats=None, s16_out=False, s16_dx=False, sums=None):
         Cp = x.shape[-1]
-        sh = ops.LinearFn.apply(z, self.shift_conv[0].weight, self.shift_conv[0].bias, ACT_RELU, Cp)
-        sc = ops.LinearFn.apply(z, self.scale_conv[0].weight, self.scale_conv[0].bias, ACT_RELU, Cp)
+        bank = getattr(z, "_acg_bank", None)   # every scale / shift of the generator computed in one launch (cond_bank)
+        if bank is not None and id(self) in bank and bank[id(self)][0].shape == (x.shape[0], Cp):
+            sc, sh = bank[id(self)]
+        else:
+            sh = ops.LinearFn.apply(z, self.shift_conv[0].weight, self.shift_conv[0].bias, ACT_RELU, Cp)
+            sc = ops.LinearFn.apply(z, self.scale_conv[0].weight, self.scale_conv[0].bias, ACT_RELU, Cp)
         y = ops.NormAct.apply(x, sc, sh, None, "cin", act, self.eps, None, None, None, None, 0.0, None, stats, s16_out, s16_dx,
                               False, sums)
         return ops.tag_s16(y) if s16_out else y
@@ -267,6 +271,28 @@ class CondInstanceNorm(TwoInputModule):
     def forward(self, input, noise):
         y = self.forward_act(ops.ToNHWC.apply(input), as_latent(noise))
         return ops.ToNCHW.apply(y, self.x_dim)
+
+
+def cond_bank(root, z):
+    """Tag latent z with the (scale, shift) pairs of every CondInstanceNorm under `root`, computed by ONE dense layer
+    (ops.CondBankFn) instead of two small ones per norm; norms of a width of their own (not the majority's) keep theirs."""
+    if not ops.COND_BANK:
+        return z
+    norms = [m for m in root.modules() if isinstance(m, CondInstanceNorm)]
+    if len(norms) < 2:
+        return z
+    widths = [m.x_dim for m in norms]
+    C = max(set(widths), key=widths.count)
+    norms = [m for m in norms if m.x_dim == C and C % 16 == 0 and m.z_dim == norms[0].z_dim]
+    if len(norms) < 2 or 2 * len(norms) > ops._lib.MAX_SEGMENTS // 2:
+        return z
+    params = []
+    for m in norms:
+        params += [m.scale_conv[0].weight, m.scale_conv[0].bias, m.shift_conv[0].weight, m.shift_conv[0].bias]
+    outs = ops.CondBankFn.apply(z, C, *params)
+    z = z.view(z.shape)   # the tag goes on an alias: the caller's tensor may feed other networks
+    z._acg_bank = {id(m): (outs[2 * k], outs[2 * k + 1]) for k, m in enumerate(norms)}
+    return z
 
 
 _ACTS = {nn.ReLU: ACT_RELU, nn.LeakyReLU: ACT_LRELU, nn.Tanh: ACT_TANH}

@@ -20,7 +20,7 @@ import torch.nn as nn
 from . import modules, ops
 from .modules import (ResnetBlock, CondInstanceNorm, TwoInputSequential, CINResnetBlock, InstanceNorm2d,  # noqa: F401
                       Conv2d, ConvTranspose2d, BatchNorm2d, BatchNorm1d, Linear, Sequential, run_sequence,
-                      run_dense, as_latent, mark_dirty)
+                      run_dense, as_latent, mark_dirty, cond_bank)
 
 
 ###############################################################################
@@ -157,7 +157,7 @@ class CINResnetGenerator(nn.Module):
 
     def forward_nhwc(self, x, z):
         """x: NHWC C16, z: (N, >=nlatent) -> NHWC C16 (output_nc valid channels)"""
-        return run_sequence(list(self.model._modules.values()), x, self.input_nc, z)[0]
+        return run_sequence(list(self.model._modules.values()), x, self.input_nc, cond_bank(self.model, z))[0]
 
     def forward(self, input, noise):
         return self.model(input, noise)

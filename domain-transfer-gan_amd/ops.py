@@ -195,7 +195,8 @@ class PackedConv(object):
 
 
 class ConvTimer(object):
-    """bench.py hook: HIP events (on the launch stream) around the launches of ONE pass ("fwd", "dgrad" or "wgrad") of ONE
+    """bench.py hook: HIP events (on the launch stream) around the launches of ONE pass ("fwd", "dgrad", "wgrad", or
+    "dgrad_sums": the data-gradient launches that also emit the backward sums of the norm in front, ops.NormSums) of ONE
     conv shape, so the roofline numerator/denominator come from the live timed region."""
 
     def __init__(self, match, kind="fwd"):
@@ -537,7 +538,11 @@ def _conv_backward_s16(ctx, x, dy, dskip):
         dx = torch.empty_like(x)
         nb = _lib.query("acg_conv2d_bwd_data_workspace_bytes", ctypes.byref(d))
         ws = workspace(nb) if nb else None
-        span = ConvTimer.span("dgrad", d)
+        ns = ctx.norm_sums if not p.dx else None
+        if ns is not None and not (ns.x is not None and tuple(ns.x.shape) == tuple(dx.shape) and
+                                   _lib.query("acg_conv2d_bwd_data_s16_sums_supported", ctypes.byref(d))):
+            ns = None
+        span = ConvTimer.span("dgrad_sums" if ns is not None else "dgrad", d)
         if p.dx:     # the gradient w.r.t. the pre-activation of the conv + ReLU in front, pre-split for its own backward
             if dskip is not None or ctx.link_in is None:
                 raise _lib.AcgError("pre-split trunk: unexpected skip gradient / missing ReLU link")
@@ -550,9 +555,7 @@ def _conv_backward_s16(ctx, x, dy, dskip):
                 dskip = dskip.contiguous()
                 if ctx.skip_grad is not None:
                     dskip, smask = ctx.skip_grad.take(dskip)
-            ns = ctx.norm_sums
-            if ns is not None and ns.x is not None and tuple(ns.x.shape) == tuple(dx.shape) and \
-                    _lib.query("acg_conv2d_bwd_data_s16_sums_supported", ctypes.byref(d)):
+            if ns is not None:
                 # dx is the gradient w.r.t. the output of the norm in front: its backward sums leave with the tiles
                 part = torch.empty((d.N, (d.Hi * d.Wi) // STATS_ROWS, 2, d.Ci), device=dx.device, dtype=torch.float32)
                 desc = ns.desc(part)
@@ -683,12 +686,18 @@ class NormAct(torch.autograd.Function):
             G, P = N, rows // N
         unbiased = 1 if kind == "cin" else (2 if kind == "bn_eval" else 0)
         if kind == "cin":
-            gp, bp, gstride = gamma.contiguous(), beta.contiguous(), C
-            if gp.shape != (N, C):
+            # (N, Cp) rows, possibly column blocks of a wider matrix (CondBankFn): the kernels take the row stride
+            if gamma.shape != (N, C) or beta.shape != (N, C):
                 raise _lib.AcgError("cin: scale/shift must be (N, Cp)")
+            ok = gamma.stride(1) == 1 and beta.stride(1) == 1 and gamma.stride(0) == beta.stride(0) and gamma.stride(0) >= C \
+                and gamma.stride(0) % 4 == 0 and gamma.data_ptr() % 16 == 0 and beta.data_ptr() % 16 == 0
+            if ok:
+                gp, bp, gstride = gamma, beta, gamma.stride(0)
+            else:
+                gp, bp, gstride = gamma.contiguous(), beta.contiguous(), C
         else:
             gp, bp, gstride = gamma_p, beta_p, 0
-        _check(gp, bp)
+        _check(gp if gp.is_contiguous() else None, bp if bp.is_contiguous() else None)   # (strided scale / shift: checked above)
         st = _stream()
         mean = torch.empty(G * C, device=x.device, dtype=torch.float32)
         rstd = torch.empty(G * C, device=x.device, dtype=torch.float32)
@@ -884,6 +893,75 @@ class LinearFn(torch.autograd.Function):
         _lib.call("acg_linear_bwd", _ptr(dy), _ptr(y), _ptr(x), _ptr(w), _ptr(dx), _ptr(dw), _ptr(db), N, I, ldx, O, Op, act,
                   _stream())
         return dx, dw, db, None, None
+
+
+COND_BANK = not _debug_switch("ACGAN_NO_COND_BANK")   # A/B switch
+
+
+class CondBankFn(torch.autograd.Function):
+    """The scale / shift layers of ALL CondInstanceNorms of a generator (modules.py:104-132: two ReLU(1x1 conv(z)) per norm,
+    19 norms in the 9-block generator) as ONE dense layer: y = ReLU(z @ Wcat.T + bcat), Wcat = the 2L weights stacked;
+    output k of the tuple is the (N, C) column block k of y (row stride 2L*C — NormAct reads scale / shift through that
+    stride).  38 forward and 76 backward launches plus the ~80 small additions with which autograd sums the 38 gradients
+    w.r.t. z and accumulates the second pass into .grad become 3 + 4.  params = w0, b0, w1, b1, ... (w_k: (C, I, 1, 1))."""
+
+    @staticmethod
+    def forward(ctx, z, C, *params):
+        z = z.contiguous()
+        ws, bs = params[0::2], params[1::2]
+        I = ws[0].numel() // C
+        O = C * len(ws)
+        N, ldx = z.shape
+        if any(w.numel() != C * I or b.numel() != C for w, b in zip(ws, bs)) or I > ldx or len(ws) > _lib.MAX_SEGMENTS // 2:
+            raise _lib.AcgError("cond bank: layers of different widths")
+        wcat = torch.cat([w.detach().reshape(C, I) for w in ws], 0)
+        bcat = torch.cat([b.detach() for b in bs], 0)
+        y = torch.empty((N, O), device=z.device, dtype=torch.float32)
+        _lib.call("acg_linear_fwd", _ptr(z), _ptr(wcat), _ptr(bcat), _ptr(y), N, I, ldx, O, O, ACT_RELU, _stream())
+        ctx.cfg = (N, I, ldx, O, C)
+        ctx.params = params
+        ctx.save_for_backward(z, wcat, y)
+        outs = tuple(y[:, k * C:(k + 1) * C] for k in range(len(ws)))
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        z, wcat, y = ctx.saved_tensors
+        N, I, ldx, O, C = ctx.cfg
+        params = ctx.params
+        zero = None
+        cols = []
+        for g in grads:
+            if g is None:
+                if zero is None:
+                    zero = torch.zeros((N, C), device=z.device, dtype=torch.float32)
+                g = zero
+            cols.append(g)
+        dy = torch.cat(cols, 1)
+        dz = torch.empty_like(z) if ctx.needs_input_grad[0] else None
+        if dz is not None and ldx > I:
+            dz.zero_()
+        need_p = any(ctx.needs_input_grad[2:])
+        dw = torch.empty((O, I), device=z.device, dtype=torch.float32) if need_p else None
+        db = torch.empty(O, device=z.device, dtype=torch.float32) if need_p else None
+        _lib.call("acg_linear_bwd", _ptr(dy), _ptr(y), _ptr(z), _ptr(wcat), _ptr(dz), _ptr(dw), _ptr(db), N, I, ldx, O, O, ACT_RELU,
+                  _stream())
+        pg = [None] * len(params)
+        if need_p:
+            direct = _direct_grad(*params)
+            if direct is not None:   # add the slices into the parameters' .grad, all in one launch per source buffer
+                for src, tens, width in ((dw, direct[0::2], C * I), (db, direct[1::2], C)):
+                    sg = _lib.Segments()
+                    for k, t in enumerate(tens):
+                        sg.dst[k], sg.off[k], sg.len[k] = t.data_ptr(), k * width, width
+                    sg.n = len(tens)
+                    _lib.call("acg_segments_accumulate", _ptr(src), ctypes.byref(sg), 1, _stream())
+                _grads_done(*params)
+            else:
+                for k in range(len(params) // 2):
+                    pg[2 * k] = dw[k * C:(k + 1) * C].view_as(params[2 * k])
+                    pg[2 * k + 1] = db[k * C:(k + 1) * C]
+        return (dz, None) + tuple(pg)
 
 
 LATENT_MLP = not _debug_switch("ACGAN_NO_LATENT_MLP")   # A/B switch

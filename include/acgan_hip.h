@@ -255,6 +255,16 @@ int acg_linear_fwd(const float *x, const float *w, const float *b, float *y, int
 /* g = dy*act'(y) is applied inside; dx may be NULL; dw[O][I], db[O] are overwritten */
 int acg_linear_bwd(const float *dy, const float *y, const float *x, const float *w, float *dx, float *dw, float *db,
                    int N, int I, int ldx, int O, int Op, int act, void *stream);
+/* dst[s][i] (+)= src[off[s] + i] for i < len[s], every segment in ONE launch: hands the slices of a concatenated gradient
+ * (the scale / shift layers of all CondInstanceNorms of a generator run as one dense layer, networks.py:98-132) to the
+ * layers' own gradient tensors.  accumulate != 0 adds (the parameter's .grad), 0 overwrites. */
+#define ACG_MAX_SEGMENTS 96
+typedef struct acg_segments {
+    void *dst[ACG_MAX_SEGMENTS];
+    int off[ACG_MAX_SEGMENTS], len[ACG_MAX_SEGMENTS];
+    int n;
+} acg_segments;
+int acg_segments_accumulate(const float *src, const acg_segments *segs, int accumulate, void *stream);
 
 /* ---- DiscriminatorLatent (networks.py:396-433) fused: Linear(I->H) BatchNorm1d LeakyReLU(0.2), two more H->H stages, then
  *      Linear(H->1), BatchNorm in train mode (batch statistics; running buffers updated when non-NULL).  One launch per

@@ -136,6 +136,33 @@ def test_norm_backward_sums_from_the_data_gradient_epilogue(kind):
         assert (pa[k] - pb[k]).abs().max().item() <= 2e-5 * pb[k].abs().max().item() + noise + 1e-12, k
 
 
+def test_cond_bank_matches_per_norm_layers():
+    """CINResnetGenerator: the scale / shift layers of all CondInstanceNorms as one dense layer (ops.CondBankFn,
+    modules.cond_bank; modules.py:104-132) against two small layers per norm.  The same dot products in the same order: the
+    image and every parameter gradient agree bit for bit, the gradient w.r.t. z up to the order of its sum over layers."""
+    from dtgan_amd import ops
+    torch.manual_seed(11)
+    xin = torch.randn(2, 3, 64, 64, device="cuda")
+    zin = torch.randn(2, 8, 1, 1, device="cuda")
+    res = {}
+    for bank in (True, False):
+        net = _gen("cin", 2, 7)
+        x, z = xin.clone().requires_grad_(True), zin.clone().requires_grad_(True)
+        old, ops.COND_BANK = ops.COND_BANK, bank
+        try:
+            y = net(x, z)
+            (y * torch.linspace(-1, 1, y.numel(), device="cuda").view_as(y)).sum().backward()
+        finally:
+            ops.COND_BANK = old
+        res[bank] = (y.detach(), x.grad.detach(), z.grad.detach(), {k: p.grad.detach().clone() for k, p in net.named_parameters()})
+    ya, xa, za, pa = res[True]
+    yb, xb, zb, pb = res[False]
+    assert torch.equal(ya, yb) and torch.equal(xa, xb)
+    assert (za - zb).abs().max().item() <= 1e-5 * zb.abs().max().item()
+    for k in pb:
+        assert torch.equal(pa[k], pb[k]), k
+
+
 def test_presplit_trunk_in_eval_and_no_grad():
     from dtgan_amd import ops
     from hip_util import precision, rel
