@@ -12,7 +12,7 @@ timeout -k 10 300 python bench.py --precision bf16 --steps 20 --warmup 5 --no-cp
 bash tools/profile_stats.sh bf16x3 $TAG > gpurun_out/${TAG}_stats.log 2>&1 || exit 1
 python3 tools/kernel_stats_md.py gpurun_out/${TAG}_kernel_stats.csv gpurun_out/${TAG}_kernel_stats.md 3 bf16x3
 bash tools/profile_traffic.sh > gpurun_out/${TAG}_traffic.log 2>&1 || exit 1
-python3 tools/summarize_traffic.py 'igemm_conv_x3_pre<true, true>' gpurun_out/${TAG}_resblock_conv_traffic.json
+python3 tools/summarize_traffic.py 'igemm_conv_x3_pre<true, true, false>' gpurun_out/${TAG}_resblock_conv_traffic.json
 tr=$(find gpurun_out/prof_$TAG -name "*kernel_trace.csv" | head -1)
 python3 tools/kernel_shapes_md.py $tr gpurun_out/${TAG}_kernel_shapes.md 3
 bash tools/profile_layer_traffic.sh a3_3x3s2,a6_convT,a2_3x3,a7_3x3,DB_4x4s2_64 $TAG > gpurun_out/${TAG}_layers.log 2>&1 || exit 1
