@@ -1117,7 +1117,7 @@ static void wgrad_plan(const acg_conv_desc *d, int Cx, int Cg, long long Mtot, i
                        long long *mps)
 {
     int bci, bco;
-    acg_wgrad_tiles(Cx, Cg, &bci, &bco);
+    acg_wgrad_tiles(Cx, Cg, &bci, &bco, wgrad_thin(d) ? 0 : d->K * d->K);
     *CiP = (Cx + bci - 1) / bci * bci;
     *CoP = (Cg + bco - 1) / bco * bco;
     if (wgrad_thin(d)) { // gathered columns = (tap, 4 channels): 32 per 8 taps, ONE tap-block
@@ -1126,11 +1126,12 @@ static void wgrad_plan(const acg_conv_desc *d, int Cx, int Cg, long long Mtot, i
         *CoP = (Cg + 31) / 32 * 32;
     }
     const int KP = 256; // multiple of every kernel variant's pixels-per-stage (fp32: 32/128, bf16: 64/256)
-    const long long base = (wgrad_thin(d) ? 1LL : (long long)d->K * d->K) * (*CiP / bci) * (*CoP / bco);
+    const int nt = acg_wgrad_taps_per_wg(Cx, Cg, d->K * d->K, wgrad_thin(d) ? 1 : 0);   // taps per workgroup (bf16 kernels)
+    const long long base = (wgrad_thin(d) ? 1LL : (long long)d->K * d->K / nt) * (*CiP / bci) * (*CoP / bco);
     // workgroups per launch: a whole number of residency waves.  The bf16 128x128 kernel holds 2 workgroups per CU:
     // 512 = exactly one wave (vs 1536: -6..-10 %, and a third of the partial-sum traffic); 768 = 1.5 waves is the worst
     // choice (+15 %).  The smaller tiles hold 3-4 per CU and keep more, shorter workgroups.
-    long long target = (g_acg_precision != ACG_PREC_F32 && g_acg_conv_impl == ACG_IMPL_MFMA && bci == 128 && bco == 128 && !wgrad_thin(d)) ? 512 : 1024;
+    long long target = (g_acg_precision != ACG_PREC_F32 && g_acg_conv_impl == ACG_IMPL_MFMA && ((bci == 128 && bco == 128) || nt == 3) && !wgrad_thin(d)) ? 512 : 1024;
     long long nblk = base;
     int gran = KP;
     // kernel-row weight gradient (conv_wgrad_tr.hip, same conditions as acg_wgrad_krow_ok): three taps per workgroup, one

@@ -489,7 +489,10 @@ int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, fl
 // LDS images: Xs[ci][KP + 8], Ds[co][KP + 8] (bf16; +16 B row pad -> conflict-free ds_read_b128).
 // ------------------------------------------------------------------------------------------------
 // SPLIT: both operands as bf16 hi + lo (lo images behind the hi images), x_lo*d_hi + x_hi*d_lo + x_hi*d_hi.
-template <int BCI, int BCO, int WI, int WJ, int WK, int KP, bool SPLIT>
+// NT: consecutive taps per workgroup.  They share the gradient-side tile (one load, split and LDS image for NT taps) and each
+// brings its own gathered tile: per tap and stage a workgroup pulls (BCI + BCO / NT) instead of (BCI + BCO) channel rows
+// through L2 — these kernels move 4-5 GB per launch through L2 for 0.8 GB of operands, and that, not HBM, is their limit.
+template <int BCI, int BCO, int WI, int WJ, int WK, int KP, bool SPLIT, int NT = 1>
 __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, const float *__restrict__ dy,
                                                   float *__restrict__ part, WGeom g, Taps taps, unsigned x_bytes,
                                                   unsigned d_bytes)
@@ -503,13 +506,15 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
     constexpr int RS = SWZ ? KP : KP + 8;               // LDS row stride (elements)
 #define ACG_WG_AT(row, pgq) ((row) * RS + (((pgq) ^ (SWZ ? ((((row) >> 2) & 3) | (((((row) >> 1) ^ ((row) >> 4)) & 1) << 2)) : 0)) * 8))
     constexpr int XU = (KP / 8) * (BCI / 4), DU = (KP / 8) * (BCO / 4); // 8-pixel x 4-channel units
-    constexpr int XL = (XU + 255) / 256, DL = (DU + 255) / 256;
+    constexpr int XL = (NT * XU + 255) / 256, DL = (DU + 255) / 256;   // x units: tap-major, unit U = tid + 256 l -> tap U / XU
     constexpr int KW = KP / WK;                         // pixels of a stage per wave
-    constexpr int DOFF = (XU + DU <= 256) ? XU : 0;     // threads [XU, XU+DU) load the dy units when both fit
+    constexpr int DOFF = (NT * XU + DU <= 256) ? NT * XU : 0; // threads [XU, XU+DU) load the dy units when both fit
     static_assert(WI * WJ * WK == 4 && MI >= 1 && MJ >= 1 && KW % 16 == 0, "tile config");
+    static_assert(NT == 1 || (WK == 1 && XU <= 256), "several taps per workgroup: no split-K inside the block");
 
     constexpr int NIMG = SPLIT ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) __bf16 Xs[NIMG * BCI * RS];
+    constexpr int XIMG = NIMG * BCI * RS;               // one tap's gathered image(s)
+    __shared__ __attribute__((aligned(16))) __bf16 Xs[NT * XIMG];
     __shared__ __attribute__((aligned(16))) __bf16 Ds[NIMG * BCO * RS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -522,22 +527,23 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
     int b = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const int tco = b % tiles_co; b /= tiles_co;
     const int tci = b % tiles_ci; b /= tiles_ci;
-    const int tap = b % taps.n;
-    const int split = b / taps.n;
+    const int tap = (b % (taps.n / NT)) * NT;   // first of this workgroup's NT taps
+    const int split = b / (taps.n / NT);
     const int ci0 = tci * BCI, co0 = tco * BCO;
-    const int ty = taps.dy[tap], tx = taps.dx[tap];
     const long long mbeg = (long long)split * g.m_per_split;
     long long mend = mbeg + g.m_per_split;
     if (mend > g.Mtot) mend = g.Mtot;
     const int GHW = g.Hg * g.Wg;
 
-    f32x16 acc[MI][MJ];
+    f32x16 acc[NT][MI][MJ];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int j = 0; j < MJ; ++j)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < MJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
 
     f32x4 rx[XL][8], rd[DL][8];
     const bool do_bias = g.bias_from != 0 && tap == 0 && (g.bias_from == 1 ? tci == 0 : tco == 0);
@@ -549,7 +555,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
     int un[XL], uy[XL], ux[XL];
 #pragma unroll
     for (int l = 0; l < XL; ++l) {
-        const int unit = tid + 256 * l;
+        const int unit = (tid + 256 * l) % XU;
         const long long m = mbeg + (unit / (BCI / 4)) * 8;
         const long long mm = m < g.Mtot ? m : 0;
         un[l] = (int)(mm / GHW);
@@ -561,12 +567,13 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
     auto load_stage = [&](long long k0) {
 #pragma unroll
         for (int l = 0; l < XL; ++l) {
-            const int unit = tid + 256 * l;
+            const int U = tid + 256 * l, tt = NT == 1 ? 0 : U / XU, unit = NT == 1 ? U : U - tt * XU;
+            const int ty = taps.dy[tap + (tt < NT ? tt : 0)], tx = taps.dx[tap + (tt < NT ? tt : 0)];
             const int c4 = unit % (BCI / 4), pg = unit / (BCI / 4);
             const int ci = ci0 + c4 * 4;
             const long long m = k0 + pg * 8;
             int n = un[l], gy = uy[l], gx = ux[l];
-            const bool uok = unit < XU && ci < g.Cin;
+            const bool uok = U < NT * XU && ci < g.Cin;
             // the 8 pixels of a unit are consecutive output positions: when no lane's unit crosses a row end (always
             // so for W % 8 == 0), the row part of the address is formed once and each pixel costs a few VALU ops
             const bool in_row = gx + 8 <= g.Wg && m + 8 <= mend;
@@ -659,9 +666,10 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
     auto store_stage = [&]() {
 #pragma unroll
         for (int l = 0; l < XL; ++l) {
-            const int unit = tid + 256 * l;
-            if (unit < XU) {
+            const int U = tid + 256 * l, tt = NT == 1 ? 0 : U / XU, unit = NT == 1 ? U : U - tt * XU;
+            if (U < NT * XU) {
                 const int c4 = unit % (BCI / 4), pg = unit / (BCI / 4);
+                __bf16 *Xt = Xs + tt * XIMG;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float v[8];
@@ -670,10 +678,10 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
                     if (SPLIT) {
                         acg_u32x4 hi, lo;
                         acg_split8(v, hi, lo);
-                        *(acg_u32x4 *)&Xs[ACG_WG_AT(c4 * 4 + c, pg)] = hi;
-                        *(acg_u32x4 *)&Xs[BCI * RS + ACG_WG_AT(c4 * 4 + c, pg)] = lo;
+                        *(acg_u32x4 *)&Xt[ACG_WG_AT(c4 * 4 + c, pg)] = hi;
+                        *(acg_u32x4 *)&Xt[BCI * RS + ACG_WG_AT(c4 * 4 + c, pg)] = lo;
                     } else {
-                        *(acg_u32x4 *)&Xs[ACG_WG_AT(c4 * 4 + c, pg)] = acg_round8(v);
+                        *(acg_u32x4 *)&Xt[ACG_WG_AT(c4 * 4 + c, pg)] = acg_round8(v);
                     }
                 }
             }
@@ -711,24 +719,16 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
                 for (int l = 0; l < DL; ++l)
 #pragma unroll
                     for (int p = 0; p < 8; ++p) bsum += rd[l][p];
-            } else {
+            } else { // the first tap's units are the first XU threads of pass 0
 #pragma unroll
-                for (int l = 0; l < XL; ++l)
-#pragma unroll
-                    for (int p = 0; p < 8; ++p) bsum += rx[l][p];
+                for (int p = 0; p < 8; ++p) bsum += rx[0][p];
             }
         }
         __syncthreads();
         if (k0 + KP < mend) load_stage(k0 + KP);
 #pragma unroll
         for (int kk = wk * KW; kk < (wk + 1) * KW; kk += 16) {
-            bf16x8 a[MI], bb[MJ], al[MI], bl[MJ];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int at = ACG_WG_AT(wi * TI + i * 32 + (lane & 31), (kk >> 3) + (lane >> 5));
-                a[i] = *(const bf16x8 *)&Xs[at];
-                if (SPLIT) al[i] = *(const bf16x8 *)&Xs[BCI * RS + at];
-            }
+            bf16x8 bb[MJ], bl[MJ];
 #pragma unroll
             for (int j = 0; j < MJ; ++j) {
                 const int bt = ACG_WG_AT(wj * TJ + j * 32 + (lane & 31), (kk >> 3) + (lane >> 5));
@@ -736,15 +736,25 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
                 if (SPLIT) bl[j] = *(const bf16x8 *)&Ds[BCO * RS + bt];
             }
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int t = 0; t < NT; ++t) {
+                bf16x8 a[MI], al[MI];
 #pragma unroll
-                for (int j = 0; j < MJ; ++j) {
-                    if (SPLIT) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bb[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
-                    }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bb[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < MI; ++i) {
+                    const int at = t * XIMG + ACG_WG_AT(wi * TI + i * 32 + (lane & 31), (kk >> 3) + (lane >> 5));
+                    a[i] = *(const bf16x8 *)&Xs[at];
+                    if (SPLIT) al[i] = *(const bf16x8 *)&Xs[BCI * RS + at];
                 }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < MJ; ++j) {
+                        if (SPLIT) {
+                            acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bb[j], acc[t][i][j], 0, 0, 0);
+                            acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bl[j], acc[t][i][j], 0, 0, 0);
+                        }
+                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bb[j], acc[t][i][j], 0, 0, 0);
+                    }
+            }
         }
     }
 
@@ -755,7 +765,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
         const int q4 = (fromD ? BCO : BCI) / 4, nun = fromD ? DU : XU, off = fromD ? DOFF : 0;
         // unit index of this thread for the chosen operand (first pass only: XL == DL == 1 whenever units <= 256)
         const int unit = fromD ? (DOFF ? (tid >= DOFF ? tid - DOFF : nun) : tid) : tid;
-        static_assert(XL == 1 && DL == 1, "bias fusion assumes one unit per thread per operand");
+        static_assert((XL == 1 || NT > 1) && DL == 1, "bias fusion assumes one unit per thread per operand (per tap)");
         (void)off;
         if (unit < nun) *(f32x4 *)&red[unit * 4] = bsum;
         __syncthreads();
@@ -778,35 +788,39 @@ __global__ __launch_bounds__(256) void wgrad_bf16(const float *__restrict__ x, c
         const int grp = wi * WJ + wj;
         if (wk > 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[((grp * (WK - 1) + wk - 1) * 16 + r) * 64 + lane] = acc[0][0][r];
+            for (int r = 0; r < 16; ++r) red[((grp * (WK - 1) + wk - 1) * 16 + r) * 64 + lane] = acc[0][0][0][r];
         }
         __syncthreads();
         if (wk == 0) {
 #pragma unroll
             for (int w = 0; w < WK - 1; ++w)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[0][0][r] += red[((grp * (WK - 1) + w) * 16 + r) * 64 + lane];
+                for (int r = 0; r < 16; ++r) acc[0][0][0][r] += red[((grp * (WK - 1) + w) * 16 + r) * 64 + lane];
         }
         if (wk != 0) return;
     }
 
-    float *o = part + ((long long)split * taps.n + tap) * g.CiP * g.CoP;
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int t = 0; t < NT; ++t) {
+        float *o = part + ((long long)split * taps.n + tap + t) * g.CiP * g.CoP;
 #pragma unroll
-        for (int j = 0; j < MJ; ++j)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ci = ci0 + wi * TI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int co = co0 + wj * TJ + j * 32 + (lane & 31);
-                o[(long long)ci * g.CoP + co] = acc[i][j][r];
-            }
+            for (int j = 0; j < MJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ci = ci0 + wi * TI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int co = co0 + wj * TJ + j * 32 + (lane & 31);
+                    o[(long long)ci * g.CoP + co] = acc[t][i][j][r];
+                }
+    }
 }
 
 int acg_wgrad_bf16_launch(const float *x, const float *dy, float *part, const WGeom &g, const Taps &t, int bci, int bco,
                           hipStream_t st)
 {
-    const int blocks = g.nsplit * t.n * (g.CiP / bci) * (g.CoP / bco);
+    const int nt = acg_wgrad_taps_per_wg(g.Cin, g.Cg, t.n, g.thin);
+    const int blocks = g.nsplit * (t.n / nt) * (g.CiP / bci) * (g.CoP / bco);
     dim3 grid(blocks), block(256);
     const long long nimg = g.Mtot / ((long long)g.Hg * g.Wg);
     const long long xbytes = nimg * g.Hin * g.Win * g.Cin * 4, dbytes = g.Mtot * g.Cg * 4;
@@ -818,13 +832,17 @@ int acg_wgrad_bf16_launch(const float *x, const float *dy, float *part, const WG
         else hipLaunchKernelGGL((wgrad_bf16<BCI_, BCO_, WI_, WJ_, WK_, KP_, false>), grid, block, 0, st, x, dy, part, g, t, xb, db);      \
     } while (0)
     const bool split = g_acg_precision == ACG_PREC_BF16X3;
-    if (bci == 128) WG_BF16(128, 128, 2, 2, 1, 64);
+    if (nt == 3) { // 64 x 128 tile, the three taps of a kernel row per workgroup (acg_wgrad_tiles gave bco = 128 for it)
+        ACG_REQUIRE(bci == 64 && bco == 128, "wgrad_bf16: tile of the three-tap variant");
+        if (split) hipLaunchKernelGGL((wgrad_bf16<64, 128, 2, 2, 1, 64, true, 3>), grid, block, 0, st, x, dy, part, g, t, xb, db);
+        else hipLaunchKernelGGL((wgrad_bf16<64, 128, 2, 2, 1, 64, false, 3>), grid, block, 0, st, x, dy, part, g, t, xb, db);
+    } else if (bci == 128) WG_BF16(128, 128, 2, 2, 1, 64);
     else if (bci == 64 && bco == 64) WG_BF16(64, 64, 2, 2, 1, 64);
     else if (bci == 32 && bco == 64) WG_BF16(32, 64, 1, 2, 2, 128);
     else if (bci == 64 && bco == 32) WG_BF16(64, 32, 2, 1, 2, 128);
     else WG_BF16(32, 32, 1, 1, 4, 256);
 #undef WG_BF16
     ACG_CHECK_LAUNCH("wgrad_bf16");
-    acg_note_kernel("wgrad_bf16<%d,%d,SPLIT=%d>", bci, bco, split ? 1 : 0);
+    acg_note_kernel("wgrad_bf16<%d,%d,SPLIT=%d,NT=%d>", bci, bco, split ? 1 : 0, nt);
     return ACG_OK;
 }

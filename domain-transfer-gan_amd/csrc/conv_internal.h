@@ -105,7 +105,8 @@ struct WGeom {
     float *bias_part;     // [nsplit][CoP or CiP] partial column sums (written by the tap-0 / tile-0 blocks)
 };
 int acg_wgrad_launch(const float *x, const float *dy, float *part, const WGeom &g, const Taps &t, hipStream_t st);
-void acg_wgrad_tiles(int Ci, int Co, int *bci, int *bco);
+void acg_wgrad_tiles(int Ci, int Co, int *bci, int *bco, int ntaps);
+int acg_wgrad_taps_per_wg(int Ci, int Co, int ntaps, int thin);
 
 extern int g_acg_precision;
 extern int g_acg_conv_impl;

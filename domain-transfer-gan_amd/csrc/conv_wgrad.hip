@@ -255,8 +255,18 @@ __global__ __launch_bounds__(256) void wgrad_f32(const float *__restrict__ x, co
             }
 }
 
-void acg_wgrad_tiles(int Ci, int Co, int *bci, int *bco)
+// taps per workgroup of the bf16 weight-gradient kernel (they share the gradient-side tile): the 64 -> 128-multiple channel
+// 3x3 layers (stride-2 downsample / ConvTranspose, networks.py:168, 178) take a 64 x 128 tile and a whole kernel row
+int acg_wgrad_taps_per_wg(int Ci, int Co, int ntaps, int thin)
 {
+    static const bool off = acg_debug_switch("ACG_NO_WGRAD_NT"); // A/B switch
+    return (!off && !thin && g_acg_precision != ACG_PREC_F32 && g_acg_conv_impl == ACG_IMPL_MFMA && ntaps == 9 && Ci == 64 &&
+            Co >= 128 && Co % 128 == 0) ? 3 : 1;
+}
+
+void acg_wgrad_tiles(int Ci, int Co, int *bci, int *bco, int ntaps)
+{
+    if (acg_wgrad_taps_per_wg(Ci, Co, ntaps, 0) == 3) { *bci = 64; *bco = 128; return; }
     // 128x128 for the dense 128/256-channel layers, 64x64 mid; thin layers 32x32; 32<->64-channel layers get a
     // rectangular 32x64 / 64x32 tile (two 32x32 wave tiles, two waves splitting K each)
     const int mn = Ci < Co ? Ci : Co, mx = Ci < Co ? Co : Ci;
@@ -269,7 +279,7 @@ void acg_wgrad_tiles(int Ci, int Co, int *bci, int *bco)
 int acg_wgrad_launch(const float *x, const float *dy, float *part, const WGeom &g, const Taps &t, hipStream_t st)
 {
     int bci, bco;
-    acg_wgrad_tiles(g.Cin, g.Cg, &bci, &bco);
+    acg_wgrad_tiles(g.Cin, g.Cg, &bci, &bco, g.thin ? 0 : t.n);
     if (acg_wgrad_krow_ok(g, t)) return acg_wgrad_krow_launch(x, dy, part, g, st);
     if (acg_wgrad_krow_s_ok(g, t)) return acg_wgrad_krow_s_launch(x, dy, part, g, st);
     if (g_acg_precision != ACG_PREC_F32 && !g.thin) return acg_wgrad_bf16_launch(x, dy, part, g, t, bci, bco, st);
