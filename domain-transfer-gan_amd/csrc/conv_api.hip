@@ -885,15 +885,22 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
         for (int i = 0; i < 64; ++i) { t.dy[i] = 0; t.dx[i] = 0; t.w[i] = 0; }
         g.nphase = 4;
         g.ph_ntaps = 0;
+        int ntp[4];
         for (int ph = 0; ph < 4; ++ph) {
             const int nt = phase_taps(ph >> 1, ph & 1, t, 16 * ph);
             ACG_REQUIRE(nt > 0, "dgrad: empty phase (K=%d p=%d)", K, p);
             g.ph_ntaps |= nt << (8 * ph);
+            ntp[ph] = nt;
         }
         if (stats != nullptr) {
             const int per = (int)(((long long)g.GH * g.GW) / 128);
             g.stats = stats; g.stats_cpi = 4 * per; g.stats_chunk0 = 0;
         }
+        // 64 output channels in the bf16x3 arithmetic: all four phases in one tile, the input rows fetched once (conv_ph4.hip)
+        Geom g4 = g;
+        g4.nphase = 0; g4.ph_ntaps = 0;
+        Taps plan;
+        if (acg_igemm_ph4_ok(g4) && acg_ph4_plan(t, ntp, &plan)) return acg_igemm_ph4_launch(src, wb, bias, dst, g4, plan, g.w_elems, st);
         return acg_igemm_launch(src, wb, bias, dst, g, t, st);
     }
     for (int py = 0; py < 2; ++py)

@@ -120,6 +120,11 @@ int acg_igemm_x3_pre_launch(const void *in, const void *wp, const float *bias, f
 bool acg_conv_patch16_ok(const Geom &g, const Taps &t);
 int acg_conv_patch16_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g, const Taps &t,
                             long long n_w_elems, hipStream_t st);
+// conv_ph4.hip: stride-2 data gradient / ConvTranspose2d forward with the four sub-pixel phases in one tile (64 columns)
+bool acg_igemm_ph4_ok(const Geom &g);
+bool acg_ph4_plan(const Taps &t, const int nt[4], Taps *out);
+int acg_igemm_ph4_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g, const Taps &plan,
+                         long long n_w_elems, hipStream_t st);
 int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g, const Taps &t,
                           int bn, long long n_w_elems, hipStream_t st);
 int acg_wgrad_bf16_launch(const float *x, const float *dy, float *part, const WGeom &g, const Taps &t, int bci, int bco,

@@ -619,9 +619,40 @@ def test_c_abi_error_convention():
     torch.cuda.synchronize()
 
 
+def test_stride2_phases_in_one_tile_match_the_fp32_kernels():
+    """networks.py:168, 178-179: the stride-2 64 -> 128 convolution's data gradient and the 128 -> 64 ConvTranspose2d forward
+    on maps whose phase-grid rows are whole tiles run all four sub-pixel phases in one tile (conv_ph4.hip, bf16x3); the strict
+    fp32 kernels (four launches of the generic tile) are the reference: border rows / columns, bias and activation included."""
+    import ctypes
+    from hip_util import t, n, rel, precision
+    from dtgan_amd import ops, _lib
+    P = ops._ptr
+    rs = np.random.RandomState(5)
+    NB, H, W, Cs, Cl = 2, 6, 128, 128, 64         # small side H x W x 128, large side 2H x 2W x 64
+    xs = t(rs.normal(0.1, 1, (NB, H, W, Cs)))     # small-side tensor (ConvTranspose input / gradient of the conv output)
+    w = t(rs.normal(0, 0.1, (Cs, Cl, 3, 3))); b = t(rs.normal(0, 1, Cl))
+    out = {}
+    for prec in ("f32", "bf16x3"):
+        with precision(prec):
+            st = ops._stream()
+            d = ops.conv_desc(NB, 2 * H, 2 * W, Cl, Cs, 3, 2, 1, 0, Cl, Cs)   # the Conv2d 64 -> 128, stride 2
+            pk = ops.PackedConv(w, b, Cl, Cs)
+            y = torch.empty((NB, 2 * H, 2 * W, Cl), device="cuda")
+            _lib.call("acg_conv_transpose2d_fwd", ctypes.byref(d), P(xs), P(pk.wb), P(pk.bias), P(y), 1, st)   # + ReLU
+            kern_fwd = _lib.query("acg_last_kernel").decode()
+            dx = torch.empty((NB, 2 * H, 2 * W, Cl), device="cuda")
+            nb = _lib.query("acg_conv2d_bwd_data_workspace_bytes", ctypes.byref(d))
+            ws = ops.workspace(max(nb, 1))
+            _lib.call("acg_conv2d_bwd_data", ctypes.byref(d), P(xs), P(pk.wb), P(dx), P(ws), nb, st)
+            out[prec] = (n(y), n(dx), kern_fwd, _lib.query("acg_last_kernel").decode())
+    assert "ph4" in out["bf16x3"][2] and "ph4" in out["bf16x3"][3], out["bf16x3"][2:]
+    assert rel(out["bf16x3"][0], out["f32"][0]) < 2e-5 and rel(out["bf16x3"][1], out["f32"][1]) < 2e-5
+
+
 @pytest.mark.parametrize("case", [("conv", 32, 64, 3, 1, 32, 32), ("conv", 64, 32, 3, 1, 16, 64), ("conv", 16, 32, 3, 2, 32, 32),
                                   ("conv", 32, 32, 3, 1, 32, 32), ("conv", 16, 32, 3, 2, 64, 64), ("conv", 32, 32, 3, 1, 8, 16),
-                                  ("conv", 64, 128, 3, 2, 32, 32), ("convT", 128, 64, 3, 2, 32, 32), ("convT", 64, 32, 3, 2, 16, 32)])
+                                  ("conv", 64, 128, 3, 2, 32, 32), ("convT", 128, 64, 3, 2, 32, 32), ("convT", 64, 32, 3, 2, 16, 32),
+                                  ("convT", 128, 64, 3, 2, 8, 128)])   # the last: four phases in one tile (conv_ph4.hip)
 def test_conv_epilogue_statistics_equal_the_statistics_pass(case):
     """Per-tile (mean, M2) from the convolution epilogues (generic bf16 tile, wave-specialised tile, the four phase launches
     of ConvTranspose2d) merged by acg_norm_stats_from_partials against acg_norm_stats on the stored output: the mean / rstd
