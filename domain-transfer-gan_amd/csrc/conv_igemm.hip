@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void igemm_conv_f32(const float *__restrict__ 
 
     __shared__ __attribute__((aligned(16))) float As[ASZ];
     __shared__ __attribute__((aligned(16))) float Bs[BSZ];
-    __shared__ long long out_off[BM];
+    __shared__ __attribute__((aligned(16))) unsigned out_rel[BM];  // byte offset of a tile row's output pixel from the tile's first, ~0u: none
     __shared__ int tap_dy[64], tap_dx[64];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -87,17 +87,14 @@ __global__ __launch_bounds__(256) void igemm_conv_f32(const float *__restrict__ 
         a_bx[j] = gx * g.is;
         a_row[j] = REFLECT ? n * g.Hin : (n * g.Hin + a_by[j]) * g.Win + a_bx[j];
     }
-    if (tid < BM) {
-        const long long m = m0 + tid;
-        long long off = -1;
-        if (m < g.Mtot) {
-            const int n = (int)(m / GHW);
-            const int r = (int)(m - (long long)n * GHW);
-            const int gy = r / g.GW, gx = r - gy * g.GW;
-            off = (((long long)n * g.Hout + (gy * g.os + g.oy0)) * g.Wout + (gx * g.os + g.ox0)) * g.Cout;
-        }
-        out_off[tid] = off;
-    }
+    auto pix_off = [&](long long m) { // element offset of grid position m's output pixel
+        const int n = (int)(m / GHW);
+        const int r = (int)(m - (long long)n * GHW);
+        const int gy = r / g.GW, gx = r - gy * g.GW;
+        return (((long long)n * g.Hout + (gy * g.os + g.oy0)) * g.Wout + (gx * g.os + g.ox0)) * g.Cout;
+    };
+    const long long off0 = pix_off(m0);   // uniform; the rows of a tile lie less than 4 GiB behind it
+    if (tid < BM) out_rel[tid] = m0 + tid < g.Mtot ? (unsigned)((pix_off(m0 + tid) - off0) * 4) : ~0u;
     // per-thread B chunk offsets (bytes) inside one stage's weight block; the stage part is a scalar offset
     unsigned b_voff[BL];
     int b_lds[BL];
@@ -230,22 +227,54 @@ __global__ __launch_bounds__(256) void igemm_conv_f32(const float *__restrict__ 
         }
     }
 
-    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Branch-free, as in
+    // conv_bf16.hip: bias and activation in a pass over the accumulators, then buffer stores relative to the tile's first
+    // pixel whose masked lanes carry an out-of-range offset (a predicated 64-bit store with a run-time activation switch per
+    // element was ~45 instructions and a branch each: as many instructions as the whole main loop).
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int co = n0 + wn * TN + j * 32 + (lane & 31);
-        const bool cok = co < g.Cout;
-        const float bv = (bias != nullptr && cok) ? bias[co] : 0.f;
+        const float bv = (bias != nullptr && co < g.Cout) ? bias[co] : 0.f;
+        if (g.act == ACG_ACT_NONE) {
 #pragma unroll
-        for (int i = 0; i < MB; ++i) {
+            for (int i = 0; i < MB; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const long long off = out_off[row];
-                if (cok && off >= 0) out[off + co] = acg_apply_act(acc[i][j][r] + bv, g.act);
-            }
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += bv;
+        } else if (g.act == ACG_ACT_RELU) {
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] + bv > 0.f ? acc[i][j][r] + bv : 0.f;
+        } else if (g.act == ACG_ACT_LRELU) {
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] + bv > 0.f ? acc[i][j][r] + bv : 0.2f * (acc[i][j][r] + bv);
+        } else {
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = acg_apply_act(acc[i][j][r] + bv, g.act);
         }
     }
+    typedef unsigned epi_u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)(out + off0), 0, 0xFFFFFFF0u, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            // accumulator registers 4 r4 .. 4 r4 + 3 are tile rows 8 r4 + 4 (lane >> 5) + 0 .. 3
+            const epi_u32x4 rel = *(const epi_u32x4 *)&out_rel[wm * TM + i * 32 + 8 * r4 + 4 * (lane >> 5)];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int co = n0 + wn * TN + j * 32 + (lane & 31);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v = acc[i][j][4 * r4 + q]; // (a bit cast of the vector-element lvalue itself reads element 0)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rout, acg_masked_off(rel[q] + (unsigned)co * 4u, rel[q] != ~0u && co < g.Cout), 0, 0);
+                }
+            }
+        }
 }
 
 static int bn_for(int c) { return c >= 128 ? 128 : (c >= 64 ? 64 : 32); }
