@@ -249,19 +249,19 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
         }
 #endif
 #undef PSTAMP
-        return;
-    }
+    }   // (no return: the producer waves take half of the epilogue's rows)
 
     // ---------------------------------------------------------------------- consumers
-    __builtin_amdgcn_s_setprio(2);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = (wave & 3) >> 1, wn = wave & 1;
     constexpr int TM = 64, TN = 64;
     f32x4 acc[4][4];
+    const int pl = lane >> 4, lr = lane & 15;
+    if (wave < 4) {
+    __builtin_amdgcn_s_setprio(2);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int pl = lane >> 4, lr = lane & 15;
     int a_base[4]; // byte offset of this lane's hi chunk in row-tile i at tap column 0 (lo: + 16)
     {
         const int x0c = m0 % g.GW, firstc = g.GW - x0c < BM ? g.GW - x0c : BM, RWc = g.GW + kdim - 1;
@@ -348,12 +348,17 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
         g_pre_stamps[(blockIdx.x * 8 + wave) * 3 + 2] = 0;
     }
 #endif
+    }   // consumers
     // Epilogue through LDS: the tile (accumulator + bias, activation) is staged in the LDS the main loop no longer needs
-    // and leaves in coalesced rows.
+    // and leaves in coalesced rows.  ALL EIGHT waves share its rows: a workgroup's tile time is loop + epilogue (the other
+    // workgroup of the CU only fills the matrix pipe meanwhile), and the epilogue is a chain of load round trips — with 512
+    // threads a thread has half the rows, i.e. half the round trips.
     constexpr int TS = BN; // row stride (floats)
+    constexpr int ET = 512; // threads of the output loops
     static_assert(BM * TS * 4 <= LDS_BYTES, "the staged tile must fit the LDS buffers");
     float *tile = (float *)lds;
-    __syncthreads(); // every consumer wave is done with the last LDS buffer (the producers have exited)
+    __syncthreads(); // every consumer wave is done with the last LDS buffer, every DMA piece has landed
+    if (wave < 4) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int cl = wn * TN + j * 16 + lr;
@@ -364,34 +369,41 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
             for (int r = 0; r < 4; ++r)
                 tile[(wm * TM + i * 16 + 4 * pl + r) * TS + cl] = acg_apply_act(acc[i][j][r] + bv, STATS ? (int)ACG_ACT_NONE : g.act);
     }
+    }
     __syncthreads();
     if (g.colfix != nullptr) { // un-padded reflect data gradient: the mirrored pad columns land on pixels 1 and W-2
         const int grow = m0 / g.GW, x0c = m0 - grow * g.GW;
         const int sd = tid >> 7, c = tid & (BN - 1), row = sd == 0 ? 1 - x0c : g.GW - 2 - x0c;
-        if ((unsigned)row < (unsigned)BM && n0 + c < g.Cout)
+        if (tid < 256 && (unsigned)row < (unsigned)BM && n0 + c < g.Cout)
             tile[row * TS + c] += g.colfix[((size_t)grow * 2 + sd) * g.Cout + n0 + c];
         __syncthreads();
     }
     if constexpr (STATS) {
         // per-tile (mean, M2) of the 128 output pixels of every channel for the InstanceNorm that follows (conv_x3.hip)
+        // (the first four waves, in the summation order of conv_x3.hip: results stay bit-identical; everybody keeps the barriers)
         float *redf = &red[0][0][0]; // 256 floats
-        const int c = tid & (BN - 1), h = tid >> 7; // tid < 256 here: column c, rows h*64 .. h*64+63
+        const int c = tid & (BN - 1), h = (tid >> 7) & 1; // column c, rows h*64 .. h*64+63
+        const bool sw = tid < 256;
         float sum = 0.f;
+        if (sw) {
 #pragma unroll 8
-        for (int r = 0; r < BM / 2; ++r) sum += tile[(h * (BM / 2) + r) * TS + c];
-        redf[h * BN + c] = sum;
+            for (int r = 0; r < BM / 2; ++r) sum += tile[(h * (BM / 2) + r) * TS + c];
+            redf[h * BN + c] = sum;
+        }
         __syncthreads();
         const float mu = (redf[c] + redf[BN + c]) * (1.f / BM);
         float sq = 0.f;
+        if (sw) {
 #pragma unroll 8
-        for (int r = 0; r < BM / 2; ++r) {
-            const float dlt = tile[(h * (BM / 2) + r) * TS + c] - mu;
-            sq += dlt * dlt;
+            for (int r = 0; r < BM / 2; ++r) {
+                const float dlt = tile[(h * (BM / 2) + r) * TS + c] - mu;
+                sq += dlt * dlt;
+            }
         }
         __syncthreads();
-        redf[h * BN + c] = sq;
+        if (sw) redf[h * BN + c] = sq;
         __syncthreads();
-        if (h == 0 && n0 + c < g.Cout) {
+        if (sw && h == 0 && n0 + c < g.Cout) {
             float *o = stats + ((m0 / BM) * 2) * g.Cout + n0 + c; // chunk = image * (GH*GW/128) + tile within the image
             o[0] = mu;
             o[g.Cout] = redf[c] + redf[BN + c];
@@ -402,19 +414,28 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
         // pre-split output: a thread converts 8 channels of one pixel (hi at +0, lo at +16 of the group's 32 bytes); the
         // optional ReLU source is pre-split too and only its sign is needed: the sign of the hi halves
         const char *rsrc = (const char *)g.relu_src;
-#pragma unroll 2
-        for (int k = 0; k < BM * (BN / 8) / 256; ++k) {
-            const int idx = tid + 256 * k, row = idx / (BN / 8), c8 = idx - row * (BN / 8);
+        constexpr int NK = BM * (BN / 8) / ET;   // 4 (pixel, 8-channel group) items per thread
+        u32x4 sv[NK];
+        // the sign words of all items first: one round trip (loaded inside the loop they were NK dependent ones)
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int idx = tid + ET * k, row = idx / (BN / 8), c8 = idx - row * (BN / 8);
+            const unsigned po = pix_off[row];
+            const bool need = rsrc != nullptr && po != NO_PIX && (po >> 31) && n0 + c8 * 8 < g.Cout;
+            sv[k] = *(const u32x4 *)(need ? rsrc + (size_t)(po & 0x7fffffffu) * 16 + (size_t)(n0 + c8 * 8) * 4 : in);
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int idx = tid + ET * k, row = idx / (BN / 8), c8 = idx - row * (BN / 8);
             const unsigned po = pix_off[row];
             if (po == NO_PIX || n0 + c8 * 8 >= g.Cout) continue;
             const size_t boff = (size_t)(po & 0x7fffffffu) * 16 + (size_t)(n0 + c8 * 8) * 4;
             const f32x4 t0 = *(const f32x4 *)&tile[row * TS + c8 * 8], t1 = *(const f32x4 *)&tile[row * TS + c8 * 8 + 4];
             float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
             if (rsrc != nullptr && (po >> 31)) {
-                const u32x4 sv = *(const u32x4 *)(rsrc + boff);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const unsigned a = sv[q] & 0xffffu, b = sv[q] >> 16;
+                    const unsigned a = sv[k][q] & 0xffffu, b = sv[k][q] >> 16;
                     v[2 * q] = (a - 1u) < 0x7fffu ? v[2 * q] : 0.f;         // positive, non-zero bf16
                     v[2 * q + 1] = (b - 1u) < 0x7fffu ? v[2 * q + 1] : 0.f;
                 }
@@ -434,8 +455,8 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
     }
     if (g.addend == nullptr && g.relu_src == nullptr && !SUMS) {
 #pragma unroll 4
-        for (int k = 0; k < BM * (BN / 4) / 256; ++k) { // 16 float4 per thread, consecutive lanes on consecutive channels
-            const int idx = tid + 256 * k, row = idx / (BN / 4), c4 = idx - row * (BN / 4);
+        for (int k = 0; k < BM * (BN / 4) / ET; ++k) { // 8 float4 per thread, consecutive lanes on consecutive channels
+            const int idx = tid + ET * k, row = idx / (BN / 4), c4 = idx - row * (BN / 4);
             const unsigned po = pix_off[row];
             if (po != NO_PIX && n0 + c4 * 4 < g.Cout)
                 *(f32x4 *)(((po >> 31) ? base1 : base0) + (size_t)(po & 0x7fffffffu) * 16 + (size_t)(n0 + c4 * 4) * 4) = *(const f32x4 *)&tile[row * TS + c4 * 4];
@@ -466,15 +487,17 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
     }
     constexpr int EB = 4;
 #pragma unroll 1
-    for (int kb = 0; kb < BM * (BN / 4) / 256; kb += EB) {
-        unsigned po[EB], nb[EB], xb[EB];
+    for (int kb = 0; kb < BM * (BN / 4) / ET; kb += EB) {
+        unsigned po[EB], nb[EB];   // nb: the addend's mask nibble | the norm mask's nibble << 4
         f32x4 v[EB], mv[EB], av[EB], xv[EB];
         // (byte offsets and flags are recomputed from po where they are used: kept in arrays they cost the registers that
         // separate this kernel from spilling)
-        auto boff = [&](unsigned p) { return (size_t)(p & 0x7fffffffu) * 16 + (size_t)(n0 + cq * 4) * 4; };
+        // (SUMS launches are bounded to 4 GiB tensors by the launcher: 32-bit offsets there)
+        typedef typename std::conditional<SUMS, unsigned, size_t>::type off_t;
+        auto boff = [&](unsigned p) { return (off_t)(p & 0x7fffffffu) * 16 + (off_t)(n0 + cq * 4) * 4; };
 #pragma unroll
         for (int u = 0; u < EB; ++u) {
-            const int row = (tid >> 5) + 8 * (kb + u);   // idx = tid + 256 (kb + u): row idx / 32, channel group idx % 32 = cq
+            const int row = (tid >> 5) + (ET / 32) * (kb + u);   // idx = tid + ET (kb + u): row idx / 32, channel group idx % 32 = cq
             po[u] = pix_off[row];
             v[u] = *(const f32x4 *)&tile[row * TS + cq * 4];
         }
@@ -482,14 +505,14 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
         for (int u = 0; u < EB; ++u) {
             const bool sd = po[u] != NO_PIX && (po[u] >> 31);
             const bool hm = sd && g.relu_src != nullptr, ha = sd && g.addend != nullptr, hx = sd && sums;
-            const size_t bo = boff(po[u]);
+            const off_t bo = boff(po[u]);
             mv[u] = *(const f32x4 *)(hm ? (const char *)g.relu_src + bo : dummy);
             av[u] = *(const f32x4 *)(ha ? (const char *)g.addend + bo : dummy);
             xv[u] = *(const f32x4 *)(hx ? (const char *)g.ns_x + bo : dummy);
-            const size_t f = ha ? bo >> 4 : 0;   // float4 index of these 4 elements
+            const off_t f = ha ? bo >> 4 : 0;   // float4 index of these 4 elements
             nb[u] = (amask[f >> 3] >> (4 * (int)(f & 7))) & 15u;
-            const size_t fx = hx ? bo >> 4 : 0;
-            xb[u] = (nmask[fx >> 3] >> (4 * (int)(fx & 7))) & 15u;
+            const off_t fx = hx ? bo >> 4 : 0;
+            nb[u] |= ((nmask[fx >> 3] >> (4 * (int)(fx & 7))) & 15u) << 4;
         }
 #pragma unroll
         for (int u = 0; u < EB; ++u) {
@@ -499,7 +522,7 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
                 for (int q = 0; q < 4; ++q) v[u][q] = mv[u][q] > 0.f ? v[u][q] : 0.f;
             }
             if (sd && g.addend != nullptr) {
-                if (g.addend_mask == nullptr) nb[u] = 15u;
+                if (g.addend_mask == nullptr) nb[u] |= 15u;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[u][q] += (nb[u] >> q) & 1u ? av[u][q] : 0.f;
             }
@@ -510,25 +533,26 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
                 if (g.ns_act != ACG_ACT_NONE) {
                     const f32x4 yy = xh * ga + be; // same expression as norm_apply_kernel: its sign is the mask
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) gy[q] = (remask ? yy[q] > 0.f : ((xb[u] >> q) & 1u) != 0u) ? gy[q] : 0.f;
+                    for (int q = 0; q < 4; ++q) gy[q] = (remask ? yy[q] > 0.f : ((nb[u] >> (4 + q)) & 1u) != 0u) ? gy[q] : 0.f;
                 }
                 s1 += gy;
                 s2 += gy * xh;
             }
         }
     }
-    if (sums) { // thread (cq, tid >> 5) holds rows (tid >> 5) + 8 j of channels 4 cq .. 4 cq + 3
-        __syncthreads(); // every thread is done reading the staged tile: its LDS becomes the scratch [2][8 row groups][BN]
+    if (sums) { // thread (cq, tid >> 5) holds rows (tid >> 5) + 16 j of channels 4 cq .. 4 cq + 3
+        __syncthreads(); // every thread is done reading the staged tile: its LDS becomes the scratch [2][16 row groups][BN]
+        constexpr int RG = ET / 32;
         float *sc = (float *)lds;
         const int rg = tid >> 5;
-        *(f32x4 *)&sc[(0 * 8 + rg) * BN + cq * 4] = s1;
-        *(f32x4 *)&sc[(1 * 8 + rg) * BN + cq * 4] = s2;
+        *(f32x4 *)&sc[(0 * RG + rg) * BN + cq * 4] = s1;
+        *(f32x4 *)&sc[(1 * RG + rg) * BN + cq * 4] = s2;
         __syncthreads();
         if (tid < 64) {
             const int k = tid >> 5, cc = tid & 31, chunk = (m0 - img * GHW) / BM;
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 8; ++r) a += *(const f32x4 *)&sc[(k * 8 + r) * BN + cc * 4];
+            for (int r = 0; r < RG; ++r) a += *(const f32x4 *)&sc[(k * RG + r) * BN + cc * 4];
             if (n0 + cc * 4 < g.Cout)
                 *(f32x4 *)(g.ns_part + ((size_t)(img * (GHW / BM) + chunk) * 2 + k) * g.Cout + n0 + cc * 4) = a;
         }
@@ -582,6 +606,7 @@ int acg_igemm_x3_pre_launch(const void *in, const void *wp, const float *bias, f
                 "igemm_conv_x3_pre: per-tile statistics need whole 128-pixel tiles per image, no activation, fp32 output");
     ACG_REQUIRE(!g.out_s16 || (g.addend == nullptr && g.Cout % 8 == 0), "igemm_conv_x3_pre: pre-split output takes no addend");
     ACG_REQUIRE(g.relu_src == nullptr || g.fold_p > 0 || g.unpad, "igemm_conv_x3_pre: the ReLU source needs the frame path");
+    ACG_REQUIRE(g.ns_part == nullptr || out_bytes < (1LL << 32), "igemm_conv_x3_pre: norm sums on a tensor of 4 GiB or more");
     ACG_REQUIRE(g.ns_part == nullptr || (g.unpad && !g.out_s16 && g.Cout % 4 == 0 && (g.ns_act == ACG_ACT_NONE || g.ns_act == ACG_ACT_RELU) &&
                                        g.ns_x != nullptr && g.ns_mean != nullptr && g.ns_rstd != nullptr &&
                                        (g.ns_act == ACG_ACT_NONE || g.ns_mask != nullptr || (g.ns_gamma != nullptr && g.ns_beta != nullptr))),

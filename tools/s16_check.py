@@ -154,9 +154,17 @@ def run(N, H, W, C, time_it, iters):
     if not time_it:
         return ok
     flops = 2.0 * N * H * W * C * C * 9
+
+    def dg_s16_add():    # + masked skip addend (fp32 out): the block's first convolution
+        _lib.call("acg_conv2d_bwd_data_s16", D, P(dys), P(pk.wb), P(dx1), P(ws), nb_d, P(skip), P(mask), None, 0, st)
+
+    def dg_s16_relu():   # pre-split output masked by the sign of the convolution's own input: conv + ReLU in front
+        _lib.call("acg_conv2d_bwd_data_s16", D, P(dys), P(pk.wb), P(dx1), P(ws), nb_d, None, None, P(xs), 1, st)
+
     for rnd in range(3):
         line = "round %d:" % rnd
         for nm, f in (("fwd ref", fwd_ref), ("fwd s16", fwd_s16), ("dgrad ref", dg_ref), ("dgrad s16", dg_s16),
+                      ("dgrad s16 + addend", dg_s16_add), ("dgrad s16 relu", dg_s16_relu),
                       ("wgrad ref", wg_ref), ("wgrad s16", wg_s16)):
             f()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
