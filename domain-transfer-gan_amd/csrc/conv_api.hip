@@ -684,62 +684,64 @@ static void fwd_geom(const acg_conv_desc *d, Geom *g, Taps *t, int act)
 // their own mirrored rows carry).  A (N H 2) x (3 C) x C GEMM, 0.4 % of the layer: one 32x32x16 MFMA tile per wave, both
 // operands read straight into fragment layout — a pre-split pixel's 8-channel group IS an A fragment, 8 consecutive output
 // channels of a packed-wb row ARE a B fragment — same bf16x3 products as the main kernel.
-// grid (N * H / 32, 2, CiP / 128) x 1024 threads: 32 rows of one image, one side, 128 dx channels.
+// grid (N * H / 32, 2, CiP / 128) x 256 threads: 32 rows of one image, one side, wave w = dx channels 32w .. 32w+31 of 128.
 typedef __bf16 cf_bf16x8 __attribute__((ext_vector_type(8)));
-__global__ __launch_bounds__(1024) void dgrad_colfix_kernel(const char *__restrict__ dy, const __bf16 *__restrict__ wb,
-                                                            long long w_lo_elems, float *__restrict__ colfix, int H, int W,
-                                                            int C, int CiP, int Cdx)
+__global__ __launch_bounds__(256) void dgrad_colfix_kernel(const char *__restrict__ dy, const __bf16 *__restrict__ wb,
+                                                           long long w_lo_elems, float *__restrict__ colfix, int H, int W,
+                                                           int C, int CiP, int Cdx)
 {
-    // 16 waves: wave = 4 sg + cg computes kernel row sg (sg == 3: the corner term of the tile that holds row 1 — kh 0, dy row 0
-    // — or row H-2 — kh 2, dy row H-1) for dx channels 32 cg .. 32 cg + 31; the four partial tiles of a channel group meet in
-    // LDS in fixed order.  Memory latency is the whole cost of this kernel: a kernel row is one round of 32 independent
-    // fragment loads per lane (128 channels), and the rows run side by side instead of one after the other (13 -> ~6 us).
-    __shared__ float red[3][4][16][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cg = wave & 3, sg = wave >> 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tiles = H / 32, n = blockIdx.x / tiles, qy0 = (blockIdx.x - n * tiles) * 32, side = blockIdx.y;
     const int lr = lane & 31, kg = lane >> 5;
-    const int qy = qy0 + lr, ci = blockIdx.z * 128 + cg * 32 + lr;
+    const int qy = qy0 + lr, ci = blockIdx.z * 128 + wave * 32 + lr;
     const int col = side ? W - 1 : 0, kw = side ? 2 : 0;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const cf_bf16x8 zero = {};
+    // kernel rows 0..2, then the corner term of the tile that holds row 1 (kh 0, dy row 0) or row H-2 (kh 2, dy row H-1).
+    // A step is 128 channels = eight 16-channel chunks whose 32 fragment loads are issued together, the next step's before this
+    // step's MFMAs (one wave per SIMD: registers are free, memory latency is the whole cost of this kernel).
     const int extra = qy0 == 0 ? 0 : (qy0 + 32 == H ? 2 : -1);
-    if (sg < 3 || extra >= 0) {
-        const int kh = sg < 3 ? sg : extra;
+    const int nsteps = (3 + (extra >= 0 ? 1 : 0)) * (C / 128);
+    cf_bf16x8 ah[2][8], al[2][8], bh[2][8], bl[2][8];
+    auto load = [&](int s, int b) {
+        const int step = s / (C / 128), c128 = s - step * (C / 128);
+        const int kh = step < 3 ? step : extra;
         int ry;
         bool ok;
-        if (sg < 3) { ry = qy + 1 - kh; ok = (unsigned)ry < (unsigned)H; }
+        if (step < 3) { ry = qy + 1 - kh; ok = (unsigned)ry < (unsigned)H; }
         else { ry = extra == 0 ? 0 : H - 1; ok = qy == (extra == 0 ? 1 : H - 2); }
-        for (int c128 = 0; c128 < C / 128; ++c128) {
-            const char *ap = dy + (((long long)n * H + (ok ? ry : 0)) * W + col) * C * 4 + c128 * 512 + kg * 32;
-            const __bf16 *bp = wb + (((long long)(kh * 3 + kw) * (C / 16) + c128 * 8) * CiP + ci) * 16 + kg * 8;
-            cf_bf16x8 ah[8], al[8], bh[8], bl[8];
+        const char *ap = dy + (((long long)n * H + (ok ? ry : 0)) * W + col) * C * 4 + c128 * 512 + kg * 32;
+        const __bf16 *bp = wb + (((long long)(kh * 3 + kw) * (C / 16) + c128 * 8) * CiP + ci) * 16 + kg * 8;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                ah[u] = zero; al[u] = zero;
-                if (ok) { ah[u] = *(const cf_bf16x8 *)(ap + u * 64); al[u] = *(const cf_bf16x8 *)(ap + u * 64 + 16); }
-                bh[u] = *(const cf_bf16x8 *)(bp + (long long)u * CiP * 16);
-                bl[u] = *(const cf_bf16x8 *)(bp + w_lo_elems + (long long)u * CiP * 16);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[u], bh[u], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], bl[u], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], bh[u], acc, 0, 0, 0);
-            }
+        for (int u = 0; u < 8; ++u) {
+            ah[b][u] = zero; al[b][u] = zero;
+            if (ok) { ah[b][u] = *(const cf_bf16x8 *)(ap + u * 64); al[b][u] = *(const cf_bf16x8 *)(ap + u * 64 + 16); }
+            bh[b][u] = *(const cf_bf16x8 *)(bp + (long long)u * CiP * 16);
+            bl[b][u] = *(const cf_bf16x8 *)(bp + w_lo_elems + (long long)u * CiP * 16);
         }
-    }
-    if (sg > 0) {
+    };
+    auto mma = [&](int b) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[sg - 1][cg][r][lane] = acc[r];
+        for (int u = 0; u < 8; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[b][u], bh[b][u], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[b][u], bl[b][u], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[b][u], bh[b][u], acc, 0, 0, 0);
+        }
+    };
+    load(0, 0);
+    for (int s = 0; s < nsteps; s += 2) {   // two steps per trip: the buffer index stays a compile-time constant
+        if (s + 1 < nsteps) load(s + 1, 1);
+        mma(0);
+        if (s + 2 < nsteps) load(s + 2, 0);
+        if (s + 1 < nsteps) mma(1);
     }
-    __syncthreads();
-    if (sg == 0 && ci < Cdx) {
+    if (ci < Cdx) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * kg;
-            colfix[(((long long)n * H + qy0 + row) * 2 + side) * Cdx + ci] = ((acc[r] + red[0][cg][r][lane]) + red[1][cg][r][lane]) + red[2][cg][r][lane];
+            colfix[(((long long)n * H + qy0 + row) * 2 + side) * Cdx + ci] = acc[r];
         }
     }
 }
@@ -801,7 +803,7 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
                         (relu_src == nullptr || relu_s16 == out_s16) && d->Co % 128 == 0,
                         "dgrad: unsupported pre-split combination (query acg_conv2d_s16_supported)");
             const int CiP = acg_ncols_pad(d->Ci);
-            hipLaunchKernelGGL(dgrad_colfix_kernel, dim3(d->N * (d->Hi / 32), 2, CiP / 128), dim3(1024), 0, st, (const char *)src,
+            hipLaunchKernelGGL(dgrad_colfix_kernel, dim3(d->N * (d->Hi / 32), 2, CiP / 128), dim3(256), 0, st, (const char *)src,
                                (const __bf16 *)wb, g.w_elems, (float *)ws, d->Hi, d->Wi, d->Co, CiP, d->Ci);
             ACG_CHECK_LAUNCH("dgrad_colfix_kernel");
             g.unpad = 1; g.colfix = (const float *)ws; g.out2 = dst; g.addend = addend; g.relu_src = relu_src; g.addend_mask = addend_mask;
