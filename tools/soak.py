@@ -17,6 +17,8 @@ from bench import make_opt  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--size", type=int, default=128, help="image side (256: the whole-row-tile kernels of the trunk)")
+    ap.add_argument("--batch", type=int, default=8)
     a = ap.parse_args()
     cfg = argparse.Namespace(nc=3, blocks=6, sync_bn=False)
     torch.manual_seed(0)
@@ -24,9 +26,9 @@ def main():
     g = torch.Generator(device="cuda"); g.manual_seed(1)
     mem = []
     for s in range(a.steps):
-        A = torch.rand((8, 3, 128, 128), device="cuda", generator=g) * 2 - 1
-        B = torch.rand((8, 3, 128, 128), device="cuda", generator=g) * 2 - 1
-        z = torch.randn((8, 16, 1, 1), device="cuda", generator=g)
+        A = torch.rand((a.batch, 3, a.size, a.size), device="cuda", generator=g) * 2 - 1
+        B = torch.rand((a.batch, 3, a.size, a.size), device="cuda", generator=g) * 2 - 1
+        z = torch.randn((a.batch, 16, 1, 1), device="cuda", generator=g)
         losses, _, gn = m.train_instance(A, B, z)
         assert all(v == v and abs(v) < 1e6 for v in losses.values()), (s, losses)
         assert all(v == v for v in gn.values()), (s, gn)
