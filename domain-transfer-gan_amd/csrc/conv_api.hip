@@ -767,7 +767,8 @@ static bool dgrad_unpad_ok(const acg_conv_desc *d)
 static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb, const float *bias, float *dst,
                        int act, void *ws, size_t ws_bytes, hipStream_t st, const float *addend = nullptr,
                        const float *relu_src = nullptr, const unsigned *addend_mask = nullptr, int in_s16 = 0, int out_s16 = 0,
-                       int relu_s16 = 0, float *stats = nullptr, const acg_norm_sums *ns = nullptr)
+                       int relu_s16 = 0, float *stats = nullptr, const acg_norm_sums *ns = nullptr,
+                       const unsigned *relu_mask = nullptr)
 {
     Geom g; Taps t;
     g.Hin = d->Ho; g.Win = d->Wo; g.Cin = d->Co;
@@ -807,7 +808,7 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
                                (const __bf16 *)wb, g.w_elems, (float *)ws, d->Hi, d->Wi, d->Co, CiP, d->Ci);
             ACG_CHECK_LAUNCH("dgrad_colfix_kernel");
             g.unpad = 1; g.colfix = (const float *)ws; g.out2 = dst; g.addend = addend; g.relu_src = relu_src; g.addend_mask = addend_mask;
-            g.out_s16 = out_s16; g.relu_s16 = relu_s16;
+            g.out_s16 = out_s16; g.relu_s16 = relu_s16; g.relu_mask = relu_mask;
             if (ns != nullptr) {
                 g.ns_x = ns->x; g.ns_mean = ns->mean; g.ns_rstd = ns->rstd; g.ns_gamma = ns->gamma; g.ns_beta = ns->beta;
                 g.ns_gstride = ns->gstride; g.ns_mask = ns->sign_mask; g.ns_act = ns->act; g.ns_part = ns->part;
@@ -815,7 +816,8 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
             }
             return acg_igemm_x3_pre_launch(src, wb, bias, dst, g, t, g.w_elems, st);
         }
-        ACG_REQUIRE(ns == nullptr, "dgrad: the norm sums need the un-padded pre-split path (query acg_conv2d_bwd_data_s16_sums_supported)");
+        ACG_REQUIRE(ns == nullptr && relu_mask == nullptr,
+                    "dgrad: norm sums / a sign bitmask as the ReLU source need the un-padded pre-split path (query acg_conv2d_bwd_data_s16_sums_supported)");
         t.n = 0;
         // zero pad: dy row = iy + p - kh ; reflect (padded grid): dy row = py - kh
         const int base = refl ? 0 : p;
@@ -1092,6 +1094,32 @@ extern "C" int acg_conv2d_bwd_data_s16(const acg_conv_desc *d, const void *dy, c
                 "acg_conv2d_bwd_data_s16: the sign bitmask needs an addend and Hi*Wi*Ci/4 %% 8 == 0");
     return dgrad_igemm(d, (const float *)dy, wb, nullptr, (float *)dx, ACG_ACT_NONE, ws, ws_bytes, (hipStream_t)stream, addend,
                        (const float *)relu_src, addend_mask, 1, out_s16, relu_src != nullptr ? 1 : 0);
+}
+
+// conv + ReLU with pre-split output that also leaves the sign bitmask of that output, and the data gradient of the NEXT
+// convolution masked by it (instead of reading the pre-split activation for its sign: 1/32 of the bytes)
+extern "C" int acg_conv2d_fwd_s16_mask(const acg_conv_desc *d, const void *x, const float *wf, const float *bias, void *y,
+                                       unsigned *sign_mask, void *stream)
+{
+    int rc = check_desc(d, "acg_conv2d_fwd_s16_mask");
+    if (rc) return rc;
+    ACG_REQUIRE(g_acg_precision == ACG_PREC_BF16X3 && g_acg_conv_impl == ACG_IMPL_MFMA && sign_mask != nullptr && d->Co % 32 == 0,
+                "acg_conv2d_fwd_s16_mask: bf16x3 MFMA mode, 32-multiple output channels");
+    Geom g; Taps t;
+    fwd_geom(d, &g, &t, ACG_ACT_RELU);
+    g.out_s16 = 1; g.mask_out = sign_mask;
+    return acg_igemm_x3_pre_launch(x, wf, bias, (float *)y, g, t, g.w_elems, (hipStream_t)stream, nullptr);
+}
+
+extern "C" int acg_conv2d_bwd_data_s16_mask(const acg_conv_desc *d, const void *dy, const float *wb, void *dx, void *ws,
+                                            size_t ws_bytes, const unsigned *relu_sign_mask, void *stream)
+{
+    int rc = check_desc(d, "acg_conv2d_bwd_data_s16_mask");
+    if (rc) return rc;
+    ACG_REQUIRE(relu_sign_mask != nullptr && acg_conv2d_bwd_data_s16_sums_supported(d) && d->Ci % 32 == 0,
+                "acg_conv2d_bwd_data_s16_mask: unsupported shape or mode (query acg_conv2d_bwd_data_s16_sums_supported)");
+    return dgrad_igemm(d, (const float *)dy, wb, nullptr, (float *)dx, ACG_ACT_NONE, ws, ws_bytes, (hipStream_t)stream, nullptr, nullptr,
+                       nullptr, 1, 1, 0, nullptr, nullptr, relu_sign_mask);
 }
 
 extern "C" int acg_conv2d_bwd_data_s16_sums_supported(const acg_conv_desc *d)

@@ -56,6 +56,11 @@ struct Geom {
     // (x = hi + lo + O(2^-17 |x|); the same 4 bytes per element as fp32).  out_s16: the written tensor (out2 on the frame
     // path) takes that form; relu_s16: relu_src is stored that way (its sign = the sign of the hi halves).
     int out_s16 = 0, relu_s16 = 0;
+    // out_s16 only.  mask_out: the launch also stores (output > 0) as one bit per element (norm.hip layout: bit e % 32 of word
+    // e / 32 for float index e) — all a later data gradient needs of a conv + ReLU output; relu_mask: such a bitmask takes the
+    // place of relu_src (1/32 of the bytes)
+    unsigned *mask_out = nullptr;
+    const unsigned *relu_mask = nullptr;
     // unpad (pre-split kernel only): data gradient of a ReflectionPad2d(1) 3x3 convolution computed on the UN-padded grid,
     // every tile one grid row.  The adjoint of the mirror folds pad row -1 onto row 1 and pad row H onto row H-2: for the
     // tiles of those two rows the kernel row that reads the mirrored dy row takes the packed slabs 9 + kw = w[0][kw] +

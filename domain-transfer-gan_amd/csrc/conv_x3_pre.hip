@@ -416,23 +416,30 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
         const char *rsrc = (const char *)g.relu_src;
         constexpr int NK = BM * (BN / 8) / ET;   // 4 (pixel, 8-channel group) items per thread
         u32x4 sv[NK];
-        // the sign words of all items first: one round trip (loaded inside the loop they were NK dependent ones)
+        // the sign words of all items first: one round trip (loaded inside the loop they were NK dependent ones).  With a
+        // sign BITMASK as the ReLU source (Geom.relu_mask) an item needs one byte of a 32-bit word: sv[k][0]
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int idx = tid + ET * k, row = idx / (BN / 8), c8 = idx - row * (BN / 8);
             const unsigned po = pix_off[row];
-            const bool need = rsrc != nullptr && po != NO_PIX && (po >> 31) && n0 + c8 * 8 < g.Cout;
-            sv[k] = *(const u32x4 *)(need ? rsrc + (size_t)(po & 0x7fffffffu) * 16 + (size_t)(n0 + c8 * 8) * 4 : in);
+            const bool live = po != NO_PIX && (po >> 31) && n0 + c8 * 8 < g.Cout;
+            const size_t boff = (size_t)(po & 0x7fffffffu) * 16 + (size_t)(n0 + c8 * 8) * 4;
+            if (g.relu_mask != nullptr) sv[k][0] = live ? g.relu_mask[boff >> 7] : 0u;   // boff / 4 = float index, / 32 = word
+            else sv[k] = *(const u32x4 *)(rsrc != nullptr && live ? rsrc + boff : in);
         }
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int idx = tid + ET * k, row = idx / (BN / 8), c8 = idx - row * (BN / 8);
             const unsigned po = pix_off[row];
-            if (po == NO_PIX || n0 + c8 * 8 >= g.Cout) continue;
+            const bool live = po != NO_PIX && n0 + c8 * 8 < g.Cout;
             const size_t boff = (size_t)(po & 0x7fffffffu) * 16 + (size_t)(n0 + c8 * 8) * 4;
             const f32x4 t0 = *(const f32x4 *)&tile[row * TS + c8 * 8], t1 = *(const f32x4 *)&tile[row * TS + c8 * 8 + 4];
             float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-            if (rsrc != nullptr && (po >> 31)) {
+            if (g.relu_mask != nullptr && (po >> 31)) {
+                const unsigned bits = sv[k][0] >> (8 * (c8 & 3));
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = (bits >> q) & 1u ? v[q] : 0.f;
+            } else if (rsrc != nullptr && (po >> 31)) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const unsigned a = sv[k][q] & 0xffffu, b = sv[k][q] >> 16;
@@ -440,6 +447,16 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
                     v[2 * q + 1] = (b - 1u) < 0x7fffu ? v[2 * q + 1] : 0.f;
                 }
             }
+            if (g.mask_out != nullptr) { // (value > 0) bits of these 8 channels; the four lanes of a 32-channel word meet by shuffle
+                unsigned w = 0u;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) w |= (v[q] > 0.f ? 1u : 0u) << q;
+                w = live ? w << (8 * (c8 & 3)) : 0u;
+                w |= __shfl_xor(w, 1);
+                w |= __shfl_xor(w, 2);
+                if (live && (c8 & 3) == 0) g.mask_out[boff >> 7] = w;
+            }
+            if (!live) continue;
             if (g.fold_p > 0 && !(po >> 31)) { // frame pixel of a reflect data gradient: fp32 into the padded scratch, the
                 *(f32x4 *)(base0 + boff) = t0; // fold kernel sums, masks and splits it
                 *(f32x4 *)(base0 + boff + 16) = t1;
@@ -606,6 +623,9 @@ int acg_igemm_x3_pre_launch(const void *in, const void *wp, const float *bias, f
                 "igemm_conv_x3_pre: per-tile statistics need whole 128-pixel tiles per image, no activation, fp32 output");
     ACG_REQUIRE(!g.out_s16 || (g.addend == nullptr && g.Cout % 8 == 0), "igemm_conv_x3_pre: pre-split output takes no addend");
     ACG_REQUIRE(g.relu_src == nullptr || g.fold_p > 0 || g.unpad, "igemm_conv_x3_pre: the ReLU source needs the frame path");
+    ACG_REQUIRE((g.mask_out == nullptr && g.relu_mask == nullptr) || (g.out_s16 && g.Cout % 32 == 0 && g.ncols_pad == g.Cout && g.fold_p == 0 &&
+                                                                        (g.relu_mask == nullptr || (g.unpad && g.relu_src == nullptr))),
+                "igemm_conv_x3_pre: sign bitmasks go with pre-split output, 32-multiple channels and the un-padded grid");
     ACG_REQUIRE(g.ns_part == nullptr || out_bytes < (1LL << 32), "igemm_conv_x3_pre: norm sums on a tensor of 4 GiB or more");
     ACG_REQUIRE(g.ns_part == nullptr || (g.unpad && !g.out_s16 && g.Cout % 4 == 0 && (g.ns_act == ACG_ACT_NONE || g.ns_act == ACG_ACT_RELU) &&
                                        g.ns_x != nullptr && g.ns_mean != nullptr && g.ns_rstd != nullptr &&

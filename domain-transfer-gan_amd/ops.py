@@ -343,9 +343,11 @@ class ReluLink(object):
 
     def __init__(self):
         self.done = False
+        self.mask = None   # sign bitmask of the ReLU output where the producing convolution stored one (pre-split trunk)
 
 
 RELU_LINK = not _debug_switch("ACGAN_NO_RELU_LINK")   # A/B switch
+RELU_MASK = not _debug_switch("ACGAN_NO_RELU_MASK")   # A/B switch: the link carries a sign bitmask instead of the activation
 
 
 # Pre-split ("S16") activation storage of the residual trunk (include/acgan_hip.h, acg_s16_encode): an S16 tensor is carried
@@ -436,8 +438,15 @@ class Conv2dFn(torch.autograd.Function):
             if want_stats is not None and act == ACT_NONE and not s16.y:
                 part = torch.empty((N, (d.Ho * d.Wo) // STATS_ROWS, 2, packed.Co), device=x.device, dtype=torch.float32)
                 want_stats.part = part
-            _lib.call("acg_conv2d_fwd_s16", ctypes.byref(d), _ptr(x), _ptr(packed.wf), _ptr(packed.bias if bias is not None else None),
-                      _ptr(y), act, _ptr(part), 1 if s16.y else 0, _stream())
+            if s16.y and act == ACT_RELU and link_out is not None and RELU_MASK and packed.Co % 32 == 0 and \
+                    _lib.query("acg_conv2d_bwd_data_s16_sums_supported", ctypes.byref(d)):
+                # conv + ReLU feeding the next trunk convolution: its data gradient needs only the SIGN of y (same shape: d fits both)
+                link_out.mask = torch.empty((y.numel() + 31) // 32, device=x.device, dtype=torch.int32)
+                _lib.call("acg_conv2d_fwd_s16_mask", ctypes.byref(d), _ptr(x), _ptr(packed.wf), _ptr(packed.bias if bias is not None else None),
+                          _ptr(y), _ptr(link_out.mask), _stream())
+            else:
+                _lib.call("acg_conv2d_fwd_s16", ctypes.byref(d), _ptr(x), _ptr(packed.wf), _ptr(packed.bias if bias is not None else None),
+                          _ptr(y), act, _ptr(part), 1 if s16.y else 0, _stream())
         elif want_stats is not None and CONV_STATS_ENABLED and act == ACT_NONE and \
                 _lib.query("acg_conv2d_fwd_stats_supported", ctypes.byref(d)):
             part = torch.empty((N, (d.Ho * d.Wo) // STATS_ROWS, 2, packed.Co), device=x.device, dtype=torch.float32)
@@ -546,8 +555,13 @@ def _conv_backward_s16(ctx, x, dy, dskip):
         if p.dx:     # the gradient w.r.t. the pre-activation of the conv + ReLU in front, pre-split for its own backward
             if dskip is not None or ctx.link_in is None:
                 raise _lib.AcgError("pre-split trunk: unexpected skip gradient / missing ReLU link")
-            _lib.call("acg_conv2d_bwd_data_s16", ctypes.byref(d), _ptr(dy), _ptr(pk.wb), _ptr(dx), _ptr(ws), nb, None, None,
-                      _ptr(x), 1, st)
+            if ctx.link_in.mask is not None and ctx.link_in.mask.numel() == (x.numel() + 31) // 32 and \
+                    _lib.query("acg_conv2d_bwd_data_s16_sums_supported", ctypes.byref(d)):
+                _lib.call("acg_conv2d_bwd_data_s16_mask", ctypes.byref(d), _ptr(dy), _ptr(pk.wb), _ptr(dx), _ptr(ws), nb,
+                          _ptr(ctx.link_in.mask), st)
+            else:
+                _lib.call("acg_conv2d_bwd_data_s16", ctypes.byref(d), _ptr(dy), _ptr(pk.wb), _ptr(dx), _ptr(ws), nb, None, None,
+                          _ptr(x), 1, st)
             ctx.link_in.done = True
         else:
             smask = None

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ACG_VERSION 111
+#define ACG_VERSION 112
 
 typedef enum {
     ACG_OK = 0,
@@ -160,6 +160,14 @@ int acg_conv2d_bwd_data_s16_sums_supported(const acg_conv_desc *d);
 int acg_conv2d_bwd_data_s16_sums(const acg_conv_desc *d, const void *dy_s16, const float *wb, float *dx, void *ws,
                                  size_t ws_bytes, const float *addend, const unsigned *addend_sign_mask,
                                  const acg_norm_sums *ns, void *stream);
+/* conv + ReLU with S16 output that also stores (y > 0) as a sign bitmask (layout of acg_norm_apply's: bit e % 32 of word e / 32
+ * for float index e; Co % 32 == 0), and the S16-output data gradient of the convolution BEHIND it masked by that bitmask
+ * instead of by the sign of its S16 input (where acg_conv2d_bwd_data_s16_sums_supported(d)): the pad-conv-ReLU-pad-conv chain
+ * of modules.py:211-227 without reading the activation a second time */
+int acg_conv2d_fwd_s16_mask(const acg_conv_desc *d, const void *x_s16, const float *wf, const float *bias, void *y_s16,
+                            unsigned *sign_mask, void *stream);
+int acg_conv2d_bwd_data_s16_mask(const acg_conv_desc *d, const void *dy_s16, const float *wb, void *dx_s16, void *ws,
+                                 size_t ws_bytes, const unsigned *relu_sign_mask, void *stream);
 /* x and dy S16; dw / db as acg_conv2d_bwd_weight */
 int acg_conv2d_bwd_weight_s16(const acg_conv_desc *d, const void *x_s16, const void *dy_s16, float *dw, float *db, int Or,
                               int Ir, void *ws, size_t ws_bytes, int accumulate, void *stream);

@@ -75,6 +75,17 @@ def run(N, H, W, C, time_it, iters):
     _lib.call("acg_conv2d_fwd_s16", D, P(xs), P(pk.wf), P(pk.bias), P(y2), 1, None, 1, st)
     ok &= check("fwd + ReLU (S16 out) vs encode(fp32 out)", y2.view(torch.int32), enc(y0).view(torch.int32))
 
+    # conv + ReLU, pre-split output + the sign bitmask of that output (Co % 32 == 0, whole-row tiles)
+    masked = W % 128 == 0 and H % 32 == 0 and H >= 64 and _lib.query("acg_conv2d_bwd_data_s16_sums_supported", ctypes.byref(d))
+    if masked:
+        y3 = torch.empty_like(x)
+        bits = torch.zeros((x.numel() + 31) // 32, device=dev, dtype=torch.int32)
+        _lib.call("acg_conv2d_fwd_s16_mask", D, P(xs), P(pk.wf), P(pk.bias), P(y3), P(bits), st)
+        ok &= check("fwd + ReLU (S16 out) + sign bitmask: y", y3.view(torch.int32), y2.view(torch.int32))
+        want = (y0.reshape(-1, 32) > 0).to(torch.int64)       # y0: fp32 conv + ReLU output
+        want = (want << torch.arange(32, device=dev)).sum(1)
+        got = bits.to(torch.int64) & 0xFFFFFFFF
+        ok &= check("fwd + ReLU (S16 out) + sign bitmask: bits", got.double(), want.double())
     # data gradients
     dx0, dx1 = torch.empty_like(x), torch.empty_like(x)
 
@@ -97,6 +108,13 @@ def run(N, H, W, C, time_it, iters):
     ok &= check("dgrad + masked skip addend (fp32 out)", dx1, dx0, exact=not unpad, tol=2e-5)
     _lib.call("acg_conv2d_bwd_data_relu", D, P(dy), P(pk.wb), P(x), P(dx0), P(ws), nb_d, st)
     _lib.call("acg_conv2d_bwd_data_s16", D, P(dys), P(pk.wb), P(dx1), P(ws), nb_d, None, None, P(xs), 1, st)
+    if masked:   # the same data gradient masked by the sign BITMASK of x instead of by x itself
+        xbits = (x.reshape(-1, 32) > 0).to(torch.int64)
+        xbits = (xbits << torch.arange(32, device=dev)).sum(1)
+        xbits = torch.where(xbits >= 2 ** 31, xbits - 2 ** 32, xbits).to(torch.int32)
+        dx2 = torch.empty_like(x)
+        _lib.call("acg_conv2d_bwd_data_s16_mask", D, P(dys), P(pk.wb), P(dx2), P(ws), nb_d, P(xbits), st)
+        ok &= check("dgrad masked by the sign bitmask vs masked by x (S16 out)", dx2.view(torch.int32), dx1.view(torch.int32))
     if unpad:
         ok &= check("dgrad * (x > 0) (S16 out) vs ref", dec(dx1), dx0, exact=False, tol=3e-5)
     else:
@@ -161,10 +179,13 @@ def run(N, H, W, C, time_it, iters):
     def dg_s16_relu():   # pre-split output masked by the sign of the convolution's own input: conv + ReLU in front
         _lib.call("acg_conv2d_bwd_data_s16", D, P(dys), P(pk.wb), P(dx1), P(ws), nb_d, None, None, P(xs), 1, st)
 
+    def dg_s16_bits():   # ... by the sign bitmask of that input
+        _lib.call("acg_conv2d_bwd_data_s16_mask", D, P(dys), P(pk.wb), P(dx1), P(ws), nb_d, P(xbits), st)
+
     for rnd in range(3):
         line = "round %d:" % rnd
         for nm, f in (("fwd ref", fwd_ref), ("fwd s16", fwd_s16), ("dgrad ref", dg_ref), ("dgrad s16", dg_s16),
-                      ("dgrad s16 + addend", dg_s16_add), ("dgrad s16 relu", dg_s16_relu),
+                      ("dgrad s16 + addend", dg_s16_add), ("dgrad s16 relu", dg_s16_relu), ("dgrad s16 bits", dg_s16_bits),
                       ("wgrad ref", wg_ref), ("wgrad s16", wg_s16)):
             f()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
