@@ -332,6 +332,13 @@ class NormSums(object):
 
 NORM_SUMS = not _debug_switch("ACGAN_NO_NORM_SUMS")   # A/B switch
 NORM_SUMS_USED = 0   # norm backward passes that took their sums from a data-gradient epilogue (tests read it)
+# Which fused paths the step actually took (bench.py prints them per step as `fused_paths`, so a fusion that a torch-side
+# change — a hook, a clone, a shape — silently turned off shows in the bench line): launches per key since the last clear()
+FUSED = {}
+
+
+def _fused(key, n=1):
+    FUSED[key] = FUSED.get(key, 0) + n
 
 
 class ReluLink(object):
@@ -442,14 +449,17 @@ class Conv2dFn(torch.autograd.Function):
                     _lib.query("acg_conv2d_bwd_data_s16_sums_supported", ctypes.byref(d)):
                 # conv + ReLU feeding the next trunk convolution: its data gradient needs only the SIGN of y (same shape: d fits both)
                 link_out.mask = torch.empty((y.numel() + 31) // 32, device=x.device, dtype=torch.int32)
+                _fused("conv_fwd_s16_relu_bitmask")
                 _lib.call("acg_conv2d_fwd_s16_mask", ctypes.byref(d), _ptr(x), _ptr(packed.wf), _ptr(packed.bias if bias is not None else None),
                           _ptr(y), _ptr(link_out.mask), _stream())
             else:
+                _fused("conv_fwd_s16")
                 _lib.call("acg_conv2d_fwd_s16", ctypes.byref(d), _ptr(x), _ptr(packed.wf), _ptr(packed.bias if bias is not None else None),
                           _ptr(y), act, _ptr(part), 1 if s16.y else 0, _stream())
         elif want_stats is not None and CONV_STATS_ENABLED and act == ACT_NONE and \
                 _lib.query("acg_conv2d_fwd_stats_supported", ctypes.byref(d)):
             part = torch.empty((N, (d.Ho * d.Wo) // STATS_ROWS, 2, packed.Co), device=x.device, dtype=torch.float32)
+            _fused("conv_fwd_tile_stats")
             _lib.call("acg_conv2d_fwd_stats", ctypes.byref(d), _ptr(x), _ptr(packed.wf),
                       _ptr(packed.bias if bias is not None else None), _ptr(y), _ptr(part), _stream())
             want_stats.part = part
@@ -497,11 +507,13 @@ class Conv2dFn(torch.autograd.Function):
                     dskip, smask = ctx.skip_grad.take(dskip)
             if dskip is not None and _lib.query("acg_conv2d_bwd_data_add_supported", ctypes.byref(d)) and \
                     (smask is None or (d.Hi * d.Wi * (d.Ci // 4)) % 8 == 0):
+                _fused("dgrad_skip_addend")
                 _lib.call("acg_conv2d_bwd_data_add", ctypes.byref(d), _ptr(g), _ptr(pk.wb), _ptr(dskip), _ptr(smask), _ptr(dx),
                           _ptr(ws), nb, st)
                 smask = None
             elif (dskip is None and ctx.link_in is not None and RELU_LINK
                   and _lib.query("acg_conv2d_bwd_data_add_supported", ctypes.byref(d))):
+                _fused("dgrad_relu_link")
                 _lib.call("acg_conv2d_bwd_data_relu", ctypes.byref(d), _ptr(g), _ptr(pk.wb), _ptr(x), _ptr(dx), _ptr(ws), nb, st)
                 ctx.link_in.done = True
             else:
@@ -557,9 +569,11 @@ def _conv_backward_s16(ctx, x, dy, dskip):
                 raise _lib.AcgError("pre-split trunk: unexpected skip gradient / missing ReLU link")
             if ctx.link_in.mask is not None and ctx.link_in.mask.numel() == (x.numel() + 31) // 32 and \
                     _lib.query("acg_conv2d_bwd_data_s16_sums_supported", ctypes.byref(d)):
+                _fused("dgrad_s16_relu_bitmask")
                 _lib.call("acg_conv2d_bwd_data_s16_mask", ctypes.byref(d), _ptr(dy), _ptr(pk.wb), _ptr(dx), _ptr(ws), nb,
                           _ptr(ctx.link_in.mask), st)
             else:
+                _fused("dgrad_s16_relu_src")
                 _lib.call("acg_conv2d_bwd_data_s16", ctypes.byref(d), _ptr(dy), _ptr(pk.wb), _ptr(dx), _ptr(ws), nb, None, None,
                           _ptr(x), 1, st)
             ctx.link_in.done = True
@@ -573,10 +587,16 @@ def _conv_backward_s16(ctx, x, dy, dskip):
                 # dx is the gradient w.r.t. the output of the norm in front: its backward sums leave with the tiles
                 part = torch.empty((d.N, (d.Hi * d.Wi) // STATS_ROWS, 2, d.Ci), device=dx.device, dtype=torch.float32)
                 desc = ns.desc(part)
+                _fused("dgrad_s16_norm_sums")
+                if smask is not None:
+                    _fused("dgrad_s16_lazy_skip")
                 _lib.call("acg_conv2d_bwd_data_s16_sums", ctypes.byref(d), _ptr(dy), _ptr(pk.wb), _ptr(dx), _ptr(ws), nb, _ptr(dskip),
                           _ptr(smask), ctypes.byref(desc), st)
                 ns.part, ns.dx = part, dx
             else:
+                _fused("dgrad_s16_plain")
+                if smask is not None:
+                    _fused("dgrad_s16_lazy_skip")
                 _lib.call("acg_conv2d_bwd_data_s16", ctypes.byref(d), _ptr(dy), _ptr(pk.wb), _ptr(dx), _ptr(ws), nb, _ptr(dskip),
                           _ptr(smask), None, 0, st)
         span.done()
@@ -590,6 +610,7 @@ def _conv_backward_s16(ctx, x, dy, dskip):
         nb = _lib.query("acg_conv2d_bwd_weight_workspace_bytes", ctypes.byref(d))
         ws = workspace(nb)
         span = ConvTimer.span("wgrad", d)
+        _fused("wgrad_s16")
         _lib.call("acg_conv2d_bwd_weight_s16", ctypes.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), pk.Or, pk.Ir, _ptr(ws),
                   nb, 1 if direct is not None else 0, st)
         span.done()
@@ -720,6 +741,7 @@ class NormAct(torch.autograd.Function):
         else:
             part = stats if kind in ("in", "cin") else None
             if part is not None:  # the producing convolution already reduced 128-pixel tiles: merge only
+                _fused("norm_stats_from_conv_epilogue")
                 _lib.call("acg_norm_stats_from_partials", _ptr(part), G, P, C, STATS_ROWS, eps, unbiased, _ptr(mean),
                           _ptr(rstd), st)
             else:
@@ -781,6 +803,7 @@ class NormAct(torch.autograd.Function):
         if part is not None:
             global NORM_SUMS_USED
             NORM_SUMS_USED += 1
+            _fused("norm_bwd_sums_from_dgrad")
             _lib.call("acg_norm_bwd_partials", _ptr(dy), _ptr(y), _ptr(mask), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gp), _ptr(bp),
                       gstride, _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), 0 if gstride else gshape[0],
                       1 if direct is not None else 0, G, P, C, act, unbiased, 1 if ctx.s16_dx else 0, _ptr(part), part.shape[1],
@@ -789,6 +812,8 @@ class NormAct(torch.autograd.Function):
             _lib.call("acg_norm_bwd", _ptr(dy), _ptr(y), _ptr(mask), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gp), _ptr(bp), gstride, _ptr(dx),
                       _ptr(dres), _ptr(dgamma), _ptr(dbeta), 0 if gstride else gshape[0], 1 if direct is not None else 0, G, P, C,
                       act, unbiased, 1 if ctx.s16_dx else 0, _ptr(ws), nb, _stream())
+        if mask is not None:
+            _fused("norm_bwd_sign_bitmask")
         if kind == "cin":
             dg, db = dgamma.view(G, C), dbeta.view(G, C)
         elif direct is not None:

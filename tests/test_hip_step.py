@@ -71,13 +71,16 @@ REC_TOL = {("f32", "init"): (2e-4, 2e-2), ("f32", "rich"): (3e-4, 4e-2),
 # flips under the 2^-17 operand rounding changes single entries discretely (tools/conditioning_probe.py).
 # Measured worst over the five fixtures: f32 inside (3e-3, 5e-3); bf16x3 on the 'init' flavour (the reference's own
 # initialisation statistics) 1.2e-2 on one CondInstanceNorm shift-conv weight of the full-width config-1 fixture (a sum over
-# ReLU-gated per-sample shifts), all other tensors < 1e-2.  On the deliberately ill-conditioned 'rich' flavour the bf16x3
+# ReLU-gated per-sample shifts), all other tensors < 1e-2.  On the deliberately ill-conditioned 'rich' flavour some bf16x3
 # digests are not a pin: switching the InstanceNorm statistics between two equally accurate fp32 methods (both 1e-7 from fp64,
 # test_conv_epilogue_statistics_equal_the_statistics_pass) moves the forward by 3e-5 and the CondInstanceNorm shift / scale
-# convolution gradients by up to 17 % there (tools/debug_stats_ab.py); those fixtures pin the gradients in the f32 mode and
-# are held to 0.25 in bf16x3.
+# convolution gradients by up to 17 % there (tools/debug_stats_ab.py).  Those tensors are SKIPPED BY NAME in bf16x3 on 'rich'
+# (RICH_X3_SKIP: the f32 mode pins them on the same fixtures); every other tensor is held to the bf16x3 tolerance.
 DIGEST_TOL = {"f32": (3e-3, 5e-3), "bf16x3": (2e-2, 2e-2)}
-DIGEST_TOL_RICH_X3 = (0.25, 0.25)
+# (network, substring of the parameter name): the latent-conditioned SHIFT layers (modules.py:111-118: ReLU(1x1 conv(z)),
+# a sum over ReLU-gated per-sample shifts) of the two full-resolution CondInstanceNorms of G_A_B whose planes are largest —
+# the only tensors of the 'rich' fixtures outside the bf16x3 tolerance (measured 3e-2 .. 0.16; all others <= 2e-2)
+RICH_X3_SKIP = (("netG_A_B", "model.2.shift_conv"), ("netG_A_B", "model.14.shift_conv"))
 # Networks whose .grad after the step is comparable: the reference lets loss_G.backward() pile the (unused) G-phase
 # gradients on top of the discriminators' D-phase .grad (model.py:509, no zero_grad for them); the HIP path skips those
 # weight gradients, so the discriminators are pinned by their UPDATE digests (which only see the D-phase gradient).
@@ -85,8 +88,9 @@ GRAD_NETS = ("netG_A_B", "netG_B_A", "netE_B")
 
 
 def _check_digests(m, arr, pre, prec, flavour="init"):
-    gt, ut = DIGEST_TOL_RICH_X3 if (prec == "bf16x3" and flavour == "rich") else DIGEST_TOL[prec]
-    bad, seen = [], 0
+    gt, ut = DIGEST_TOL[prec]
+    skip = RICH_X3_SKIP if (prec == "bf16x3" and flavour == "rich") else ()
+    bad, seen, skipped = [], 0, []
     for nname, net in m._net_dict().items():
         params = dict(net.named_parameters())
         grads = {k: (p.grad.detach().cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32))
@@ -96,23 +100,24 @@ def _check_digests(m, arr, pre, prec, flavour="init"):
             key = "s0/grad/%s/%s" % (nname, k)
             assert key in arr, key
             g = grads[k]
+            is_skip = any(nname == sn and sub in k for sn, sub in skip)
             if nname in GRAD_NETS:
                 dg, rg = digest(g), arr[key]
                 floor = 3e-5 * gmax * np.array([g.size, np.sqrt(g.size)])    # summation noise on analytically-zero gradients
                 if not np.all(np.abs(dg[1:3] - rg[1:3]) <= gt * np.abs(rg[1:3]) + floor):
-                    bad.append(("grad", nname, k, dg[1:3], rg[1:3]))
-                if os.environ.get("ACG_TEST_VERBOSE") and "_conv" in k:
-                    print("digest", nname, k, np.abs(dg[1:3] - rg[1:3]) / np.abs(rg[1:3]))
-                seen += 1
+                    (skipped if is_skip else bad).append(("grad", nname, k, float(np.max(np.abs(dg[1:3] - rg[1:3]) / (np.abs(rg[1:3]) + 1e-30)))))
+                seen += 0 if is_skip else 1
             d = digest(p.detach().cpu().numpy().astype(np.float64) - pre[nname][k].astype(np.float64))
             r = arr["s0/upd/%s/%s" % (nname, k)]
             # Adam's g / (|g| + eps) amplifies rounding noise on ~zero gradients to O(lr): well-conditioned tensors only (for
             # the discriminators the criterion uses this side's D-phase gradient, which is what their update was made from)
             if np.min(np.abs(g)) > 1e-5 * gmax and np.min(np.abs(g)) > 1e-6:
                 if not (abs(d[1] - r[1]) <= ut * r[1] + 1e-12 and abs(d[2] - r[2]) <= ut * r[2] + 1e-12):
-                    bad.append(("upd", nname, k, d[1:3], r[1:3]))
-                seen += 1
-    assert seen > 50 and not bad, (len(bad), bad[:6])
+                    (skipped if is_skip else bad).append(("upd", nname, k, float(max(abs(d[1] - r[1]) / (r[1] + 1e-30), abs(d[2] - r[2]) / (r[2] + 1e-30)))))
+                seen += 0 if is_skip else 1
+    if skipped:
+        print("digests outside the tolerance on tensors skipped by name (%s, %s):" % (prec, flavour), skipped)
+    assert seen > 50 and not bad, (len(bad), bad)
 
 
 def _check_steps(name, prec):
