@@ -44,6 +44,11 @@ constexpr unsigned NO_PIX = 0xFFFFFFFFu;
 #ifdef ACG_STAMP
 // diagnostic build only: per consumer wave (barrier wait, rest) cycles of the main loop, [workgroup][wave][2]
 __device__ unsigned long long g_pre_stamps[8192 * 8 * 3];   // [workgroup][wave][3]
+__device__ unsigned long long g_pre_tile[8192 * 4];        // [workgroup]: cycles of set-up, main loop, epilogue (wave 0); start (100 MHz clock)
+extern "C" int acg_debug_pre_tile(unsigned long long *host, size_t n)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pre_tile), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
 extern "C" int acg_debug_pre_stamps(unsigned long long *host, size_t n)
 {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pre_stamps), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
@@ -66,6 +71,10 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwg = gridDim.x, bid = blockIdx.x;
+#ifdef ACG_STAMP
+    const unsigned long long tl_entry = __builtin_amdgcn_s_memtime(), tl_real = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tl_loop0 = 0, tl_loop1 = 0;
+#endif
     const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
     const int swz = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const int tiles_n = g.ncols_pad / BN;
@@ -305,6 +314,7 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
     const char *pb0 = ldsb + A_BYTES + b_base, *pb1 = pb0 + BBUF;
 #ifdef ACG_STAMP
     unsigned long long st_wait = 0, st_work = 0, st_t = __builtin_amdgcn_s_memtime();
+    tl_loop0 = st_t;
 #endif
     bool done = false;
     if (kdim == 3 && S % 6 == 0) {
@@ -342,6 +352,7 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
     }
     __builtin_amdgcn_s_setprio(0);
 #ifdef ACG_STAMP
+    tl_loop1 = __builtin_amdgcn_s_memtime();
     if (lane == 0 && blockIdx.x < 8192) {
         g_pre_stamps[(blockIdx.x * 8 + wave) * 3] = st_wait;
         g_pre_stamps[(blockIdx.x * 8 + wave) * 3 + 1] = st_work + (__builtin_amdgcn_s_memtime() - st_t);
@@ -353,23 +364,175 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
     // and leaves in coalesced rows.  ALL EIGHT waves share its rows: a workgroup's tile time is loop + epilogue (the other
     // workgroup of the CU only fills the matrix pipe meanwhile), and the epilogue is a chain of load round trips — with 512
     // threads a thread has half the rows, i.e. half the round trips.
+#ifdef ACG_STAMP
+#define TILE_STAMP_END()                                                                                              \
+    if (tid == 0 && blockIdx.x < 8192) {                                                                              \
+        const unsigned long long te_ = __builtin_amdgcn_s_memtime();                                                  \
+        g_pre_tile[blockIdx.x * 4] = tl_loop0 - tl_entry; g_pre_tile[blockIdx.x * 4 + 1] = tl_loop1 - tl_loop0;       \
+        g_pre_tile[blockIdx.x * 4 + 2] = te_ - tl_loop1; g_pre_tile[blockIdx.x * 4 + 3] = tl_real;                    \
+    }
+#else
+#define TILE_STAMP_END()
+#endif
     constexpr int TS = BN; // row stride (floats)
     constexpr int ET = 512; // threads of the output loops
     static_assert(BM * TS * 4 <= LDS_BYTES, "the staged tile must fit the LDS buffers");
     float *tile = (float *)lds;
+    // fp32 side inputs of a data-gradient tile (skip gradient + its sign bitmask; the input and the activation mask of the
+    // norm whose backward sums leave with the tile): item u of a thread = row (tid >> 5) + 16 u, channels 4 cq .. 4 cq + 3.
+    // They do not depend on the tile, so ALL of a thread's side loads are issued in one go as early as its registers are free:
+    // by the producer waves right behind their last DMA wait — in flight while the consumers run the last stage and stage
+    // their accumulators — and by the consumer waves as soon as the accumulators are in LDS: one memory round trip per tile
+    // instead of two dependent ones (the side streams are 2 x 268 MB per launch at batch 32: what they cost is latency the
+    // other workgroup of the CU cannot hide, not bandwidth).  The two roles run two COPIES of this epilogue (side_epilogue
+    // below) — joined in one region, the compiler keeps the producers' prefetched values live across the consumers'
+    // accumulator staging and spills — and pass its barriers as raw s_barrier: __syncthreads() would drain the vector-memory
+    // queue, i.e. the prefetch, in front of every barrier.
+    // (data-gradient instantiations only: the forward kernels keep their registers)
+    const bool side32 = !REFLECT && !STATS && !g.out_s16 && (SUMS || g.addend != nullptr);
+    auto stage_tile = [&]() {   // consumer waves: accumulator + bias, activation -> LDS
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cl = wn * TN + j * 16 + lr;
+            const float bv = (bias != nullptr && n0 + cl < g.Cout) ? bias[n0 + cl] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    tile[(wm * TM + i * 16 + 4 * pl + r) * TS + cl] = acg_apply_act(acc[i][j][r] + bv, STATS ? (int)ACG_ACT_NONE : g.act);
+        }
+    };
+    auto lds_barrier = [&]() { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); };   // lgkmcnt(0) only
+    auto side_epilogue = [&](auto early_c) {
+        constexpr bool EARLY = decltype(early_c)::value;   // producer waves: loads first, then the barriers
+        constexpr int NI = BM * (BN / 4) / ET;   // 8
+        const int cq = tid & 31;
+        // (launches with side inputs are bounded to 4 GiB tensors by the launcher: 32-bit offsets into buffer resources; a
+        // null side pointer gives a resource of zero records, whose loads return zeros — as do lanes masked to offset ~0)
+        const unsigned tb = 0xFFFFFFF0u;
+        const __amdgpu_buffer_rsrc_t r_add = __builtin_amdgcn_make_buffer_rsrc((void *)g.addend, 0, g.addend != nullptr ? tb : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_am = __builtin_amdgcn_make_buffer_rsrc((void *)g.addend_mask, 0, g.addend_mask != nullptr ? tb : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc((void *)g.ns_x, 0, (SUMS && g.ns_x != nullptr) ? tb : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_nm = __builtin_amdgcn_make_buffer_rsrc((void *)g.ns_mask, 0, (SUMS && g.ns_mask != nullptr) ? tb : 0u, 0x00020000);
+        auto side_off = [&](unsigned p) { return (p & 0x7fffffffu) * 16u + (unsigned)(n0 + cq * 4) * 4u; };
+        unsigned s_aw[NI], s_nw[NI];   // mask WORDS (the nibble is picked where it is used, as are the rows' output offsets)
+        f32x4 s_av[NI], s_xv[NI];
+        // un-padded reflect data gradient: the mirrored pad columns land on pixels 1 and W-2 (threads 0 .. 255: consumer
+        // waves).  Its load goes FIRST: vmcnt counts in order, so waiting for a load issued behind the side loads would
+        // wait for all of them in front of the barrier.
+        const int cf_grow = m0 / g.GW, cf_x0 = m0 - cf_grow * g.GW;
+        const int cf_sd = tid >> 7, cf_c = tid & (BN - 1), cf_row = cf_sd == 0 ? 1 - cf_x0 : g.GW - 2 - cf_x0;
+        const bool cf_on = !EARLY && g.colfix != nullptr && tid < 256 && (unsigned)cf_row < (unsigned)BM && n0 + cf_c < g.Cout;
+        float cf = 0.f;
+        if (!EARLY) {
+            __syncthreads();   // every consumer wave is done with the last LDS buffer, every DMA piece has landed
+            stage_tile();      // ... and the accumulators' registers are free
+            if (cf_on) cf = g.colfix[((size_t)cf_grow * 2 + cf_sd) * g.Cout + n0 + cf_c];
+        }
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const unsigned po = pix_off[(tid >> 5) + (ET / 32) * u];
+            const bool sd = po != NO_PIX && (po >> 31);
+            const unsigned bo = side_off(po);
+            const unsigned mo = acg_masked_off((bo >> 7) << 2, sd);   // float index bo / 4, word index / 32, byte offset * 4
+            s_av[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_add, acg_masked_off(bo, sd), 0, 0));
+            if (SUMS) s_xv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_x, acg_masked_off(bo, sd), 0, 0));
+            s_aw[u] = __builtin_amdgcn_raw_buffer_load_b32(r_am, mo, 0, 0);
+            if (SUMS) s_nw[u] = __builtin_amdgcn_raw_buffer_load_b32(r_nm, mo, 0, 0);
+        }
+        if (EARLY) __builtin_amdgcn_s_barrier();   // (the consumers' __syncthreads above)
+        lds_barrier();                             // the tile is staged
+        if (g.colfix != nullptr) {
+            if (cf_on) tile[cf_row * TS + cf_c] += cf;
+            lds_barrier();
+        }
+        // Geom.ns_part: the tile is one 128-pixel chunk of the gradient w.r.t. a norm's output, and its share of that norm's
+        // backward sums (norm.hip norm_bwd_partial: gy = dy * act'(y), S1 = sum gy, S2 = sum gy * xhat) leaves with it: the
+        // norm's input rides along as one more side stream (same addresses as the output), a thread sums its 8 rows of 4
+        // channels in registers (rows in ascending order: the sums of the two-batch loop this replaces, bit for bit) and
+        // the 16 row groups meet in LDS behind the loop.
+        char *const base0 = (char *)out, *const base1 = (char *)g.out2;
+        constexpr bool sums = SUMS;
+        const bool remask = sums && g.ns_act != ACG_ACT_NONE && g.ns_mask == nullptr;
+        const int img = m0 / GHW;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, mu = s1, rs = s1;
+        const bool cok = n0 + cq * 4 < g.Cout;
+        if (sums && cok) {
+            mu = *(const f32x4 *)(g.ns_mean + (size_t)img * g.Cout + n0 + cq * 4);
+            rs = *(const f32x4 *)(g.ns_rstd + (size_t)img * g.Cout + n0 + cq * 4);
+        }
+        // (trimmed for instruction count — with 16 waves on the CU the loop is issue-bound, not latency-bound: masks as
+        // sign-extended one-bit fields ANDed onto the value, the un-padded grid's stores through a buffer resource with the
+        // 32-bit offset the loads used)
+        const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc((void *)g.out2, 0, tb, 0x00020000);
+        const unsigned cq4 = (unsigned)(n0 >> 2) + (unsigned)cq;
+        const bool add_on = g.addend != nullptr, act_on = g.ns_act != ACG_ACT_NONE;
+        const unsigned all_add = g.addend_mask == nullptr ? 15u : 0u;
+        auto keep = [](float val, unsigned word, int bit) {   // val where bit `bit` of word is set, else +0
+            const int m = __builtin_amdgcn_sbfe((int)word, bit, 1);   // 0 or -1
+            return __builtin_bit_cast(float, __builtin_bit_cast(int, val) & m);
+        };
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int row = (tid >> 5) + (ET / 32) * u;   // idx = tid + ET u: row idx / 32, channel group idx % 32 = cq
+            const unsigned po = pix_off[row];
+            f32x4 v = *(const f32x4 *)&tile[row * TS + cq * 4];
+            const bool sd = po != NO_PIX && (po >> 31), live = po != NO_PIX && cok;
+            const int sh = 4 * (int)(((po & 0x7fffffffu) + cq4) & 7u);   // these 4 elements' nibble of the mask words
+            if (sd && add_on) {
+                const unsigned nb = (s_aw[u] >> sh) | all_add;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] += keep(s_av[u][q], nb, q);
+            }
+            if (live) {
+                if (g.unpad) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, side_off(po), 0, 0);
+                else *(f32x4 *)(((po >> 31) ? base1 : base0) + (size_t)side_off(po)) = v;
+            }
+            if (sums && live) {
+                f32x4 gy = v;
+                const f32x4 xh = (s_xv[u] - mu) * rs;
+                if (remask) {   // no stored sign bitmask (rare): the mask from the norm's own expression (norm_apply_kernel);
+                    // scale and shift are fetched per item — cache hits — instead of held across the loop
+                    const f32x4 ga = *(const f32x4 *)(g.ns_gamma + (size_t)img * g.ns_gstride + n0 + cq * 4);
+                    const f32x4 be = *(const f32x4 *)(g.ns_beta + (size_t)img * g.ns_gstride + n0 + cq * 4);
+                    const f32x4 yy = xh * ga + be;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) gy[q] = yy[q] > 0.f ? gy[q] : 0.f;
+                } else if (act_on) {
+                    const unsigned nm = s_nw[u] >> sh;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) gy[q] = keep(gy[q], nm, q);
+                }
+                s1 += gy;
+                s2 += gy * xh;
+            }
+        }
+        if (sums) { // thread (cq, tid >> 5) holds rows (tid >> 5) + 16 j of channels 4 cq .. 4 cq + 3
+            __syncthreads(); // every thread is done reading the staged tile: its LDS becomes the scratch [2][16 row groups][BN]
+            constexpr int RG = ET / 32;
+            float *sc = (float *)lds;
+            const int rg = tid >> 5;
+            *(f32x4 *)&sc[(0 * RG + rg) * BN + cq * 4] = s1;
+            *(f32x4 *)&sc[(1 * RG + rg) * BN + cq * 4] = s2;
+            __syncthreads();
+            if (tid < 64) {
+                const int k = tid >> 5, cc = tid & 31, chunk = (m0 - img * GHW) / BM;
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < RG; ++r) a += *(const f32x4 *)&sc[(k * RG + r) * BN + cc * 4];
+                if (n0 + cc * 4 < g.Cout)
+                    *(f32x4 *)(g.ns_part + ((size_t)(img * (GHW / BM) + chunk) * 2 + k) * g.Cout + n0 + cc * 4) = a;
+            }
+        }
+    };
+    if (side32) {   // (wave-uniform)
+        if (wave >= 4) side_epilogue(std::integral_constant<bool, true>{});
+        else side_epilogue(std::integral_constant<bool, false>{});
+        TILE_STAMP_END()
+        return;
+    }
     __syncthreads(); // every consumer wave is done with the last LDS buffer, every DMA piece has landed
-    if (wave < 4) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int cl = wn * TN + j * 16 + lr;
-        const float bv = (bias != nullptr && n0 + cl < g.Cout) ? bias[n0 + cl] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                tile[(wm * TM + i * 16 + 4 * pl + r) * TS + cl] = acg_apply_act(acc[i][j][r] + bv, STATS ? (int)ACG_ACT_NONE : g.act);
-    }
-    }
+    if (wave < 4) stage_tile();
     __syncthreads();
     if (g.colfix != nullptr) { // un-padded reflect data gradient: the mirrored pad columns land on pixels 1 and W-2
         const int grow = m0 / g.GW, x0c = m0 - grow * g.GW;
@@ -468,9 +631,10 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
             *(acg_u32x4 *)dst = hi;
             *(acg_u32x4 *)(dst + 16) = lo;
         }
+        TILE_STAMP_END()
         return;
     }
-    if (g.addend == nullptr && g.relu_src == nullptr && !SUMS) {
+    {
 #pragma unroll 4
         for (int k = 0; k < BM * (BN / 4) / ET; ++k) { // 8 float4 per thread, consecutive lanes on consecutive channels
             const int idx = tid + ET * k, row = idx / (BN / 4), c4 = idx - row * (BN / 4);
@@ -478,103 +642,10 @@ igemm_conv_x3_pre(const char *__restrict__ in, const __bf16 *__restrict__ wp, co
             if (po != NO_PIX && n0 + c4 * 4 < g.Cout)
                 *(f32x4 *)(((po >> 31) ? base1 : base0) + (size_t)(po & 0x7fffffffu) * 16 + (size_t)(n0 + c4 * 4) * 4) = *(const f32x4 *)&tile[row * TS + c4 * 4];
         }
-        return;
     }
-    // Data-gradient epilogue with fp32 side inputs (skip gradient and its sign bitmask; fp32 ReLU source): four rows at a
-    // time, every side load issued before the first is used; rows without a side input read a dummy address instead of
-    // branching (conv_x3.hip).
-    // Geom.ns_part: the tile is one 128-pixel chunk of the gradient w.r.t. a norm's output, and its share of that norm's
-    // backward sums (norm.hip norm_bwd_partial: gy = dy * act'(y), S1 = sum gy, S2 = sum gy * xhat) leaves with it: the
-    // norm's input rides along as one more side stream (same addresses as the output), a thread sums its 16 rows of 4
-    // channels in registers and the 8 row groups meet in LDS behind the loop.
-    const char *dummy = in;
-    const unsigned *amask = g.addend_mask != nullptr ? g.addend_mask : (const unsigned *)in;
-    constexpr bool sums = SUMS;
-    const unsigned *nmask = sums && g.ns_mask != nullptr ? g.ns_mask : (const unsigned *)in;
-    const bool remask = sums && g.ns_act != ACG_ACT_NONE && g.ns_mask == nullptr;
-    const int cq = tid & 31, img = m0 / GHW;
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, mu = s1, rs = s1, ga = s1, be = s1;
-    if (sums && n0 + cq * 4 < g.Cout) {
-        mu = *(const f32x4 *)(g.ns_mean + (size_t)img * g.Cout + n0 + cq * 4);
-        rs = *(const f32x4 *)(g.ns_rstd + (size_t)img * g.Cout + n0 + cq * 4);
-        if (remask) {
-            ga = *(const f32x4 *)(g.ns_gamma + (size_t)img * g.ns_gstride + n0 + cq * 4);
-            be = *(const f32x4 *)(g.ns_beta + (size_t)img * g.ns_gstride + n0 + cq * 4);
-        }
-    }
-    constexpr int EB = 4;
-#pragma unroll 1
-    for (int kb = 0; kb < BM * (BN / 4) / ET; kb += EB) {
-        unsigned po[EB], nb[EB];   // nb: the addend's mask nibble | the norm mask's nibble << 4
-        f32x4 v[EB], mv[EB], av[EB], xv[EB];
-        // (byte offsets and flags are recomputed from po where they are used: kept in arrays they cost the registers that
-        // separate this kernel from spilling)
-        // (SUMS launches are bounded to 4 GiB tensors by the launcher: 32-bit offsets there)
-        typedef typename std::conditional<SUMS, unsigned, size_t>::type off_t;
-        auto boff = [&](unsigned p) { return (off_t)(p & 0x7fffffffu) * 16 + (off_t)(n0 + cq * 4) * 4; };
-#pragma unroll
-        for (int u = 0; u < EB; ++u) {
-            const int row = (tid >> 5) + (ET / 32) * (kb + u);   // idx = tid + ET (kb + u): row idx / 32, channel group idx % 32 = cq
-            po[u] = pix_off[row];
-            v[u] = *(const f32x4 *)&tile[row * TS + cq * 4];
-        }
-#pragma unroll
-        for (int u = 0; u < EB; ++u) {
-            const bool sd = po[u] != NO_PIX && (po[u] >> 31);
-            const bool hm = sd && g.relu_src != nullptr, ha = sd && g.addend != nullptr, hx = sd && sums;
-            const off_t bo = boff(po[u]);
-            mv[u] = *(const f32x4 *)(hm ? (const char *)g.relu_src + bo : dummy);
-            av[u] = *(const f32x4 *)(ha ? (const char *)g.addend + bo : dummy);
-            xv[u] = *(const f32x4 *)(hx ? (const char *)g.ns_x + bo : dummy);
-            const off_t f = ha ? bo >> 4 : 0;   // float4 index of these 4 elements
-            nb[u] = (amask[f >> 3] >> (4 * (int)(f & 7))) & 15u;
-            const off_t fx = hx ? bo >> 4 : 0;
-            nb[u] |= ((nmask[fx >> 3] >> (4 * (int)(fx & 7))) & 15u) << 4;
-        }
-#pragma unroll
-        for (int u = 0; u < EB; ++u) {
-            const bool sd = po[u] != NO_PIX && (po[u] >> 31), live = po[u] != NO_PIX && n0 + cq * 4 < g.Cout;
-            if (sd && g.relu_src != nullptr) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[u][q] = mv[u][q] > 0.f ? v[u][q] : 0.f;
-            }
-            if (sd && g.addend != nullptr) {
-                if (g.addend_mask == nullptr) nb[u] |= 15u;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[u][q] += (nb[u] >> q) & 1u ? av[u][q] : 0.f;
-            }
-            if (live) *(f32x4 *)(((po[u] >> 31) ? base1 : base0) + boff(po[u])) = v[u];
-            if (sums && live) {
-                f32x4 gy = v[u];
-                const f32x4 xh = (xv[u] - mu) * rs;
-                if (g.ns_act != ACG_ACT_NONE) {
-                    const f32x4 yy = xh * ga + be; // same expression as norm_apply_kernel: its sign is the mask
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) gy[q] = (remask ? yy[q] > 0.f : ((nb[u] >> (4 + q)) & 1u) != 0u) ? gy[q] : 0.f;
-                }
-                s1 += gy;
-                s2 += gy * xh;
-            }
-        }
-    }
-    if (sums) { // thread (cq, tid >> 5) holds rows (tid >> 5) + 16 j of channels 4 cq .. 4 cq + 3
-        __syncthreads(); // every thread is done reading the staged tile: its LDS becomes the scratch [2][16 row groups][BN]
-        constexpr int RG = ET / 32;
-        float *sc = (float *)lds;
-        const int rg = tid >> 5;
-        *(f32x4 *)&sc[(0 * RG + rg) * BN + cq * 4] = s1;
-        *(f32x4 *)&sc[(1 * RG + rg) * BN + cq * 4] = s2;
-        __syncthreads();
-        if (tid < 64) {
-            const int k = tid >> 5, cc = tid & 31, chunk = (m0 - img * GHW) / BM;
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < RG; ++r) a += *(const f32x4 *)&sc[(k * RG + r) * BN + cc * 4];
-            if (n0 + cc * 4 < g.Cout)
-                *(f32x4 *)(g.ns_part + ((size_t)(img * (GHW / BM) + chunk) * 2 + k) * g.Cout + n0 + cc * 4) = a;
-        }
-    }
+    TILE_STAMP_END()
 }
+#undef TILE_STAMP_END
 
 // Row-patch geometry the pre-split kernel needs: K x K tap lists in kernel-row order (forward: dx ascending, stride-1 data
 // gradient: descending) whose patch fills exactly the eleven 1 KB pieces per parity image the kernel issues.
@@ -622,11 +693,12 @@ int acg_igemm_x3_pre_launch(const void *in, const void *wp, const float *bias, f
     ACG_REQUIRE(stats == nullptr || (((long long)g.GH * g.GW) % BM == 0 && g.act == ACG_ACT_NONE && !g.out_s16),
                 "igemm_conv_x3_pre: per-tile statistics need whole 128-pixel tiles per image, no activation, fp32 output");
     ACG_REQUIRE(!g.out_s16 || (g.addend == nullptr && g.Cout % 8 == 0), "igemm_conv_x3_pre: pre-split output takes no addend");
-    ACG_REQUIRE(g.relu_src == nullptr || g.fold_p > 0 || g.unpad, "igemm_conv_x3_pre: the ReLU source needs the frame path");
+    ACG_REQUIRE(g.relu_src == nullptr || ((g.fold_p > 0 || g.unpad) && g.out_s16), "igemm_conv_x3_pre: the ReLU source needs the frame path and pre-split output");
     ACG_REQUIRE((g.mask_out == nullptr && g.relu_mask == nullptr) || (g.out_s16 && g.Cout % 32 == 0 && g.ncols_pad == g.Cout && g.fold_p == 0 &&
                                                                         (g.relu_mask == nullptr || (g.unpad && g.relu_src == nullptr))),
                 "igemm_conv_x3_pre: sign bitmasks go with pre-split output, 32-multiple channels and the un-padded grid");
-    ACG_REQUIRE(g.ns_part == nullptr || out_bytes < (1LL << 32), "igemm_conv_x3_pre: norm sums on a tensor of 4 GiB or more");
+    ACG_REQUIRE((g.ns_part == nullptr && (g.addend == nullptr || g.out_s16)) || out_bytes < (1LL << 32),
+                "igemm_conv_x3_pre: side inputs (skip addend / norm sums) on a tensor of 4 GiB or more");
     ACG_REQUIRE(g.ns_part == nullptr || (g.unpad && !g.out_s16 && g.Cout % 4 == 0 && (g.ns_act == ACG_ACT_NONE || g.ns_act == ACG_ACT_RELU) &&
                                        g.ns_x != nullptr && g.ns_mean != nullptr && g.ns_rstd != nullptr &&
                                        (g.ns_act == ACG_ACT_NONE || g.ns_mask != nullptr || (g.ns_gamma != nullptr && g.ns_beta != nullptr))),

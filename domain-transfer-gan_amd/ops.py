@@ -212,9 +212,10 @@ class ConvTimer(object):
         def done(self):
             if self.timers:
                 self.e1.record()
+                k = _lib.query("acg_last_kernel").decode()   # what the dispatcher actually launched
                 for t in self.timers:
-                    t.events.append((self.e0, self.e1))
-                    t.kernel = _lib.query("acg_last_kernel").decode()   # what the dispatcher actually launched
+                    t.events.append((self.e0, self.e1, k))
+                    t.kernel = k
 
     @staticmethod
     def span(kind, d):
@@ -222,7 +223,14 @@ class ConvTimer(object):
         return ConvTimer._Span([t for t in CONV_TIMERS if t.kind == kind and t.match(d)])
 
     def ms(self):
-        return [a.elapsed_time(b) for a, b in self.events]
+        return [a.elapsed_time(b) for a, b, _ in self.events]
+
+    def by_kernel(self):
+        """-> {kernel label: [ms per launch]} (one pass of one layer can be served by several template instances)"""
+        out = {}
+        for a, b, k in self.events:
+            out.setdefault(k, []).append(a.elapsed_time(b))
+        return out
 
 
 CONV_TIMERS = []   # bench.py appends ConvTimer objects; every matching forward launch is bracketed by HIP events

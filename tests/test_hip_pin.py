@@ -17,9 +17,11 @@ NORM-WISE in both arithmetics: the trunk holds five ReLU layers of 2 M units eac
 rounding of zero (2^-17 relative in bf16x3, 2^-24 in f32 against the fp64 oracle) lands on the other side of its ReLU and
 changes the gradient discretely in that unit's receptive field — a flipped fraction p moves the gradient by ~sqrt(p)
 norm-wise (p ~ 1e-5 -> 3e-3) whatever the kernels do, while an indexing or fusion error shows at the 1e-1 level.  bf16x3:
-the parameter gradients of the two blocks 5e-3 (tests/test_hip_nets.py's bar; measured <= 3e-3), the gradients that pass
-all five ReLU layers — the input's and the stem's parameters' — 1e-2 (measured 3.2e-3 .. 5.2e-3); f32: 1e-3 / 5e-4
-(measured 1e-6 .. 2.3e-4: one flipped unit among 10 M shows as 3e-3 max-abs on the input gradient).
+1e-2 on every gradient (measured 3.0e-3 .. 5.2e-3: the same level on the input, the stem and the first block, i.e. set by
+the ReLU layers behind them, not by a kernel); f32: 1e-3 / 5e-4 (measured 1e-6 .. 2.3e-4: one flipped unit among 10 M shows
+as 3e-3 max-abs on the input gradient).  Because ReLU flips blur the end-to-end gradients, the LINEAR maps of the backward
+kernels are pinned separately and tightly below (test_presplit_kernels_at_bench_geometry_match_the_oracle: each C-ABI entry
+point against the oracle's adjoints with the masks given, 2e-5 / 1e-4).
 """
 import numpy as np
 import pytest
@@ -197,7 +199,7 @@ def test_trunk_at_bench_geometry_matches_the_oracle(kind, prec):
     assert e_gx < (1e-2 if x3 else 1e-3), e_gx
     if kind == "cin":
         e_gz = l2rel(n(zt.grad), ref["gz"])
-        assert e_gz < (5e-3 if x3 else 5e-4), e_gz
+        assert e_gz < (1e-2 if x3 else 5e-4), e_gz
     gmax = max(float(np.max(np.abs(g))) for g in ref["grads"].values())
     worst = 0.0
     for k, p in names.items():
@@ -205,8 +207,7 @@ def test_trunk_at_bench_geometry_matches_the_oracle(kind, prec):
         assert g.shape == go.shape, k
         # (a convolution bias in front of a norm has the exact gradient 0: both sides hold summation noise there, allowed
         # for by the absolute term tied to the largest gradient of the net)
-        # (the stem's parameters sit in front of all five ReLU layers, like the input: the input gradient's bar)
-        tol = (1e-2 if k.startswith("stem") else 5e-3) if x3 else 5e-4
+        tol = 1e-2 if x3 else 5e-4
         err = np.linalg.norm(g - go) / (np.linalg.norm(go) + 2e-5 * gmax * np.sqrt(go.size) / tol)
         assert err < tol, (k, err)
         worst = max(worst, err)
@@ -225,6 +226,107 @@ def test_trunk_at_bench_geometry_matches_the_oracle(kind, prec):
         assert used == (2 if kind == "plain" else 4), used
     else:
         assert not any(e.endswith("_s16") or "_s16_" in e for e in ents), ents
+
+
+def _pack(w, b, Cn):
+    from dtgan_amd import ops
+    from hip_util import t
+    return ops.PackedConv(t(w), t(b), Cn, Cn)
+
+
+def test_presplit_kernels_at_bench_geometry_match_the_oracle():
+    """Every pre-split (S16) entry point of the trunk layer at N = 1, 128 x 128 x 128 through the C ABI, against the oracle's
+    convolution and its adjoints in fp64 (oracle/ops.py conv2d: ReflectionPad2d(1) + 3x3, modules.py:205-227) with the masks,
+    the skip addend and the norm statistics GIVEN — linear maps, so the bars are the kernel bars of tests/test_hip_ops.py:
+    2e-5 (forward, data gradient), 1e-4 (long pixel sums: weight gradient, bias gradient, per-tile norm sums).  Operands are
+    what the step feeds these kernels: x = hi + lo of an fp32 tensor (decode(encode(.)) is what the oracle sees)."""
+    import ctypes
+    from dtgan_amd import ops, _lib
+    from hip_util import precision, t, n, rel
+    P, st = ops._ptr, None
+    N, H, W, Cn = 1, 128, 128, 128
+    rs = np.random.RandomState(5)
+    w = rs.normal(0, 0.05, (Cn, Cn, 3, 3)); b = rs.normal(0, 0.5, (Cn,))
+    x = np.maximum(rs.normal(0, 1, (N, Cn, H, W)), 0)          # a ReLU output
+    dy = rs.normal(0, 1e-3, (N, Cn, H, W))
+    skip = rs.normal(0, 1e-3, (N, Cn, H, W))
+    xn = rs.normal(0.3, 1.2, (N, Cn, H, W))                     # the input of the norm in front of the layer
+    skip_bits = rs.rand(N, Cn, H, W) > 0.4                      # sign bitmask of the block output the skip gradient passes
+    norm_bits = rs.rand(N, Cn, H, W) > 0.5                      # activation mask of the norm's output
+    nhwc = lambda a: np.ascontiguousarray(np.transpose(a, (0, 2, 3, 1)))
+    nchw = lambda a: np.transpose(a, (0, 3, 1, 2))
+
+    def bits(m):   # norm.hip layout: bit e % 32 of word e / 32 for NHWC float index e
+        f = nhwc(m).reshape(-1, 32).astype(np.int64)
+        v = (f << np.arange(32)).sum(1)
+        return torch.from_numpy(np.where(v >= 2 ** 31, v - 2 ** 32, v).astype(np.int32)).cuda()
+
+    with precision("bf16x3"):
+        st = ops._stream()
+        d = ops.conv_desc(N, H, W, Cn, Cn, 3, 1, 1, 1, Cn, Cn)
+        D = ctypes.byref(d)
+        assert _lib.query("acg_conv2d_s16_supported", D) and _lib.query("acg_conv2d_bwd_data_s16_sums_supported", D)
+        pk = _pack(w, b, Cn)
+
+        def enc(a):   # fp32 NHWC -> S16
+            y = torch.empty_like(a)
+            _lib.call("acg_s16_encode", P(a), P(y), a.numel(), st)
+            return y
+
+        def dec(a):
+            y = torch.empty_like(a)
+            _lib.call("acg_s16_decode", P(a), P(y), a.numel(), st)
+            return y
+        xs, dys = enc(t(nhwc(x))), enc(t(nhwc(dy)))
+        x_hl, dy_hl = nchw(n(dec(xs))).astype(np.float64), nchw(n(dec(dys))).astype(np.float64)   # what the kernels consume
+        assert rel(x_hl, x) < 1e-5 and rel(dy_hl, dy) < 1e-5
+        # ---- oracle: forward, and the adjoints for the gradient dy
+        X, Wt, Bt = leaf(x_hl), leaf(w), leaf(b)
+        yo = oops.conv2d(X, Wt, Bt, pad=1, pad_mode="reflect")
+        backward(yo, seed=dy_hl)
+        # ---- forward: fp32 out + per-tile statistics; conv + ReLU with pre-split output + sign bitmask
+        y = torch.empty((N, H, W, Cn), device="cuda")
+        part = torch.empty((N, H * W // 128, 2, Cn), device="cuda")
+        _lib.call("acg_conv2d_fwd_s16", D, P(xs), P(pk.wf), P(pk.bias), P(y), 0, P(part), 0, st)
+        assert _lib.query("acg_last_kernel").decode().startswith("igemm_conv_x3_pre<REFLECT=1,STATS=1")
+        assert rel(nchw(n(y)), yo.v) < 2e-5, "forward"
+        yt = nhwc(yo.v).reshape(N, H * W // 128, 128, Cn)
+        assert rel(n(part)[:, :, 0], yt.mean(2)) < 1e-5 and rel(n(part)[:, :, 1], ((yt - yt.mean(2, keepdims=True)) ** 2).sum(2)) < 1e-4, "tile statistics"
+        y2 = torch.empty_like(y)
+        mk = torch.zeros((y.numel() + 31) // 32, device="cuda", dtype=torch.int32)
+        _lib.call("acg_conv2d_fwd_s16_mask", D, P(xs), P(pk.wf), P(pk.bias), P(y2), P(mk), st)
+        assert rel(nchw(n(dec(y2))), np.maximum(yo.v, 0)) < 2e-5, "conv + ReLU, pre-split output"
+        # (the sign of an output within rounding of zero is the kernel's own: compare the bits where |y| is not tiny)
+        got = ((n(mk).astype(np.int64)[:, None] >> np.arange(32)) & 1).reshape(N, H, W, Cn).astype(bool)
+        sure = np.abs(nhwc(yo.v)) > 1e-4 * np.abs(yo.v).max()
+        assert np.array_equal(got[sure], (nhwc(yo.v) > 0)[sure]), "sign bitmask of the conv + ReLU output"
+        # ---- data gradient (un-padded grid + column-term kernel): fp32 out with the masked skip addend and the norm sums
+        nbw = _lib.query("acg_conv2d_bwd_data_workspace_bytes", D)
+        ws = ops.workspace(max(nbw, _lib.query("acg_conv2d_bwd_weight_workspace_bytes", D), 1))
+        dx = torch.empty_like(y)
+        mean = rs.normal(0.3, 0.1, (N, Cn)); rstd = rs.uniform(0.5, 1.5, (N, Cn))
+        psum = torch.empty((N, H * W // 128, 2, Cn), device="cuda")
+        ns = _lib.NormSumsDesc()
+        xn_t, mean_t, rstd_t, nb_t, sb_t, skip_t = t(nhwc(xn)), t(mean.reshape(-1)), t(rstd.reshape(-1)), bits(norm_bits), bits(skip_bits), t(nhwc(skip))
+        ns.x, ns.mean, ns.rstd, ns.gamma, ns.beta, ns.gstride = P(xn_t), P(mean_t), P(rstd_t), None, None, 0
+        ns.sign_mask, ns.act, ns.part = P(nb_t), ops.ACT_RELU, P(psum)
+        _lib.call("acg_conv2d_bwd_data_s16_sums", D, P(dys), P(pk.wb), P(dx), P(ws), nbw, P(skip_t), P(sb_t), ctypes.byref(ns), st)
+        assert "SUMS=1" in _lib.query("acg_last_kernel").decode()
+        dx_o = X.g + skip * skip_bits
+        assert rel(nchw(n(dx)), dx_o) < 2e-5, "data gradient + masked skip addend"
+        gy = nhwc(dx_o * norm_bits).reshape(N, H * W // 128, 128, Cn)
+        xh = nhwc((xn.astype(np.float32).astype(np.float64) - mean[:, :, None, None]) * rstd[:, :, None, None]).reshape(N, H * W // 128, 128, Cn)
+        assert rel(n(psum)[:, :, 0], gy.sum(2)) < 1e-4 and rel(n(psum)[:, :, 1], (gy * xh).sum(2)) < 1e-4, "norm backward sums"
+        # ---- data gradient with pre-split output masked by the sign bitmask of the layer's own input (conv + ReLU in front)
+        dxs = torch.empty_like(y)
+        _lib.call("acg_conv2d_bwd_data_s16_mask", D, P(dys), P(pk.wb), P(dxs), P(ws), nbw, P(bits(x > 0)), st)
+        assert rel(nchw(n(dec(dxs))), X.g * (x > 0)) < 2e-5, "data gradient masked by the ReLU bitmask, pre-split output"
+        # ---- weight gradient (kernel rows, pre-split operands)
+        dw, db = torch.empty((Cn, Cn, 3, 3), device="cuda"), torch.empty(Cn, device="cuda")
+        _lib.call("acg_conv2d_bwd_weight_s16", D, P(xs), P(dys), P(dw), P(db), Cn, Cn, P(ws),
+                  _lib.query("acg_conv2d_bwd_weight_workspace_bytes", D), 0, st)
+        assert _lib.query("acg_last_kernel").decode() == "wgrad_x3_krow_s16"
+        assert rel(n(dw), Wt.g) < 1e-4 and rel(n(db), Bt.g) < 1e-4, "weight / bias gradient"
 
 
 # ---------------------------------------------------------------------------------------------------------------------
