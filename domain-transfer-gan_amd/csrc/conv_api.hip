@@ -255,11 +255,14 @@ static int thin_out_launch(const float *in, const float *wn, const float *bias, 
     return ACG_OK;
 }
 
-extern "C" size_t acg_packed_wf_elems(int K, int Ci, int Co) { return (size_t)K * K * (Ci / 8) * acg_ncols_pad(Co) * 8; }
+// Packed weights are laid out on channel counts padded to 16 whatever the stored width of the activation tensors: an image
+// tensor (<= 4 real channels) may be stored with 4 channels ("C4", acg_conv_desc), its layer's weights are packed as before.
+static inline int c16(int c) { return (c + 15) / 16 * 16; }
+extern "C" size_t acg_packed_wf_elems(int K, int Ci, int Co) { return (size_t)K * K * (c16(Ci) / 8) * acg_ncols_pad(c16(Co)) * 8; }
 // K == 3: three more slabs behind the nine taps, 9 + kw = w[0][kw] + w[2][kw] (bf16 packings only): what the kernel row that
 // reads a mirrored row uses in the un-padded data gradient of a reflection-padded layer (Geom.unpad)
 static inline int wb_slabs(int K) { return K * K + (K == 3 ? 3 : 0); }
-extern "C" size_t acg_packed_wb_elems(int K, int Ci, int Co) { return (size_t)wb_slabs(K) * (Co / 8) * acg_ncols_pad(Ci) * 8; }
+extern "C" size_t acg_packed_wb_elems(int K, int Ci, int Co) { return (size_t)wb_slabs(K) * (c16(Co) / 8) * acg_ncols_pad(c16(Ci)) * 8; }
 
 extern "C" int acg_pack_conv_weight(const float *w, int Or, int Ir, int K, int Ci, int Co, float *wf, float *wb,
                                     void *stream)
@@ -538,6 +541,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
 // naive direct kernels (cross-check path, ACG_IMPL_DIRECT): one thread per output element,
 // geometry taken straight from the descriptor (independent of the tap-list machinery).
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int c16d(int c) { return (c + 15) / 16 * 16; }   // packed-weight channel count of a stored width
 __device__ __forceinline__ int reflect_idx(int i, int n)
 {
     i = i < 0 ? -i : i;
@@ -567,7 +571,7 @@ __global__ void direct_fwd_kernel(acg_conv_desc d, const float *__restrict__ x, 
             const float *xp = x + (((long long)n * d.Hi + iy) * d.Wi + ix) * d.Ci;
             const int tap = kh * d.K + kw;
             for (int ci = 0; ci < d.Ci; ++ci)
-                acc += xp[ci] * wf[(((long long)tap * (d.Ci / 8) + ci / 8) * CoP + co) * 8 + (ci & 7)];
+                acc += xp[ci] * wf[(((long long)tap * (c16d(d.Ci) / 8) + ci / 8) * CoP + co) * 8 + (ci & 7)];
         }
     y[i] = acg_apply_act(acc, act);
 }
@@ -607,7 +611,7 @@ __global__ void direct_dgrad_kernel(acg_conv_desc d, const float *__restrict__ d
                     const float *gp = dy + (((long long)n * d.Ho + oy) * d.Wo + ox) * d.Co;
                     const int tap = kh * d.K + kw;
                     for (int co = 0; co < d.Co; ++co)
-                        acc += gp[co] * wb[(((long long)tap * (d.Co / 8) + co / 8) * CiP + ci) * 8 + (co & 7)];
+                        acc += gp[co] * wb[(((long long)tap * (c16d(d.Co) / 8) + co / 8) * CiP + ci) * 8 + (co & 7)];
                 }
     dx[i] = acg_apply_act(acc, act);
 }
@@ -648,8 +652,14 @@ static int check_desc(const acg_conv_desc *d, const char *who)
 {
     ACG_REQUIRE(d != nullptr, "%s: null descriptor", who);
     ACG_REQUIRE(d->N > 0 && d->Hi > 0 && d->Wi > 0 && d->Ho > 0 && d->Wo > 0, "%s: empty tensor", who);
-    ACG_REQUIRE(d->Ci % 16 == 0 && d->Co % 16 == 0 && d->Ci > 0 && d->Co > 0,
-                "%s: channels must be padded to 16 (Ci=%d Co=%d)", who, d->Ci, d->Co);
+    // stored channel counts: multiples of 16, or 4 for a tensor of <= 4 real channels on the thin side of a thin layer (K > 1,
+    // the other side wider: what thin_in / thin_out select) — every other kernel gathers 16-channel chunks
+    ACG_REQUIRE(d->Ci > 0 && d->Co > 0 && (d->Ci % 16 == 0 || d->Ci == 4) && (d->Co % 16 == 0 || d->Co == 4),
+                "%s: channels must be padded to 16, or to 4 for image tensors (Ci=%d Co=%d)", who, d->Ci, d->Co);
+    ACG_REQUIRE(d->Ci != 4 || (d->Cir >= 1 && d->Cir <= 4 && d->K > 1 && !(d->Cor >= 1 && d->Cor <= 4)),
+                "%s: a 4-channel input needs a thin-input layer (Cir=%d Cor=%d K=%d)", who, d->Cir, d->Cor, d->K);
+    ACG_REQUIRE(d->Co != 4 || (d->Cor >= 1 && d->Cor <= 4 && d->K > 1 && !(d->Cir >= 1 && d->Cir <= 4)),
+                "%s: a 4-channel output needs a thin-output layer (Cir=%d Cor=%d K=%d)", who, d->Cir, d->Cor, d->K);
     ACG_REQUIRE(d->K >= 1 && d->K <= 7 && (d->stride == 1 || d->stride == 2), "%s: K=%d stride=%d unsupported", who,
                 d->K, d->stride);
     ACG_REQUIRE(d->pad >= 0 && d->pad < d->K, "%s: pad=%d", who, d->pad);

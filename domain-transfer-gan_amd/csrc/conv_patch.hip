@@ -104,11 +104,12 @@ __global__ __launch_bounds__(256) void conv_patch16_x3(const float *__restrict__
     }
 }
 
-// eligibility: bf16x3, 32 gathered channels, 16 stored output channels, unit strides, tap window <= 7x7
+// eligibility: bf16x3, 32 gathered channels, 16 (or, for an image tensor stored C4, 4) stored output channels, unit strides,
+// tap window <= 7x7
 bool acg_conv_patch16_ok(const Geom &g, const Taps &t)
 {
     if (g_acg_precision != ACG_PREC_BF16X3 || g_acg_conv_impl != ACG_IMPL_MFMA || g.thin || g.fold_p) return false;
-    if (g.Cin != 32 || g.Cout != 16 || g.os != 1 || g.is != 1 || g.oy0 != 0 || g.ox0 != 0 || t.n < 1) return false;
+    if (g.Cin != 32 || (g.Cout != 16 && g.Cout != 4) || g.os != 1 || g.is != 1 || g.oy0 != 0 || g.ox0 != 0 || t.n < 1) return false;
     int ymin = t.dy[0], ymax = t.dy[0], xmin = t.dx[0], xmax = t.dx[0];
     for (int i = 1; i < t.n; ++i) {
         ymin = t.dy[i] < ymin ? t.dy[i] : ymin; ymax = t.dy[i] > ymax ? t.dy[i] : ymax;

@@ -478,7 +478,7 @@ class StochCycleGAN(_Base):
             f.check()
         if self.ignore_noise:
             prior_z_B = prior_z_B.mul(0.).add(1.)                                               # model.py:128-129
-        A, B, z = ops.ToNHWC.apply(real_A), ops.ToNHWC.apply(real_B), as_latent(prior_z_B)
+        A, B, z = ops.ToNHWC.apply(real_A, True), ops.ToNHWC.apply(real_B, True), as_latent(prior_z_B)
         fake_B = self.netG_A_B.forward_nhwc(A, z)
         fake_A = self.netG_B_A.forward_nhwc(B)
 
@@ -654,7 +654,7 @@ class AugmentedCycleGAN(_Base):
         flats_D = [self.f_D_A, self.f_D_B, self.f_D_z_B]
         for f in flats_D + [self.f_G_A_B, self.f_G_B_A, self.f_E_B]:
             f.check()
-        A, B, z = ops.ToNHWC.apply(real_A), ops.ToNHWC.apply(real_B), as_latent(prior_z_B)
+        A, B, z = ops.ToNHWC.apply(real_A, True), ops.ToNHWC.apply(real_B, True), as_latent(prior_z_B)
         bs = z.shape[0]
 
         fake_B = self.netG_A_B.forward_nhwc(A, z)                                               # model.py:404
@@ -759,7 +759,7 @@ class AugmentedCycleGAN(_Base):
     def _supervised_train_instance(self, real_A, real_B, prior_z_B):
         o = self.opt
         nA, nB, nl = o.input_nc, o.output_nc, o.nlatent
-        A, B, z = ops.ToNHWC.apply(real_A), ops.ToNHWC.apply(real_B), as_latent(prior_z_B)
+        A, B, z = ops.ToNHWC.apply(real_A, True), ops.ToNHWC.apply(real_B, True), as_latent(prior_z_B)
         bs = z.shape[0]
         mu, logvar = self._encode(A, B)
         if o.stoch_enc:

@@ -79,6 +79,7 @@ class Conv2d(nn.Conv2d, _Cached):
             pad, mode = reflect_pad, PAD_REFLECT
         else:
             pad, mode = self.padding[0], PAD_ZERO
+        x = restore_width(x, self.packed().Cis)
         out = ops.Conv2dFn.apply(x, self.weight, self.bias, self.packed(), self.stride[0], pad, mode, act, want_stats,
                                  want_identity, link_out, link_in, skip_grad, s16, norm_sums)
         if s16 is not None and s16.x:   # tag what left the convolution pre-split: its output (conv + ReLU) and the alias of x
@@ -89,7 +90,18 @@ class Conv2d(nn.Conv2d, _Cached):
         return out
 
     def forward(self, input):
-        return ops.ToNCHW.apply(self.forward_nhwc(ops.ToNHWC.apply(input)), self.out_channels)
+        return ops.ToNCHW.apply(self.forward_nhwc(ops.ToNHWC.apply(input, True)), self.out_channels)
+
+
+def restore_width(x, C):
+    """An image tensor stored C4 (ops.cimg) that reaches a layer which is not its thin-channel consumer (a 1x1 or a
+    3 -> 3 convolution, a ConvTranspose2d, a norm: none of them on the networks' path) is widened to C16 with zero
+    channels — and a C16 tensor of <= 4 real channels in front of a thin-input layer narrowed — by plain torch ops."""
+    if x.shape[-1] == C:
+        return x
+    if x.shape[-1] < C:
+        return torch.nn.functional.pad(x, (0, C - x.shape[-1]))
+    return x[..., :C].contiguous()
 
 
 class ConvTranspose2d(nn.ConvTranspose2d, _Cached):
@@ -100,6 +112,7 @@ class ConvTranspose2d(nn.ConvTranspose2d, _Cached):
         return self._cached(lambda: ops.PackedConv(self.weight, self.bias, cpad(self.out_channels), cpad(self.in_channels)))
 
     def forward_nhwc(self, x, act=ACT_NONE, want_stats=None):
+        x = restore_width(x, cpad(self.in_channels))
         return ops.ConvTranspose2dFn.apply(x, self.weight, self.bias, self.packed(), self.stride[0], self.padding[0],
                                            self.output_padding[0], act, want_stats)
 
@@ -113,6 +126,8 @@ class _BatchNormMixin(_Cached):
         return self._cached(lambda: (_padded_vec(self.weight, C), _padded_vec(self.bias, C)))
 
     def forward_act(self, x, act=ACT_NONE):
+        if self._pad16:
+            x = restore_width(x, cpad(self.num_features))
         C = x.shape[-1]
         g, b = self._gb()
         if not self.training:  # eval mode: normalise with the running buffers (model.eval(), train.py:258)
@@ -192,9 +207,18 @@ class TwoInputSequential(nn.Sequential, TwoInputModule):
         super(TwoInputSequential, self).__init__(*args)
 
     def forward(self, input1, input2):
-        x = ops.ToNHWC.apply(input1)
+        x = ops.ToNHWC.apply(input1, _starts_with_conv(self))
         y, C = run_sequence(list(self._modules.values()), x, input1.shape[1], cond_bank(self, as_latent(input2)))
         return ops.ToNCHW.apply(y, C)
+
+
+def _starts_with_conv(seq):
+    """does the layer list take its input straight into a Conv2d (then an image input may be stored C4, ops.cimg)?"""
+    for m in seq._modules.values():
+        if isinstance(m, nn.ReflectionPad2d):
+            continue
+        return isinstance(m, Conv2d) or (isinstance(m, MergeModule) and isinstance(m.module1, Conv2d))
+    return False
 
 
 def as_latent(z):
@@ -231,6 +255,7 @@ class InstanceNorm(nn.Module, _Cached):
         return torch.ones(C, device=dev), torch.zeros(C, device=dev)
 
     def forward_act(self, x, act=ACT_NONE, res=None, lazy_dres=None, stats=None, s16_out=False, s16_dx=False, sums=None):
+        x = restore_width(x, cpad(self.num_features))
         g, b = self._gb()
         y = ops.NormAct.apply(x, self.scale, self.shift, res, "in", act, self.eps, g, b, None, None, 0.0, lazy_dres, stats,
                               s16_out, s16_dx, res is not None and ops.is_s16(res), sums)
@@ -257,6 +282,7 @@ class CondInstanceNorm(TwoInputModule):
         self.scale_conv = nn.Sequential(Conv2d(z_dim, x_dim, kernel_size=1, padding=0, bias=True), nn.ReLU(True))
 
     def forward_act(self, x, z, act=ACT_NONE, stats=None, s16_out=False, s16_dx=False, sums=None):
+        x = restore_width(x, cpad(self.x_dim))
         Cp = x.shape[-1]
         bank = getattr(z, "_acg_bank", None)   # every scale / shift of the generator computed in one launch (cond_bank)
         if bank is not None and id(self) in bank and bank[id(self)][0].shape == (x.shape[0], Cp):
@@ -549,7 +575,7 @@ class Sequential(nn.Sequential):
     def forward(self, input):
         if input.dim() == 2:
             return run_dense(list(self._modules.values()), input)
-        x = ops.ToNHWC.apply(input)
+        x = ops.ToNHWC.apply(input, _starts_with_conv(self))
         y, C = run_sequence(list(self._modules.values()), x, input.shape[1])
         return ops.ToNCHW.apply(y, C)
 

@@ -303,5 +303,5 @@ class LatentEncoder(nn.Module):
         return ops.SpatialMean.apply(self.enc_mu.forward_nhwc(h)), ops.SpatialMean.apply(self.enc_logvar.forward_nhwc(h))
 
     def forward(self, input):
-        mu, logvar = self.forward_nhwc(ops.ToNHWC.apply(input))
+        mu, logvar = self.forward_nhwc(ops.ToNHWC.apply(input, True))
         return mu[:, :self.nlatent], logvar[:, :self.nlatent]

@@ -19,8 +19,22 @@ _VP = ctypes.c_void_p
 
 
 def cpad(c):
-    """stored channel count for `c` real channels"""
+    """stored channel count for `c` real channels (feature maps, latents: multiples of 16)"""
     return (int(c) + 15) // 16 * 16
+
+
+def cimg(c):
+    """stored channel count of an IMAGE tensor (network inputs / outputs, their gradients): 4 for up to 4 real channels
+    ("C4": one 16-byte load per pixel instead of a 64-byte row that is three quarters padding), else as cpad.  Only the thin
+    side of a thin convolution layer reads or writes such a tensor (conv_thin_sides); everything else sees multiples of 16."""
+    return 4 if int(c) <= 4 else cpad(c)
+
+
+def conv_thin_sides(Or, Ir, K):
+    """-> (input may be stored C4, output is stored C4) for a Conv2d of real widths Ir -> Or: the library's thin-channel
+    kernels (K flattened over (tap, 4 channels)) take the thin side of a layer with K > 1 whose other side is wider"""
+    ti, to = 1 <= Ir <= 4, 1 <= Or <= 4
+    return (ti and not to and K > 1), (to and not ti and K > 1)
 
 
 def _ptr(t):
@@ -96,13 +110,15 @@ class ToNHWC(torch.autograd.Function):
     """(N,C,H,W) -> (N,H,W,Cp)"""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, img=False):
+        """img: the tensor is an image that goes into a convolution (cimg: C4 storage for <= 4 channels)"""
         x = x.contiguous()
         _check(x)
         N, C, H, W = x.shape
         ctx.C = C
-        y = torch.empty((N, H, W, cpad(C)), device=x.device, dtype=torch.float32)
-        _lib.call("acg_nchw_to_nhwc16", _ptr(x), _ptr(y), N, C, H, W, cpad(C), _stream())
+        Cp = cimg(C) if img else cpad(C)
+        y = torch.empty((N, H, W, Cp), device=x.device, dtype=torch.float32)
+        _lib.call("acg_nchw_to_nhwc16", _ptr(x), _ptr(y), N, C, H, W, Cp, _stream())
         return y
 
     @staticmethod
@@ -111,7 +127,7 @@ class ToNHWC(torch.autograd.Function):
         N, H, W, Cp = g.shape
         d = torch.empty((N, ctx.C, H, W), device=g.device, dtype=torch.float32)
         _lib.call("acg_nhwc16_to_nchw", _ptr(g), _ptr(d), N, ctx.C, H, W, Cp, _stream())
-        return d
+        return d, None
 
 
 class ToNCHW(torch.autograd.Function):
@@ -145,7 +161,7 @@ class Concat(torch.autograd.Function):
         _check(a, b)
         N, H, W, Cap = a.shape
         Cbp = b.shape[3]
-        Cdp = cpad(Ca + Cb)
+        Cdp = cimg(Ca + Cb)   # (an image again: the encoder's first layer takes it)
         ctx.dims = (Ca, Cap, Cb, Cbp, Cdp)
         y = torch.empty((N, H, W, Cdp), device=a.device, dtype=torch.float32)
         _lib.call("acg_concat_channels", _ptr(a), Ca, Cap, _ptr(b), Cb, Cbp, _ptr(y), Cdp, N * H * W, _stream())
@@ -171,7 +187,10 @@ class PackedConv(object):
 
     def __init__(self, weight, bias, Ci, Co):
         Or, Ir, K, _ = weight.shape
-        self.Or, self.Ir, self.K, self.Ci, self.Co = Or, Ir, K, Ci, Co
+        self.Or, self.Ir, self.K, self.Ci, self.Co = Or, Ir, K, Ci, Co   # Ci / Co: the PACKED widths (multiples of 16)
+        # stored widths of the layer's input / output tensors: C4 on the thin side of a thin layer (image tensors)
+        tin, tout = conv_thin_sides(Or, Ir, K)
+        self.Cis, self.Cos = (4 if tin else Ci), (4 if tout else Co)
         dev = weight.device
         self.wf = torch.empty(_lib.query("acg_packed_wf_elems", K, Ci, Co), device=dev, dtype=torch.float32)
         self.wb = torch.empty(_lib.query("acg_packed_wb_elems", K, Ci, Co), device=dev, dtype=torch.float32)
@@ -441,12 +460,12 @@ class Conv2dFn(torch.autograd.Function):
         x = x.contiguous()
         _check(x)
         N, Hi, Wi, Ci = x.shape
-        if Ci != packed.Ci:
-            raise _lib.AcgError("conv: input has %d stored channels, weight packed for %d" % (Ci, packed.Ci))
-        d = conv_desc(N, Hi, Wi, Ci, packed.Co, packed.K, stride, pad, pad_mode, packed.Ir, packed.Or)
+        if Ci != packed.Cis:
+            raise _lib.AcgError("conv: input has %d stored channels, the layer takes %d" % (Ci, packed.Cis))
+        d = conv_desc(N, Hi, Wi, Ci, packed.Cos, packed.K, stride, pad, pad_mode, packed.Ir, packed.Or)
         if d.Ho <= 0 or d.Wo <= 0:
             raise _lib.AcgError("conv: input %dx%d too small for kernel %d" % (Hi, Wi, packed.K))
-        y = torch.empty((N, d.Ho, d.Wo, packed.Co), device=x.device, dtype=torch.float32)
+        y = torch.empty((N, d.Ho, d.Wo, packed.Cos), device=x.device, dtype=torch.float32)
         span = ConvTimer.span("fwd", d)
         if s16 is not None and s16.x:   # pre-split input (and, for a conv + ReLU inside the trunk, output)
             part = None
