@@ -142,7 +142,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 112   # include/acgan_hip.h ACG_VERSION this binding was written against
+ABI_VERSION = 113   # include/acgan_hip.h ACG_VERSION this binding was written against
 
 
 class AcgError(RuntimeError):

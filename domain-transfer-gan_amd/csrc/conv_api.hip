@@ -258,11 +258,40 @@ static int thin_out_launch(const float *in, const float *wn, const float *bias, 
 // Packed weights are laid out on channel counts padded to 16 whatever the stored width of the activation tensors: an image
 // tensor (<= 4 real channels) may be stored with 4 channels ("C4", acg_conv_desc), its layer's weights are packed as before.
 static inline int c16(int c) { return (c + 15) / 16 * 16; }
-extern "C" size_t acg_packed_wf_elems(int K, int Ci, int Co) { return (size_t)K * K * (c16(Ci) / 8) * acg_ncols_pad(c16(Co)) * 8; }
+// The thin-OUTPUT layers with 32 gathered channels (7x7 32 -> nc head, data gradient of the nc -> 32 stem) carry a second,
+// "N-packed" weight form behind the regular one (conv_patch.hip conv_patchn_x3): K rows x (K + 3) window columns of 1 KB
+// hi + 1 KB lo, where the 16 MFMA columns are (4 horizontally adjacent output pixels) x (4 channels).
+static inline size_t npack_elems(int K) { return (size_t)K * (K + 3) * 512; }   // floats
+static inline bool npack_wf(int K, int Ci, int Co) { return K > 1 && K <= 7 && c16(Co) == 16 && c16(Ci) == 32; }   // thin-out forward
+static inline bool npack_wb(int K, int Ci, int Co) { return K > 1 && K <= 7 && c16(Ci) == 16 && c16(Co) == 32; }   // thin-in data gradient
+static size_t wf_regular_elems(int K, int Ci, int Co) { return (size_t)K * K * (c16(Ci) / 8) * acg_ncols_pad(c16(Co)) * 8; }
+extern "C" size_t acg_packed_wf_elems(int K, int Ci, int Co) { return wf_regular_elems(K, Ci, Co) + (npack_wf(K, Ci, Co) ? npack_elems(K) : 0); }
 // K == 3: three more slabs behind the nine taps, 9 + kw = w[0][kw] + w[2][kw] (bf16 packings only): what the kernel row that
 // reads a mirrored row uses in the un-padded data gradient of a reflection-padded layer (Geom.unpad)
 static inline int wb_slabs(int K) { return K * K + (K == 3 ? 3 : 0); }
-extern "C" size_t acg_packed_wb_elems(int K, int Ci, int Co) { return (size_t)wb_slabs(K) * (c16(Co) / 8) * acg_ncols_pad(c16(Ci)) * 8; }
+static size_t wb_regular_elems(int K, int Ci, int Co) { return (size_t)wb_slabs(K) * (c16(Co) / 8) * acg_ncols_pad(c16(Ci)) * 8; }
+extern "C" size_t acg_packed_wb_elems(int K, int Ci, int Co) { return wb_regular_elems(K, Ci, Co) + (npack_wb(K, Ci, Co) ? npack_elems(K) : 0); }
+
+// N-packed weights: out[hi | lo][(ry * (K + 3) + u)][kg (4)][col (16)][8]: k = 8 kg + j is the gathered channel, col = 4 dxo + c
+// the output pixel offset dxo and channel c.  mode 0 (forward of a thin-output layer): k = input channel, c = output channel,
+// value w[c][k][ry][u - dxo]; mode 1 (data gradient of a thin-input layer): k = output channel, c = input channel, the
+// window walks the flipped kernel: value w[k][c][K-1-ry][K-1-(u - dxo)].  Zero where u - dxo falls outside the kernel.
+__global__ void pack_weight_npack_kernel(const float *__restrict__ w, int Or, int Ir, int K, int mode, __bf16 *__restrict__ out)
+{
+    const int KU = K + 3, total = K * KU * 512;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int j = i & 7, col = (i >> 3) & 15, kg = (i >> 7) & 3, slab = i >> 9;
+        const int ry = slab / KU, u = slab - ry * KU, dxo = col >> 2, c = col & 3, k = kg * 8 + j, kw = u - dxo;
+        float v = 0.f;
+        if (kw >= 0 && kw < K) {
+            if (mode == 0) { if (c < Or && k < Ir) v = w[(((long long)c * Ir + k) * K + ry) * K + kw]; }
+            else           { if (k < Or && c < Ir) v = w[(((long long)k * Ir + c) * K + (K - 1 - ry)) * K + (K - 1 - kw)]; }
+        }
+        const __bf16 hi = (__bf16)v;
+        out[i] = hi;
+        out[total + i] = (__bf16)(v - (float)hi);
+    }
+}
 
 extern "C" int acg_pack_conv_weight(const float *w, int Or, int Ir, int K, int Ci, int Co, float *wf, float *wb,
                                     void *stream)
@@ -290,10 +319,14 @@ extern "C" int acg_pack_conv_weight(const float *w, int Or, int Ir, int K, int C
             if (wf) hipLaunchKernelGGL(pack_weight_thin_kernel, dim3(64), dim3(256), 0, st, w, Or, Ir, K * K, acg_ncols_pad(Co), 0, wf);
             if (wb && thin_valu_c(Co)) hipLaunchKernelGGL(pack_weight_thinN_kernel, dim3(64), dim3(256), 0, st, w, Or, Ir, K * K, Co, 1, wb);
             else if (wb) regular(nullptr, wb);
+            if (wb && npack_wb(K, Ci, Co) && g_acg_precision == ACG_PREC_BF16X3 && use_bf16())
+                hipLaunchKernelGGL(pack_weight_npack_kernel, dim3(64), dim3(256), 0, st, w, Or, Ir, K, 1, (__bf16 *)(wb + wb_regular_elems(K, Ci, Co)));
         } else {
             if (wf && thin_valu_c(Ci)) hipLaunchKernelGGL(pack_weight_thinN_kernel, dim3(64), dim3(256), 0, st, w, Or, Ir, K * K, Ci, 0, wf);
             else if (wf) regular(wf, nullptr);
             if (wb) hipLaunchKernelGGL(pack_weight_thin_kernel, dim3(64), dim3(256), 0, st, w, Or, Ir, K * K, acg_ncols_pad(Ci), 1, wb);
+            if (wf && npack_wf(K, Ci, Co) && g_acg_precision == ACG_PREC_BF16X3 && use_bf16())
+                hipLaunchKernelGGL(pack_weight_npack_kernel, dim3(64), dim3(256), 0, st, w, Or, Ir, K, 0, (__bf16 *)(wf + wf_regular_elems(K, Ci, Co)));
         }
         ACG_CHECK_LAUNCH("pack_weight_thin_kernel");
         return ACG_OK;
@@ -679,7 +712,7 @@ static void fwd_geom(const acg_conv_desc *d, Geom *g, Taps *t, int act)
     g->reflect = d->pad_mode == ACG_PAD_REFLECT; g->act = act; g->ncols_pad = acg_ncols_pad(d->Co);
     g->Mtot = (long long)d->N * d->Ho * d->Wo;
     g->thin = thin_in(d) ? 1 : 0;
-    g->w_elems = (long long)acg_packed_wf_elems(d->K, d->Ci, d->Co);
+    g->w_elems = (long long)wf_regular_elems(d->K, d->Ci, d->Co);
     t->n = 0;
     for (int kh = 0; kh < d->K; ++kh)
         for (int kw = 0; kw < d->K; ++kw) {
@@ -784,7 +817,7 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
     g.Hin = d->Ho; g.Win = d->Wo; g.Cin = d->Co;
     g.Cout = d->Ci; g.reflect = 0; g.act = act; g.ncols_pad = acg_ncols_pad(d->Ci); g.is = 1;
     g.thin = (d->stride == 1 && thin_out(d)) ? 1 : 0;
-    g.w_elems = (long long)acg_packed_wb_elems(d->K, d->Ci, d->Co);
+    g.w_elems = (long long)wb_regular_elems(d->K, d->Ci, d->Co);
     const int p = d->pad, K = d->K;
     if (d->stride == 1) {
         const bool refl = d->pad_mode == ACG_PAD_REFLECT && p > 0;

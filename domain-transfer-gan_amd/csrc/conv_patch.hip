@@ -41,25 +41,35 @@ __global__ __launch_bounds__(256) void conv_patch16_x3(const float *__restrict__
     // lanes take consecutive pixels of one 8-channel plane (conflict-free 16-byte LDS stores)
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, in_bytes, 0x00020000);
     const int npp = PH * PW;
-    for (int i = tid; i < 4 * PT_PIX; i += 256) {
+    constexpr int NIT = 4 * PT_PIX / 256;   // 5 (plane, pixel) items per thread: all ten loads in flight before the first split
+    static_assert(4 * PT_PIX % 256 == 0, "patch items per thread");
+    f32x4 plo[NIT], phi[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + 256 * it;
         const int u = i / PT_PIX, pp = i - u * PT_PIX; // plane, patch pixel
-        if (pp >= npp) continue;
         const int py = pp / PW, px = pp - py * PW;
         int iy = gy0 + py + dymin, ix = gx0 + px + dxmin;
-        bool ok = true;
+        bool ok = pp < npp;
         if (REFLECT) {
-            ok = iy > -g.Hin && iy < 2 * g.Hin - 1 && ix > -g.Win && ix < 2 * g.Win - 1; // pixels of partial tiles
+            ok = ok && iy > -g.Hin && iy < 2 * g.Hin - 1 && ix > -g.Win && ix < 2 * g.Win - 1; // pixels of partial tiles
             iy = iy < 0 ? -iy : iy;
             iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
             ix = ix < 0 ? -ix : ix;
             ix = ix >= g.Win ? 2 * (g.Win - 1) - ix : ix;
         } else {
-            ok = (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+            ok = ok && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
         }
         const unsigned off = (unsigned)(((n * g.Hin + iy) * g.Win + ix) * g.Cin + 8 * u) * 4u;
-        const f32x4 lo4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off, ok), 0, 0));
-        const f32x4 hi4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off + 16u, ok), 0, 0));
-        const float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+        plo[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off, ok), 0, 0));
+        phi[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off + 16u, ok), 0, 0));
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + 256 * it;
+        const int u = i / PT_PIX, pp = i - u * PT_PIX;
+        if (pp >= npp) continue;
+        const float v[8] = {plo[it][0], plo[it][1], plo[it][2], plo[it][3], phi[it][0], phi[it][1], phi[it][2], phi[it][3]};
         acg_u32x4 hi, lo;
         acg_split8(v, hi, lo);
         *(acg_u32x4 *)&Ap[u * PT_PLANE + pp * 8] = hi;
@@ -73,21 +83,48 @@ __global__ __launch_bounds__(256) void conv_patch16_x3(const float *__restrict__
     // B fragment of a tap: packed [tap][Cin/16][ncols_pad][16] -> column lr, k = 8*pl .. 8*pl+7 of the 32 channels
     const long long boff = ((long long)(pl >> 1) * g.ncols_pad + lr) * 16 + (pl & 1) * 8;
     const long long tap_stride = (long long)(g.Cin / 16) * g.ncols_pad * 16;
-    for (int t = 0; t < taps.n; ++t) {
-        const int pk = taps.pk[t];
-        const int dy = ((pk << 24) >> 24) - dymin, dx = ((pk << 16) >> 24) - dxmin, tw = pk >> 16;
+    // The weights of a tap are 2 x 16 bytes per lane straight from L1 / L2, and nothing else in the loop waits on memory: loaded
+    // inside the tap's own iteration (with the tap entry fetched by a scalar load in front of them) every tap paid two memory
+    // round trips for six MFMAs — 22 VGPRs, the matrix pipe ~12 % busy per wave.  Now the tap table sits in a VGPR (lane t =
+    // tap t, read with v_readlane: no memory access in the loop) and the B fragments run PF taps ahead of their MFMAs.
+    constexpr int PF = 7;   // a 7x7 window is seven whole groups
+    const int tap_v = taps.pk[lane < taps.n ? lane : 0];
+    bf16x8 bh[PF], bl[PF];
+    auto bload = [&](int t, bf16x8 &h, bf16x8 &l) {   // (a tap index past the end loads tap 0 again: never used)
+        const int tw = __builtin_amdgcn_readlane(tap_v, t < taps.n ? t : 0) >> 16;
         const __bf16 *wt = wp + tw * tap_stride + boff;
-        const bf16x8 bh = *(const bf16x8 *)wt;
-        const bf16x8 bl = *(const bf16x8 *)(wt + w_lo_elems);
+        h = *(const bf16x8 *)wt;
+        l = *(const bf16x8 *)(wt + w_lo_elems);
+    };
+    auto tap_mma = [&](int t, const bf16x8 &ch, const bf16x8 &cl) {
+        const int pk = __builtin_amdgcn_readlane(tap_v, t);
+        const int dy = ((pk << 24) >> 24) - dymin, dx = ((pk << 16) >> 24) - dxmin;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int pp = (wave * 2 + r + dy) * PW + dx + lr;
             const bf16x8 ah = *(const bf16x8 *)&Ap[pl * PT_PLANE + pp * 8];
             const bf16x8 al = *(const bf16x8 *)&Ap[PT_IMG + pl * PT_PLANE + pp * 8];
-            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[r], 0, 0, 0);
-            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[r], 0, 0, 0);
-            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[r], 0, 0, 0);
+            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ch, acc[r], 0, 0, 0);
+            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, cl, acc[r], 0, 0, 0);
+            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ch, acc[r], 0, 0, 0);
         }
+    };
+    const int nfull = taps.n / PF * PF;
+    if (nfull > 0) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) bload(j, bh[j], bl[j]);
+    }
+    for (int t0 = 0; t0 < nfull; t0 += PF) {   // whole groups: no branch in the body, every slot reloaded unconditionally
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            tap_mma(t0 + j, bh[j], bl[j]);
+            bload(t0 + j + PF, bh[j], bl[j]);   // this slot's next tap, PF taps ahead, into the registers the MFMAs just read
+        }
+    }
+    for (int t = nfull; t < taps.n; ++t) {   // the taps of a window that is not a multiple of PF
+        bf16x8 ch, cl;
+        bload(t, ch, cl);
+        tap_mma(t, ch, cl);
     }
 
     // ---- epilogue: lane l holds column l&15 of pixels 4*(l>>4) .. +3 of its rows
@@ -102,6 +139,185 @@ __global__ __launch_bounds__(256) void conv_patch16_x3(const float *__restrict__
                 out[(((long long)n * g.Hout + gy) * g.Wout + gx) * g.Cout + lr] = acg_apply_act(acc[r][k] + bv, g.act);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same layers with the image tensor stored C4 (Geom.Cout == 4) and "N-packed" weights: the 16 MFMA columns are
+// (4 horizontally adjacent output pixels) x (4 channels) instead of 16 channels of which 13 are padding.  A row of the MFMA
+// tile is then a BASE pixel that stands for output pixels 4 b .. 4 b + 3 of its row, and K runs over the window positions
+// (ry, u), u = dxo + kw in 0 .. KW + 2: K = KH (KW + 3) 32-channel steps per 64 output pixels (a 4 x 4 block of base
+// pixels = 4 rows x 16 pixels) instead of KH KW per 16 — 2.8x fewer MFMAs, fragment reads and weight loads per output
+// pixel for a 7x7 (the kernel is bound by those loads: 2 KB of B fragments per tap and wave through the CU's one
+// vector-memory pipe).  The B operand of step (ry, u) holds w[ry][u - dxo] in column (dxo, c), zero outside the kernel
+// (pack_weight_npack_kernel, conv_api.hip).  A workgroup owns the 8 x 16 output tile of conv_patch16_x3 = two such blocks;
+// its four waves split the K steps (step s -> wave s % 4) and fold their partial blocks through LDS, so every B fragment
+// is loaded once per workgroup.
+template <bool REFLECT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_patchn_x3(const float *__restrict__ in, const __bf16 *__restrict__ wn,
+                                                      const float *__restrict__ bias, float *__restrict__ out, Geom g,
+                                                      int dymin, int dxmin, int KH, int KW, unsigned in_bytes)
+{
+    __shared__ __attribute__((aligned(16))) __bf16 Ap[2 * PT_IMG]; // [hi|lo][plane][pixel][8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (g.GW + PT_TW - 1) / PT_TW, tiles_y = (g.GH + PT_TH - 1) / PT_TH;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int n = b / tiles_y;
+    const int gy0 = ty * PT_TH, gx0 = tx * PT_TW;
+    const int PH = PT_TH + KH - 1, PW = PT_TW + KW - 1;
+
+    // ---- the patch, as in conv_patch16_x3
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, in_bytes, 0x00020000);
+    const int npp = PH * PW;
+    constexpr int NIT = 4 * PT_PIX / 256;
+    f32x4 plo[NIT], phi[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + 256 * it;
+        const int u = i / PT_PIX, pp = i - u * PT_PIX; // plane, patch pixel
+        const int py = pp / PW, px = pp - py * PW;
+        int iy = gy0 + py + dymin, ix = gx0 + px + dxmin;
+        bool ok = pp < npp;
+        if (REFLECT) {
+            ok = ok && iy > -g.Hin && iy < 2 * g.Hin - 1 && ix > -g.Win && ix < 2 * g.Win - 1; // pixels of partial tiles
+            iy = iy < 0 ? -iy : iy;
+            iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
+            ix = ix < 0 ? -ix : ix;
+            ix = ix >= g.Win ? 2 * (g.Win - 1) - ix : ix;
+        } else {
+            ok = ok && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+        }
+        const unsigned off = (unsigned)(((n * g.Hin + iy) * g.Win + ix) * g.Cin + 8 * u) * 4u;
+        plo[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off, ok), 0, 0));
+        phi[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off + 16u, ok), 0, 0));
+    }
+    // this wave's B fragments (steps wave, wave + 4, ...: at most NSW of them), PF steps ahead of their MFMAs (all 18 in
+    // registers cost the kernel half its occupancy): the first PF are on their way while the patch is split.  Lane l reads
+    // bytes 16 l .. 16 l + 15 of a step's 1 KB hi / lo block — its column l & 15, channels 8 (l >> 4) ..
+    const int KU = KW + 3, S = KH * KU;
+    constexpr int NSW = (7 * 10 + 3) / 4, PF = 6;   // 18 steps per wave at most
+    bf16x8 bh[PF], bl[PF];
+    auto bload = [&](int k, bf16x8 &h, bf16x8 &l) {   // step wave + 4 k (past the end: the last step again, unused)
+        int s = wave + 4 * k;
+        s = s < S ? s : S - 1;
+        h = *(const bf16x8 *)(wn + (long long)s * 512 + lane * 8);
+        l = *(const bf16x8 *)(wn + (long long)(S + s) * 512 + lane * 8);
+    };
+#pragma unroll
+    for (int k = 0; k < PF; ++k) bload(k, bh[k], bl[k]);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + 256 * it;
+        const int u = i / PT_PIX, pp = i - u * PT_PIX;
+        if (pp >= npp) continue;
+        const float v[8] = {plo[it][0], plo[it][1], plo[it][2], plo[it][3], phi[it][0], phi[it][1], phi[it][2], phi[it][3]};
+        acg_u32x4 hi, lo;
+        acg_split8(v, hi, lo);
+        *(acg_u32x4 *)&Ap[u * PT_PLANE + pp * 8] = hi;
+        *(acg_u32x4 *)&Ap[PT_IMG + u * PT_PLANE + pp * 8] = lo;
+    }
+    __syncthreads();
+
+    // ---- K steps: lane l: base pixel m = l & 15 of a block = row m >> 2, output pixels 4 (m & 3) .. + 3; channels 8 (l >> 4) ..
+    const int kg = lane >> 4, m = lane & 15, br = m >> 2, bc = m & 3;
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const int a0 = kg * PT_PLANE + (br * PW + 4 * bc) * 8;   // block 0, window position (0, 0)
+#pragma unroll
+    for (int k = 0; k < NSW; ++k) {
+        const int s = wave + 4 * k;
+        if (s < S) {   // (wave-uniform)
+            const int ry = s / KU, u = s - ry * KU;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int e = a0 + ((4 * mt + ry) * PW + u) * 8;
+                const bf16x8 ah = *(const bf16x8 *)&Ap[e];
+                const bf16x8 al = *(const bf16x8 *)&Ap[PT_IMG + e];
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[k % PF], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[k % PF], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[k % PF], acc[mt], 0, 0, 0);
+            }
+        }
+        if (k + PF < NSW) bload(k + PF, bh[k % PF], bl[k % PF]);   // into the registers the MFMAs just read
+    }
+    // ---- fold the four waves' partial blocks (fixed order: wave 0 + 1 + 2 + 3), then bias, activation and the C4 store:
+    // lane l holds column (dxo, c) = (l & 15) of base pixels (row l >> 4, b = register index)
+    __syncthreads();   // the patch is no longer read
+    float *red = (float *)Ap;   // [wave][block][reg][lane]
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave * 2 + mt) * 4 + r) * 64 + lane] = acc[mt][r];
+    __syncthreads();
+    if (wave < 2) {   // wave w finishes block w
+        const int mt = wave, c = lane & 3, dxo = (lane >> 2) & 3, q = lane >> 4;
+        const float bv = (bias != nullptr && c < g.Cout) ? bias[c] : 0.f;
+        const int gy = gy0 + 4 * mt + q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = red[((0 * 2 + mt) * 4 + r) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) v += red[((w * 2 + mt) * 4 + r) * 64 + lane];
+            const int gx = gx0 + 4 * r + dxo;
+            if (gy < g.GH && gx < g.GW)   // 16 consecutive lanes: 4 pixels x 4 channels = 64 contiguous bytes
+                out[(((long long)n * g.Hout + gy) * g.Wout + gx) * 4 + c] = acg_apply_act(v + bv, g.act);
+        }
+    }
+}
+
+// the taps of the launch are a full KH x KW window (any order: the N-packed weights are indexed by window position)
+static bool patchn_window(const Taps &t, int *ymin, int *xmin, int *KH, int *KW)
+{
+    int y0 = t.dy[0], y1 = t.dy[0], x0 = t.dx[0], x1 = t.dx[0];
+    for (int i = 1; i < t.n; ++i) {
+        y0 = t.dy[i] < y0 ? t.dy[i] : y0; y1 = t.dy[i] > y1 ? t.dy[i] : y1;
+        x0 = t.dx[i] < x0 ? t.dx[i] : x0; x1 = t.dx[i] > x1 ? t.dx[i] : x1;
+    }
+    const int kh = y1 - y0 + 1, kw = x1 - x0 + 1;
+    if (kh != kw || kh * kw != t.n || kh < 2 || kh > 7) return false;
+    unsigned long long seen = 0;
+    bool all_fwd = true, all_bwd = true;
+    for (int i = 0; i < t.n; ++i) {
+        const int pos = (t.dy[i] - y0) * kw + (t.dx[i] - x0);
+        if (seen >> pos & 1ull) return false;
+        seen |= 1ull << pos;
+        // the window position must be the kernel position the packing assumed (pack_weight_npack_kernel): a forward tap
+        // (kh, kw) = slab kh K + kw sits at window position (kh, kw), a data-gradient tap at (K-1-kh, K-1-kw)
+        const int skh = t.w[i] / kw, skw = t.w[i] - skh * kw;
+        all_fwd = all_fwd && skh == t.dy[i] - y0 && skw == t.dx[i] - x0;
+        all_bwd = all_bwd && skh == kh - 1 - (t.dy[i] - y0) && skw == kw - 1 - (t.dx[i] - x0);
+    }
+    if (!all_fwd && !all_bwd) return false;
+    *ymin = y0; *xmin = x0; *KH = kh; *KW = kw;
+    return true;
+}
+
+bool acg_conv_patchn_ok(const Geom &g, const Taps &t)
+{
+    static const bool off = acg_debug_switch("ACG_NO_PATCHN"); // A/B switch
+    if (off || g_acg_precision != ACG_PREC_BF16X3 || g_acg_conv_impl != ACG_IMPL_MFMA || g.thin || g.fold_p || g.stats) return false;
+    if (g.Cin != 32 || g.Cout != 4 || g.os != 1 || g.is != 1 || g.oy0 != 0 || g.ox0 != 0 || t.n < 4) return false;
+    int a, b, kh, kw;
+    if (!patchn_window(t, &a, &b, &kh, &kw)) return false;
+    return (PT_TH + kh - 1) * (PT_TW + kw - 1) <= PT_PIX && g.Hin >= 2 && g.Win >= 2;
+}
+
+// wn: the N-packed weights (behind the regular packed form: acg_packed_w{f,b}_elems)
+int acg_conv_patchn_launch(const float *in, const void *wn, const float *bias, float *out, const Geom &g, const Taps &t, hipStream_t st)
+{
+    int ymin, xmin, KH, KW;
+    ACG_REQUIRE(acg_conv_patchn_ok(g, t) && patchn_window(t, &ymin, &xmin, &KH, &KW), "conv_patchn_x3: unsupported geometry");
+    const long long nimg = g.Mtot / ((long long)g.GH * g.GW);
+    const long long in_bytes = nimg * g.Hin * g.Win * g.Cin * 4;
+    ACG_REQUIRE(in_bytes < (1LL << 32), "conv_patchn_x3: gathered tensor exceeds the 4 GiB buffer-addressing limit");
+    const long long blocks = nimg * ((g.GH + PT_TH - 1) / PT_TH) * ((g.GW + PT_TW - 1) / PT_TW);
+    if (g.reflect)
+        hipLaunchKernelGGL((conv_patchn_x3<true>), dim3((unsigned)blocks), dim3(256), 0, st, in, (const __bf16 *)wn, bias, out, g, ymin, xmin, KH, KW, (unsigned)in_bytes);
+    else
+        hipLaunchKernelGGL((conv_patchn_x3<false>), dim3((unsigned)blocks), dim3(256), 0, st, in, (const __bf16 *)wn, bias, out, g, ymin, xmin, KH, KW, (unsigned)in_bytes);
+    ACG_CHECK_LAUNCH("conv_patchn_x3");
+    acg_note_kernel("conv_patchn_x3<REFLECT=%d> (%dx%d window, %d K steps)", g.reflect ? 1 : 0, KH, KW, KH * (KW + 3));
+    return ACG_OK;
 }
 
 // eligibility: bf16x3, 32 gathered channels, 16 (or, for an image tensor stored C4, 4) stored output channels, unit strides,

@@ -14,8 +14,11 @@
  *  - return 0 on success, a negative acg_status otherwise; acg_last_error()
  *    returns a thread-local message for the last failure on this thread.
  *  - activations are fp32 NHWC with the channel count padded to a multiple of 16
- *    ("C16"); padded channels hold zeros.  Weights are passed in the packed forms
- *    produced by acg_pack_conv_weight().
+ *    ("C16"); padded channels hold zeros.  IMAGE tensors — up to 4 real channels: the
+ *    networks' inputs and outputs (networks.py:159-160, 187-188, 321, 365, 445), their
+ *    gradients, the PatchGAN maps — may be stored with 4 channels ("C4", 16 bytes per pixel)
+ *    where they are the thin side of a thin layer: see acg_conv_desc.  Weights are passed in
+ *    the packed forms produced by acg_pack_conv_weight().
  */
 #ifndef ACGAN_HIP_H
 #define ACGAN_HIP_H
@@ -27,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ACG_VERSION 112
+#define ACG_VERSION 113
 
 typedef enum {
     ACG_OK = 0,
@@ -43,7 +46,9 @@ typedef enum { ACG_IMPL_MFMA = 0, ACG_IMPL_DIRECT = 1 } acg_conv_impl;
 typedef enum { ACG_PREC_F32 = 0, ACG_PREC_BF16 = 1, ACG_PREC_BF16X3 = 2 } acg_precision;
 
 /* Geometry of one nn.Conv2d (or of the Conv2d whose adjoint an nn.ConvTranspose2d is).
- * Ci / Co are the STORED (padded-to-16) channel counts of the NHWC tensors. */
+ * Ci / Co are the STORED channel counts of the NHWC tensors: multiples of 16, or 4 for an image tensor (Cir resp. Cor <= 4)
+ * on the thin side of a layer with K > 1 whose other side is wider — the layers whose kernels gather / write 4 channels per
+ * pixel anyway.  Packed weights do not depend on it (acg_pack_conv_weight takes widths padded to 16). */
 typedef struct {
     int N, Hi, Wi, Ci;
     int Ho, Wo, Co;
@@ -88,7 +93,8 @@ int acg_split_channels(const float *gdst, int Cdp, float *ga, int Ca, int Cap, f
 /* ---- weights: OIHW (torch layout, real channel counts Or x Ir) -> packed, zero padded ----
  * wf: [K*K][Ci/8][CoP][8]  (B operand of forward / ConvTranspose-backward GEMMs)
  * wb: [K*K][Co/8][CiP][8]  (B operand of data-gradient / ConvTranspose-forward GEMMs)
- * CoP = acg_ncols_pad(Co), CiP = acg_ncols_pad(Ci).  Either output may be NULL. */
+ * CoP = acg_ncols_pad(Co), CiP = acg_ncols_pad(Ci); Ci / Co here are widths padded to 16.  Either output may be NULL.
+ * Size the buffers with acg_packed_w{f,b}_elems: some layers carry a second packed form behind the first. */
 int acg_ncols_pad(int c);
 size_t acg_packed_wf_elems(int K, int Ci, int Co);
 size_t acg_packed_wb_elems(int K, int Ci, int Co);

@@ -22,17 +22,17 @@ from dtgan_amd import _lib, ops  # noqa: E402
 # (transposed: the descriptor is the Conv2d whose adjoint the ConvTranspose2d is; H, W = its INPUT = the convT OUTPUT side)
 SHAPES = [
     ("resblock_3x3_128", 32, 128, 128, 128, 128, 3, 1, 1, 1, 128, 128, 0),
-    ("stem_7x7_3to32", 32, 256, 256, 16, 32, 7, 1, 3, 1, 3, 32, 0),
+    ("stem_7x7_3to32", 32, 256, 256, 4, 32, 7, 1, 3, 1, 3, 32, 0),
     ("a2_3x3_32to64", 32, 256, 256, 32, 64, 3, 1, 1, 0, 32, 64, 0),
     ("a3_3x3s2_64to128", 32, 256, 256, 64, 128, 3, 2, 1, 0, 64, 128, 0),
     ("a6_convT_128to64", 32, 256, 256, 64, 128, 3, 2, 1, 0, 64, 128, 1),
     ("a7_3x3_64to32", 32, 256, 256, 64, 32, 3, 1, 1, 0, 64, 32, 0),
-    ("a8_7x7_32to3", 32, 256, 256, 32, 16, 7, 1, 3, 0, 32, 3, 0),
+    ("a8_7x7_32to3", 32, 256, 256, 32, 4, 7, 1, 3, 0, 32, 3, 0),
     ("DB_4x4_128to256", 32, 64, 64, 128, 256, 4, 1, 1, 0, 128, 256, 0),
     ("DB_4x4_256to256", 32, 63, 63, 256, 256, 4, 1, 1, 0, 256, 256, 0),
-    ("DB_4x4s2_3to64", 32, 256, 256, 16, 64, 4, 2, 1, 0, 3, 64, 0),
+    ("DB_4x4s2_3to64", 32, 256, 256, 4, 64, 4, 2, 1, 0, 3, 64, 0),
     ("DB_4x4s2_64to128", 32, 128, 128, 64, 128, 4, 2, 1, 0, 64, 128, 0),
-    ("DB_head_4x4_256to1", 32, 62, 62, 256, 16, 4, 1, 1, 0, 256, 1, 0),
+    ("DB_head_4x4_256to1", 32, 62, 62, 256, 4, 4, 1, 1, 0, 256, 1, 0),
 ]
 
 
@@ -64,7 +64,7 @@ def main():
         dy = torch.randn((N, d.Ho, d.Wo, Co), device=dev)    # conv-output side
         w = torch.randn((Cor, Cir, K, K), device=dev) * 0.05
         b = torch.randn(Cir if tr else Cor, device=dev)
-        pk = ops.PackedConv(w, b, Ci, Co)
+        pk = ops.PackedConv(w, b, ops.cpad(Ci), ops.cpad(Co))   # packed widths: multiples of 16 (the tensors may be C4)
         y = torch.empty_like(dy)
         dx = torch.empty_like(x)
         dw = torch.empty_like(w)
