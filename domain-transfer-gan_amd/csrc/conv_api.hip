@@ -264,13 +264,46 @@ static inline int c16(int c) { return (c + 15) / 16 * 16; }
 static inline size_t npack_elems(int K) { return (size_t)K * (K + 3) * 512; }   // floats
 static inline bool npack_wf(int K, int Ci, int Co) { return K > 1 && K <= 7 && c16(Co) == 16 && c16(Ci) == 32; }   // thin-out forward
 static inline bool npack_wb(int K, int Ci, int Co) { return K > 1 && K <= 7 && c16(Ci) == 16 && c16(Co) == 32; }   // thin-in data gradient
+// ... and the thin-INPUT layers with 32 output channels (7x7 nc -> 32 stem forward, data gradient of the 32 -> nc head) a
+// "row-packed" form (conv_patch.hip conv_thinrow_x3): per kernel row one 32-deep K step = 8 window columns (the eighth zero)
+// x 4 channels, [row][k-group 4][32 columns][8] bf16 hi + lo = 4 KB per row.
+static inline size_t trow_elems(int K) { return (size_t)K * 1024; }   // floats
+static inline bool trow_wf(int K, int Ci, int Co) { return K > 1 && K <= 7 && c16(Ci) == 16 && c16(Co) == 32; }   // thin-in forward
+static inline bool trow_wb(int K, int Ci, int Co) { return K > 1 && K <= 7 && c16(Co) == 16 && c16(Ci) == 32; }   // thin-out data gradient
 static size_t wf_regular_elems(int K, int Ci, int Co) { return (size_t)K * K * (c16(Ci) / 8) * acg_ncols_pad(c16(Co)) * 8; }
-extern "C" size_t acg_packed_wf_elems(int K, int Ci, int Co) { return wf_regular_elems(K, Ci, Co) + (npack_wf(K, Ci, Co) ? npack_elems(K) : 0); }
+extern "C" size_t acg_packed_wf_elems(int K, int Ci, int Co)
+{
+    return wf_regular_elems(K, Ci, Co) + (npack_wf(K, Ci, Co) ? npack_elems(K) : 0) + (trow_wf(K, Ci, Co) ? trow_elems(K) : 0);
+}
 // K == 3: three more slabs behind the nine taps, 9 + kw = w[0][kw] + w[2][kw] (bf16 packings only): what the kernel row that
 // reads a mirrored row uses in the un-padded data gradient of a reflection-padded layer (Geom.unpad)
 static inline int wb_slabs(int K) { return K * K + (K == 3 ? 3 : 0); }
 static size_t wb_regular_elems(int K, int Ci, int Co) { return (size_t)wb_slabs(K) * (c16(Co) / 8) * acg_ncols_pad(c16(Ci)) * 8; }
-extern "C" size_t acg_packed_wb_elems(int K, int Ci, int Co) { return wb_regular_elems(K, Ci, Co) + (npack_wb(K, Ci, Co) ? npack_elems(K) : 0); }
+extern "C" size_t acg_packed_wb_elems(int K, int Ci, int Co)
+{
+    return wb_regular_elems(K, Ci, Co) + (npack_wb(K, Ci, Co) ? npack_elems(K) : 0) + (trow_wb(K, Ci, Co) ? trow_elems(K) : 0);
+}
+
+// Row-packed thin-K weights: out[hi | lo][ry][kg (4)][col (32)][8]: k = 8 kg + j = window column kw = 2 kg + (j >> 2), gathered
+// channel ch = j & 3.  mode 0 (forward of a thin-input layer): value w[col][ch][ry][kw]; mode 1 (data gradient of a
+// thin-output layer; gathered channel = its output channel, col = its input channel): the flipped kernel,
+// w[ch][col][K-1-ry][K-1-kw].  Zero for kw >= K (the eighth column of a 7-wide row).
+__global__ void pack_weight_trow_kernel(const float *__restrict__ w, int Or, int Ir, int K, int mode, __bf16 *__restrict__ out)
+{
+    const int total = K * 1024;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int j = i & 7, col = (i >> 3) & 31, kg = (i >> 8) & 3, ry = i >> 10;
+        const int kw = 2 * kg + (j >> 2), ch = j & 3;
+        float v = 0.f;
+        if (kw < K) {
+            if (mode == 0) { if (col < Or && ch < Ir) v = w[(((long long)col * Ir + ch) * K + ry) * K + kw]; }
+            else           { if (ch < Or && col < Ir) v = w[(((long long)ch * Ir + col) * K + (K - 1 - ry)) * K + (K - 1 - kw)]; }
+        }
+        const __bf16 hi = (__bf16)v;
+        out[i] = hi;
+        out[total + i] = (__bf16)(v - (float)hi);
+    }
+}
 
 // N-packed weights: out[hi | lo][(ry * (K + 3) + u)][kg (4)][col (16)][8]: k = 8 kg + j is the gathered channel, col = 4 dxo + c
 // the output pixel offset dxo and channel c.  mode 0 (forward of a thin-output layer): k = input channel, c = output channel,
@@ -321,12 +354,16 @@ extern "C" int acg_pack_conv_weight(const float *w, int Or, int Ir, int K, int C
             else if (wb) regular(nullptr, wb);
             if (wb && npack_wb(K, Ci, Co) && g_acg_precision == ACG_PREC_BF16X3 && use_bf16())
                 hipLaunchKernelGGL(pack_weight_npack_kernel, dim3(64), dim3(256), 0, st, w, Or, Ir, K, 1, (__bf16 *)(wb + wb_regular_elems(K, Ci, Co)));
+            if (wf && trow_wf(K, Ci, Co) && g_acg_precision == ACG_PREC_BF16X3 && use_bf16())
+                hipLaunchKernelGGL(pack_weight_trow_kernel, dim3(28), dim3(256), 0, st, w, Or, Ir, K, 0, (__bf16 *)(wf + wf_regular_elems(K, Ci, Co)));
         } else {
             if (wf && thin_valu_c(Ci)) hipLaunchKernelGGL(pack_weight_thinN_kernel, dim3(64), dim3(256), 0, st, w, Or, Ir, K * K, Ci, 0, wf);
             else if (wf) regular(wf, nullptr);
             if (wb) hipLaunchKernelGGL(pack_weight_thin_kernel, dim3(64), dim3(256), 0, st, w, Or, Ir, K * K, acg_ncols_pad(Ci), 1, wb);
             if (wf && npack_wf(K, Ci, Co) && g_acg_precision == ACG_PREC_BF16X3 && use_bf16())
                 hipLaunchKernelGGL(pack_weight_npack_kernel, dim3(64), dim3(256), 0, st, w, Or, Ir, K, 0, (__bf16 *)(wf + wf_regular_elems(K, Ci, Co)));
+            if (wb && trow_wb(K, Ci, Co) && g_acg_precision == ACG_PREC_BF16X3 && use_bf16())
+                hipLaunchKernelGGL(pack_weight_trow_kernel, dim3(28), dim3(256), 0, st, w, Or, Ir, K, 1, (__bf16 *)(wb + wb_regular_elems(K, Ci, Co)));
         }
         ACG_CHECK_LAUNCH("pack_weight_thin_kernel");
         return ACG_OK;
@@ -993,6 +1030,10 @@ extern "C" int acg_conv2d_fwd(const acg_conv_desc *d, const float *x, const floa
 extern "C" int acg_conv2d_fwd_stats_supported(const acg_conv_desc *d)
 {
     if (d == nullptr || g_acg_precision == ACG_PREC_F32 || g_acg_conv_impl != ACG_IMPL_MFMA) return 0;
+    // the C4 image -> 32 channel stem (conv_thinrow_x3): statistics over its 8 x 16 pixel tiles
+    if (thin_in(d) && d->Ci == 4 && d->Co == 32 && d->stride == 1 && d->K <= 7 && g_acg_precision == ACG_PREC_BF16X3 && d->Ho % 8 == 0 &&
+        d->Wo % 16 == 0 && !acg_debug_switch("ACG_NO_THINROW"))
+        return 1;
     if (thin_in(d) || thin_out(d) || d->Co < 32 || d->Ci % 16 != 0) return 0;    // MFMA tiles of the bf16 kernels only
     if (d->Co < 128 && acg_debug_switch("ACG_NO_GENERIC_STATS")) return 0;   // A/B switch: statistics pass for the narrow layers
     return ((long long)d->Ho * d->Wo) % 128 == 0 ? 1 : 0;

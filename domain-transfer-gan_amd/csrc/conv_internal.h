@@ -127,6 +127,8 @@ int acg_conv_patch16_launch(const float *in, const void *wp, const float *bias, 
                             long long n_w_elems, hipStream_t st);
 bool acg_conv_patchn_ok(const Geom &g, const Taps &t);   // ... with C4 output and N-packed weights (conv_patchn_x3)
 int acg_conv_patchn_launch(const float *in, const void *wn, const float *bias, float *out, const Geom &g, const Taps &t, hipStream_t st);
+bool acg_conv_thinrow_ok(const Geom &g, const Taps &t);  // C4 gathered tensor -> 32 channels, one K step per kernel row (conv_thinrow_x3)
+int acg_conv_thinrow_launch(const float *in, const void *wr, const float *bias, float *out, const Geom &g, const Taps &t, hipStream_t st);
 // conv_ph4.hip: stride-2 data gradient / ConvTranspose2d forward with the four sub-pixel phases in one tile (64 columns)
 bool acg_igemm_ph4_ok(const Geom &g);
 bool acg_ph4_plan(const Taps &t, const int nt[4], Taps *out);

@@ -320,6 +320,209 @@ int acg_conv_patchn_launch(const float *in, const void *wn, const float *bias, f
     return ACG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The mirror image: layers that GATHER a C4 image tensor and write 32 channels — the 7x7 reflect stem forward, the data
+// gradient of the 7x7 head (networks.py:159-160, 187-188).  The generic thin kernel (conv_igemm.hip, K flattened over (tap,
+// 4 channels)) gathers 128 pixels x 8 taps from global memory per 32-deep stage, seven dependent stages per tile: latency,
+// not bytes.  Here the 8 x 16 output tile's input patch (14 x 24 pixels x 8 bytes of bf16 hi, the same of lo: 5 KB) is
+// loaded and split ONCE, and one K step is one kernel ROW: 8 window columns (the eighth has zero weights) x 4 channels = 32 —
+// the two pixels x 4 channels of a lane's A fragment are 16 contiguous bytes of the patch row.  Weights in the row-packed
+// form (pack_weight_trow_kernel), B fragments straight from L1 / L2, three rows ahead.
+namespace {
+constexpr int TR_PW = PT_TW + 8;                  // patch row: 16 output pixels + 8 window columns
+constexpr int TR_PHMAX = PT_TH + 6;               // 7-row window
+constexpr int TR_PLANE = TR_PHMAX * TR_PW * 4;    // bf16 elements of one hi (or lo) patch
+}
+template <bool REFLECT>
+__global__ __launch_bounds__(256) void conv_thinrow_x3(const float *__restrict__ in, const __bf16 *__restrict__ wr,
+                                                       const float *__restrict__ bias, float *__restrict__ out, Geom g,
+                                                       int dymin, int dxmin, int KH, unsigned in_bytes)
+{
+    // the patch [hi|lo][row][pixel][4] bf16 (5.4 KB); afterwards the output tile [128 pixels][32] fp32 + 512 floats of scratch
+    __shared__ __attribute__((aligned(16))) float smem[PT_TH * PT_TW * 32 + 512];
+    static_assert(sizeof(smem) >= 2 * TR_PLANE * sizeof(__bf16), "patch fits the tile buffer");
+    __bf16 *const Ap = (__bf16 *)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (g.GW + PT_TW - 1) / PT_TW, tiles_y = (g.GH + PT_TH - 1) / PT_TH;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int n = b / tiles_y;
+    const int gy0 = ty * PT_TH, gx0 = tx * PT_TW;
+    const int PH = PT_TH + KH - 1;
+
+    // ---- B fragments of the first PF kernel rows (lane l: column l & 15 of column tile ct, k-group l >> 4)
+    constexpr int PF = 3;
+    const int kg = lane >> 4, lr = lane & 15;
+    bf16x8 bh[PF][2], bl[PF][2];
+    auto bload = [&](int ry, bf16x8 (&h)[2], bf16x8 (&l)[2]) {   // (a row past the window loads the last row again: unused)
+        const int r = ry < KH ? ry : KH - 1;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const long long e = ((long long)(r * 4 + kg) * 32 + ct * 16 + lr) * 8;
+            h[ct] = *(const bf16x8 *)(wr + e);
+            l[ct] = *(const bf16x8 *)(wr + (long long)KH * 1024 + e);
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < PF; ++k) bload(k, bh[k], bl[k]);
+
+    // ---- the patch: pixel (py, px) <-> gathered pixel (gy0 + py + dymin, gx0 + px + dxmin); 16 bytes of fp32 C4 per pixel in,
+    // 8 + 8 bytes of bf16 hi / lo out.  Columns past the window only meet zero weights but must hold finite values: they
+    // are loaded like the others (zeros outside the image)
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, in_bytes, 0x00020000);
+    constexpr int NIT = (TR_PHMAX * TR_PW + 255) / 256;   // 2
+    f32x4 pv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int pp = tid + 256 * it;
+        const int py = pp / TR_PW, px = pp - py * TR_PW;
+        int iy = gy0 + py + dymin, ix = gx0 + px + dxmin;
+        bool ok = py < PH;
+        if (REFLECT) {
+            ok = ok && iy > -g.Hin && iy < 2 * g.Hin - 1 && ix > -g.Win && ix < 2 * g.Win - 1;
+            iy = iy < 0 ? -iy : iy;
+            iy = iy >= g.Hin ? 2 * (g.Hin - 1) - iy : iy;
+            ix = ix < 0 ? -ix : ix;
+            ix = ix >= g.Win ? 2 * (g.Win - 1) - ix : ix;
+        } else {
+            ok = ok && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+        }
+        const unsigned off = (unsigned)(((n * g.Hin + iy) * g.Win + ix) * 4) * 4u;
+        pv[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off, ok), 0, 0));
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int pp = tid + 256 * it;
+        if (pp >= PH * TR_PW) continue;
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        uint2 hi, lo;
+        unsigned *hp = &hi.x, *lp = &lo.x;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { // the arithmetic of acg_split8
+            const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){pv[it][2 * q], pv[it][2 * q + 1]}, bf16x2_t));
+            const float ha = __builtin_bit_cast(float, h << 16), hb = __builtin_bit_cast(float, h & 0xffff0000u);
+            hp[q] = h;
+            lp[q] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){pv[it][2 * q] - ha, pv[it][2 * q + 1] - hb}, bf16x2_t));
+        }
+        *(uint2 *)&Ap[pp * 4] = hi;
+        *(uint2 *)&Ap[TR_PLANE + pp * 4] = lo;
+    }
+    __syncthreads();
+
+    // ---- kernel rows: wave w owns tile rows 2w, 2w+1; lane l: pixel l & 15 of the row, window columns 2 (l >> 4), + 1
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[r][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    auto afrag = [&](int e) {   // 16 bytes at an 8-byte-aligned element offset: two ds_read_b64
+        const u32x2 a = *(const u32x2 *)&Ap[e], c = *(const u32x2 *)&Ap[e + 4];
+        return __builtin_bit_cast(bf16x8, (u32x4){a[0], a[1], c[0], c[1]});
+    };
+    const int a0 = ((wave * 2) * TR_PW + lr + 2 * kg) * 4;
+#pragma unroll
+    for (int ry = 0; ry < 7; ++ry) {
+        if (ry < KH) {   // (uniform)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int e = a0 + (r + ry) * TR_PW * 4;
+                const bf16x8 ah = afrag(e), al = afrag(TR_PLANE + e);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    acc[r][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ry % PF][ct], acc[r][ct], 0, 0, 0);
+                    acc[r][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ry % PF][ct], acc[r][ct], 0, 0, 0);
+                    acc[r][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ry % PF][ct], acc[r][ct], 0, 0, 0);
+                }
+            }
+        }
+        if (ry + PF < 7) bload(ry + PF, bh[ry % PF], bl[ry % PF]);
+    }
+
+    // ---- epilogue through LDS: lane l holds column l & 15 (+ 16 ct) of pixels 4 (l >> 4) .. + 3 of its rows; the tile leaves in
+    // whole 128-byte pixel rows (16 bytes per lane), and — for an InstanceNorm behind the layer — with its (mean, M2) per channel
+    // over the tile's 128 pixels (Geom.stats: any 128-pixel partition of the image serves acg_norm_stats_from_partials)
+    __syncthreads();   // the patch is no longer read
+    float *const tile = smem, *const red = smem + PT_TH * PT_TW * 32;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int co = ct * 16 + lr;
+        const float bv = (bias != nullptr && co < g.Cout) ? bias[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                tile[((wave * 2 + r) * PT_TW + 4 * kg + k) * 32 + co] = acg_apply_act(acc[r][ct][k] + bv, g.stats != nullptr ? (int)ACG_ACT_NONE : g.act);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PT_TH * PT_TW * 8 / 256; ++k) {   // 4 float4 per thread: 8 lanes per pixel
+        const int idx = tid + 256 * k, pix = idx >> 3, c4 = idx & 7;
+        const int gy = gy0 + pix / PT_TW, gx = gx0 + pix % PT_TW;
+        if (gy < g.GH && gx < g.GW && c4 * 4 < g.Cout)
+            *(f32x4 *)(out + (((long long)n * g.Hout + gy) * g.Wout + gx) * g.Cout + c4 * 4) = *(const f32x4 *)&tile[pix * 32 + c4 * 4];
+    }
+    if (g.stats != nullptr) {   // (uniform; whole tiles only: the launcher checks)
+        const int c = tid & 31, h = tid >> 5;   // channel c, pixels 16 h .. 16 h + 15
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += tile[(h * 16 + r) * 32 + c];
+        red[h * 32 + c] = sum;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) tot += red[q * 32 + c];
+        const float mu = tot * (1.f / (PT_TH * PT_TW));
+        float sq = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float dlt = tile[(h * 16 + r) * 32 + c] - mu;
+            sq += dlt * dlt;
+        }
+        __syncthreads();
+        red[h * 32 + c] = sq;
+        __syncthreads();
+        if (h == 0 && c < g.Cout) {
+            float m2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) m2 += red[q * 32 + c];
+            float *o = g.stats + ((long long)(n * g.stats_cpi + g.stats_chunk0 + ty * tiles_x + tx) * 2) * g.Cout + c;
+            o[0] = mu;
+            o[g.Cout] = m2;
+        }
+    }
+}
+
+bool acg_conv_thinrow_ok(const Geom &g, const Taps &t)
+{
+    static const bool off = acg_debug_switch("ACG_NO_THINROW"); // A/B switch
+    if (off || g_acg_precision != ACG_PREC_BF16X3 || g_acg_conv_impl != ACG_IMPL_MFMA || !g.thin || g.fold_p) return false;
+    if (g.Cin != 4 || g.Cout != 32 || g.ncols_pad != 32 || g.os != 1 || g.is != 1 || g.oy0 != 0 || g.ox0 != 0 || t.n < 4) return false;
+    if (g.stats != nullptr && (g.GH % PT_TH != 0 || g.GW % PT_TW != 0 || g.act != ACG_ACT_NONE)) return false;   // whole 128-pixel tiles
+    int a, b, kh, kw;
+    return patchn_window(t, &a, &b, &kh, &kw) && g.Hin >= 2 && g.Win >= 2;
+}
+
+// wr: the row-packed weights (behind the regular packed form: acg_packed_w{f,b}_elems)
+int acg_conv_thinrow_launch(const float *in, const void *wr, const float *bias, float *out, const Geom &g, const Taps &t, hipStream_t st)
+{
+    int ymin, xmin, KH, KW;
+    ACG_REQUIRE(acg_conv_thinrow_ok(g, t) && patchn_window(t, &ymin, &xmin, &KH, &KW), "conv_thinrow_x3: unsupported geometry");
+    const long long nimg = g.Mtot / ((long long)g.GH * g.GW);
+    const long long in_bytes = nimg * g.Hin * g.Win * g.Cin * 4;
+    ACG_REQUIRE(in_bytes < (1LL << 32), "conv_thinrow_x3: gathered tensor exceeds the 4 GiB buffer-addressing limit");
+    const long long blocks = nimg * ((g.GH + PT_TH - 1) / PT_TH) * ((g.GW + PT_TW - 1) / PT_TW);
+    if (g.reflect)
+        hipLaunchKernelGGL((conv_thinrow_x3<true>), dim3((unsigned)blocks), dim3(256), 0, st, in, (const __bf16 *)wr, bias, out, g, ymin, xmin, KH, (unsigned)in_bytes);
+    else
+        hipLaunchKernelGGL((conv_thinrow_x3<false>), dim3((unsigned)blocks), dim3(256), 0, st, in, (const __bf16 *)wr, bias, out, g, ymin, xmin, KH, (unsigned)in_bytes);
+    ACG_CHECK_LAUNCH("conv_thinrow_x3");
+    acg_note_kernel("conv_thinrow_x3<REFLECT=%d> (%dx%d window)", g.reflect ? 1 : 0, KH, KW);
+    return ACG_OK;
+}
+
 // eligibility: bf16x3, 32 gathered channels, 16 (or, for an image tensor stored C4, 4) stored output channels, unit strides,
 // tap window <= 7x7
 bool acg_conv_patch16_ok(const Geom &g, const Taps &t)

@@ -652,7 +652,8 @@ def test_stride2_phases_in_one_tile_match_the_fp32_kernels():
 @pytest.mark.parametrize("case", [("conv", 32, 64, 3, 1, 32, 32), ("conv", 64, 32, 3, 1, 16, 64), ("conv", 16, 32, 3, 2, 32, 32),
                                   ("conv", 32, 32, 3, 1, 32, 32), ("conv", 16, 32, 3, 2, 64, 64), ("conv", 32, 32, 3, 1, 8, 16),
                                   ("conv", 64, 128, 3, 2, 32, 32), ("convT", 128, 64, 3, 2, 32, 32), ("convT", 64, 32, 3, 2, 16, 32),
-                                  ("convT", 128, 64, 3, 2, 8, 128)])   # the last: four phases in one tile (conv_ph4.hip)
+                                  ("convT", 128, 64, 3, 2, 8, 128),   # four phases in one tile (conv_ph4.hip)
+                                  ("stem", 3, 32, 7, 1, 24, 48)])       # C4 image -> 32 channels, 8 x 16 pixel tiles (conv_thinrow_x3)
 def test_conv_epilogue_statistics_equal_the_statistics_pass(case):
     """Per-tile (mean, M2) from the convolution epilogues (generic bf16 tile, wave-specialised tile, the four phase launches
     of ConvTranspose2d) merged by acg_norm_stats_from_partials against acg_norm_stats on the stored output: the mean / rstd
@@ -666,7 +667,20 @@ def test_conv_epilogue_statistics_equal_the_statistics_pass(case):
         st = ops._stream()
         rs = np.random.RandomState(Ci + Co)
         NB = 4
-        if kind == "conv":
+        if kind == "stem":   # networks.py:159-160: ReflectionPad2d(3) + 7x7 on an image stored C4
+            d = ops.conv_desc(NB, H, W, 4, Co, K, stride, 3, 1, Ci, Co)
+            x = t(np.concatenate([rs.normal(0.3, 1, (NB, H, W, Ci)), np.zeros((NB, H, W, 4 - Ci))], -1))
+            w = t(rs.normal(0, 0.2, (Co, Ci, K, K))); b = t(rs.normal(0, 1, Co))
+            pk = ops.PackedConv(w, b, 16, Co)
+            y = torch.empty((NB, d.Ho, d.Wo, Co), device="cuda")
+            assert _lib.query("acg_conv2d_fwd_stats_supported", ctypes.byref(d))
+            part = torch.zeros((NB, d.Ho * d.Wo // 128, 2, Co), device="cuda")
+            _lib.call("acg_conv2d_fwd_stats", ctypes.byref(d), P(x), P(pk.wf), P(pk.bias), P(y), P(part), st)
+            assert _lib.query("acg_last_kernel").decode().startswith("conv_thinrow_x3")
+            y2 = torch.empty_like(y)
+            _lib.call("acg_conv2d_fwd", ctypes.byref(d), P(x), P(pk.wf), P(pk.bias), P(y2), 0, st)
+            C = Co
+        elif kind == "conv":
             d = ops.conv_desc(NB, H, W, Ci, Co, K, stride, 1, 1 if stride == 1 else 0, Ci, Co)
             x = t(rs.normal(0.3, 1, (NB, H, W, Ci)))
             w = t(rs.normal(0, 0.2, (Co, Ci, K, K))); b = t(rs.normal(0, 1, Co))
