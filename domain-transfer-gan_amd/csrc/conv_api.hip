@@ -1231,6 +1231,19 @@ extern "C" int acg_conv2d_bwd_weight_s16(const acg_conv_desc *d, const void *x, 
 
 // split-K plan shared by the workspace query and the launch
 static bool wgrad_thin(const acg_conv_desc *d) { return thin_in(d); }
+// the persistent patch kernel of the 7x7 image layers (conv_wgrad_thin.hip): workgroups = partial slabs, or 0 where the layer
+// does not take it (same conditions as acg_wgrad_thin_patch_ok, on the descriptor)
+static int wgrad_thin_patch_splits(const acg_conv_desc *d)
+{
+    if (g_acg_precision != ACG_PREC_BF16X3 || g_acg_conv_impl != ACG_IMPL_MFMA || d->stride != 1 || d->K < 2 || d->K > 7 ||
+        d->Hi != d->Ho || d->Wi != d->Wo || acg_debug_switch("ACG_NO_WGRAD_THIN_PATCH"))
+        return 0;
+    const bool stem = thin_in(d) && d->Ci == 4 && d->Co == 32;
+    const bool head = thin_out(d) && d->Co == 4 && d->Ci == 32 && !(d->pad_mode == ACG_PAD_REFLECT && d->pad > 0);
+    if (!stem && !head) return 0;
+    const long long ntiles = (long long)d->N * ((d->Ho + 7) / 8) * ((d->Wo + 15) / 16);
+    return (int)(ntiles < 768 ? ntiles : 768);
+}
 
 static void wgrad_plan(const acg_conv_desc *d, int Cx, int Cg, long long Mtot, int *CiP, int *CoP, int *nsplit,
                        long long *mps)
@@ -1268,6 +1281,11 @@ static void wgrad_plan(const acg_conv_desc *d, int Cx, int Cg, long long Mtot, i
         target = 512;
         gran = 128;
     }
+    if (wgrad_thin(d) && wgrad_thin_patch_splits(d) > 0) {   // one slab per persistent workgroup
+        *nsplit = wgrad_thin_patch_splits(d);
+        *mps = (Mtot + *nsplit - 1) / *nsplit;
+        return;
+    }
     long long ns = target / nblk;
     const long long cap = Mtot / (KP * 4);
     if (ns > cap) ns = cap;
@@ -1295,6 +1313,7 @@ static size_t wgrad_ws_bytes(const acg_conv_desc *d, int Cx, int Cg, long long M
         if (ns2 > cap) ns2 = cap;
         if (ns2 > 512) ns2 = 512;
         if (ns2 < 1) ns2 = 1;
+        if (wgrad_thin_patch_splits(d) > ns2) ns2 = wgrad_thin_patch_splits(d);
         const size_t t2 = (size_t)(ns2 + 1) * 32 * ((d->K * d->K + 7) / 8) * ((d->Ci + 31) / 32 * 32) * sizeof(float);
         if (t2 > total) total = t2;
     }
@@ -1381,6 +1400,7 @@ static int wgrad_thin_out(const acg_conv_desc *d, const float *x, const float *d
     per = (per + 255) / 256 * 256;
     g.nsplit = (int)((g.Mtot + per - 1) / per);
     g.m_per_split = per;
+    if (wgrad_thin_patch_splits(d) > 0) g.nsplit = wgrad_thin_patch_splits(d);   // one slab per persistent workgroup
     const size_t need = (size_t)g.nsplit * g.CiP * g.CoP * sizeof(float);
     if (ws == nullptr || ws_bytes < need) {
         acg_set_error("acg_conv2d_bwd_weight(thin out): workspace %zu < %zu", ws_bytes, need);

@@ -143,6 +143,10 @@ bool acg_wgrad_krow_ok(const WGeom &g, const Taps &t);
 int acg_wgrad_krow_launch(const float *x, const float *dy, float *part, const WGeom &g, hipStream_t st);
 int acg_wgrad_krow_s16_launch(const void *x, const void *dy, float *part, const WGeom &g, hipStream_t st); // pre-split operands
 bool acg_wgrad_krow_s_ok(const WGeom &g, const Taps &t);   // its 32 <-> 64 channel, 128-pixel-run variant
+// conv_wgrad_thin.hip: the 7x7 image layers (C4 tensor on one side, 32 channels on the other), persistent over 8 x 16 tiles
+bool acg_wgrad_thin_patch_ok(const WGeom &g, const Taps &t, int *K, int *flip);
+int acg_wgrad_thin_patch_tiles(const WGeom &g);
+int acg_wgrad_thin_patch_launch(const float *thin, const float *wide, float *part, const WGeom &g, const Taps &t, hipStream_t st);
 int acg_wgrad_krow_s_launch(const float *x, const float *dy, float *part, const WGeom &g, hipStream_t st);
 
 #ifdef __HIPCC__
