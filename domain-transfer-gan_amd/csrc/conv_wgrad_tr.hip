@@ -746,10 +746,12 @@ __global__ __launch_bounds__(512 + 64 * ACG_KROW_NDW) void wgrad_x3_krow_s16(con
         return f;
     };
     auto mma = [&](int t, const AF &a, const BF &bf) {
+#ifndef ACG_ABL_HIONLY   // (timing-only ablation: one MFMA per product, the lo halves still loaded — what plain bf16 MFMAs would take)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, bf.h[j], acc[t][j], 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, bf.l[j], acc[t][j], 0, 0, 0);
+#endif
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, bf.h[j], acc[t][j], 0, 0, 0);
     };
