@@ -31,7 +31,10 @@ __global__ __launch_bounds__(256) void conv_patch16_x3(const float *__restrict__
     __shared__ __attribute__((aligned(16))) __bf16 Ap[2 * PT_IMG]; // [hi|lo][plane][pixel][8]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_x = (g.GW + PT_TW - 1) / PT_TW, tiles_y = (g.GH + PT_TH - 1) / PT_TH;
-    int b = blockIdx.x;
+    // XCD-aware tile order (bijective for any grid size): workgroups are dealt to the 8 XCDs round-robin, so consecutive tiles
+    // — whose patches overlap — are made neighbours on ONE XCD and fetch the shared rows through one L2
+    const int nwg_ = gridDim.x, bid_ = blockIdx.x, xq_ = nwg_ >> 3, xr_ = nwg_ & 7, xcd_ = bid_ & 7;
+    int b = (xcd_ < xr_ ? xcd_ * (xq_ + 1) : xr_ * (xq_ + 1) + (xcd_ - xr_) * xq_) + (bid_ >> 3);
     const int tx = b % tiles_x; b /= tiles_x;
     const int ty = b % tiles_y;
     const int n = b / tiles_y;
@@ -160,7 +163,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __shared__ __attribute__((aligned(16))) __bf16 Ap[2 * PT_IMG]; // [hi|lo][plane][pixel][8]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_x = (g.GW + PT_TW - 1) / PT_TW, tiles_y = (g.GH + PT_TH - 1) / PT_TH;
-    int b = blockIdx.x;
+    // XCD-aware tile order (bijective for any grid size): workgroups are dealt to the 8 XCDs round-robin, so consecutive tiles
+    // — whose patches overlap — are made neighbours on ONE XCD and fetch the shared rows through one L2
+    const int nwg_ = gridDim.x, bid_ = blockIdx.x, xq_ = nwg_ >> 3, xr_ = nwg_ & 7, xcd_ = bid_ & 7;
+    int b = (xcd_ < xr_ ? xcd_ * (xq_ + 1) : xr_ * (xq_ + 1) + (xcd_ - xr_) * xq_) + (bid_ >> 3);
     const int tx = b % tiles_x; b /= tiles_x;
     const int ty = b % tiles_y;
     const int n = b / tiles_y;
@@ -344,7 +350,10 @@ __global__ __launch_bounds__(256) void conv_thinrow_x3(const float *__restrict__
     __bf16 *const Ap = (__bf16 *)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_x = (g.GW + PT_TW - 1) / PT_TW, tiles_y = (g.GH + PT_TH - 1) / PT_TH;
-    int b = blockIdx.x;
+    // XCD-aware tile order (bijective for any grid size): workgroups are dealt to the 8 XCDs round-robin, so consecutive tiles
+    // — whose patches overlap — are made neighbours on ONE XCD and fetch the shared rows through one L2
+    const int nwg_ = gridDim.x, bid_ = blockIdx.x, xq_ = nwg_ >> 3, xr_ = nwg_ & 7, xcd_ = bid_ & 7;
+    int b = (xcd_ < xr_ ? xcd_ * (xq_ + 1) : xr_ * (xq_ + 1) + (xcd_ - xr_) * xq_) + (bid_ >> 3);
     const int tx = b % tiles_x; b /= tiles_x;
     const int ty = b % tiles_y;
     const int n = b / tiles_y;
