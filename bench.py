@@ -19,7 +19,8 @@ losses and Adam are fp32 throughout; the convolution products run on the matrix 
   bf16x3  fp32 operands split hi + lo into bf16, three bf16 MFMAs per product, fp32 accumulate: 16-bit operand
           mantissas (config 3 names plain bf16 = 8), parity-tested at the 1e-3 bar;
   f32     exact fp32 products on v_mfma_f32_32x32x2_f32 (strict mode, 1/16 of the bf16 MFMA rate);
-  bf16    operands rounded to bf16 (what config 3 names; NOT inside the parity bar, reported for reference).
+  (a plain-bf16 mode is not offered: DESIGN_LOG.md A.4 — an MFMA-only ablation bounds it at 1.24x, a storage mode short of
+  330 images/s; `ops.set_precision("bf16")` remains as the operand-rounding probe of tests/test_hip_bf16.py.)
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel: the 3x3 reflect-pad 128->128 resblock convolution forward),
 `roofline_hbm` (the stride-2 64->128 downsample convolution forward, HBM-bound) — both timed live with HIP events on the
@@ -56,7 +57,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-bn", action="store_true", help="BatchNorm statistics over all ranks (default: per rank, as the "
                                                            "reference's data_parallel)")
-    ap.add_argument("--precision", default=None, choices=["f32", "bf16x3", "bf16"],
+    ap.add_argument("--precision", default=None, choices=["f32", "bf16x3"],
                     help="conv arithmetic, see the module docstring (default: the config's)")
     ap.add_argument("--cpu-baseline-only", type=int, default=0, metavar="THREADS",
                     help="(internal) time the oracle step on THREADS host threads and print its JSON object")
@@ -276,12 +277,11 @@ def main():
     achieved = flops / (kern_ms * 1e-3) / 1e12 if ms else None
     # dense MFMA peaks (MI355X_MICROARCH.md): fp32 157.3, bf16 2500 TFLOP/s; bf16x3 issues 3 bf16 MFMAs per
     # algorithmic product, so its ceiling for ALGORITHMIC flops is 2500 / 3
-    peak = {"f32": 157.3, "bf16x3": round(2500.0 / 3, 1), "bf16": 2500.0}[a.precision]
+    peak = {"f32": 157.3, "bf16x3": round(2500.0 / 3, 1)}[a.precision]
     dtype = {"f32": "f32",
              "bf16x3": "f32 tensors; conv products as 3 bf16 MFMAs on hi/lo-split fp32 operands (~2^-17 operand rounding), fp32 "
                        "accumulate; parity vs the reference goldens: losses / single-pass images / cycle reconstructions <= 1e-3 "
-                       "(3e-3 on rec_A/rec_B of the deliberately ill-conditioned 'rich' fixture only)",
-             "bf16": "bf16 (MFMA operands; fp32 accumulate and fp32 tensors)"}[a.precision]
+                       "(3e-3 on rec_A/rec_B of the deliberately ill-conditioned 'rich' fixture only)"}[a.precision]
     # HBM traffic of the dominant kernel: measured by tools/profile_traffic.sh + tools/summarize_traffic.py (separate
     # rocprofv3 --pmc passes; counters cannot be read inside the timed run), committed per kernel under profiles/
     traffic, traffic_src = None, None

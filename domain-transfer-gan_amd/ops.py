@@ -91,7 +91,8 @@ def set_precision(name):
     """Arithmetic of the MFMA convolution kernels: 'bf16x3' (default: each fp32 operand split into bf16 hi + lo in
     LDS, lo*hi + hi*lo + hi*hi on the bf16 matrix pipe, fp32 accumulate — operands keep 16 mantissa bits, ~4e-6 rms
     per conv, well inside the 1e-3 parity bar), 'f32' (exact-fp32 matrix pipe, the strict mode the tight tests pin the
-    kernels with) or 'bf16' (operands rounded to bf16, fp32 accumulate — throughput mode, NOT a parity path).  HBM
+    kernels with) or 'bf16' (operands rounded to bf16, fp32 accumulate: a numerics PROBE for tests/test_hip_bf16.py, not offered by
+    bench.py / options.py — no faster than bf16x3 with fp32 tensors, DESIGN_LOG.md A.4).  HBM
     tensors stay fp32 in every mode."""
     global CONFIG_EPOCH, _PRECISION
     _lib.call("acg_set_conv_precision", {"f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16, "bf16x3": _lib.PREC_BF16X3}[name])

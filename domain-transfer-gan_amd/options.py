@@ -71,9 +71,9 @@ _T = [
     ("eval_B_freq", int, 1, "frequency of evaluating on B"),
     # additions of this implementation
     ("n_blocks", int, 3, "residual blocks per generator (the reference builds 3)"),
-    ("precision", ("choice", str, ["bf16x3", "f32", "bf16"]), "bf16x3",
+    ("precision", ("choice", str, ["bf16x3", "f32"]), "bf16x3",
      "conv arithmetic on the matrix cores: bf16x3 (default; split-bf16 products, inside the 1e-3 parity bar — what bench.py "
-     "and the parity tests run), f32 (exact products, 2.4x slower), bf16 (rounded operands, outside the parity bar)"),
+     "and the parity tests run), f32 (exact products, 2.4x slower)"),
     ("synthetic", int, 0, "use N synthetic U(-1,1) samples per split instead of --dataroot"),
     ("sync_bn", "flag", False, "data parallel: BatchNorm (E_B, D_z_B) statistics across all ranks"),
     ("step_graph", "flag", False, "replay the training step as one captured HIP graph (launch-bound sizes: small images / "

@@ -8,7 +8,6 @@ cat gpurun_out/${TAG}_bench_cfg3.json
 timeout -k 10 300 python bench.py --config 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_cfg2.json 2> gpurun_out/${TAG}_bench_cfg2.err || exit 1
 timeout -k 10 300 python bench.py --config 5 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_cfg5.json 2> gpurun_out/${TAG}_bench_cfg5.err || exit 1
 timeout -k 10 300 python bench.py --precision f32 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_cfg3_f32.json 2> gpurun_out/${TAG}_bench_cfg3_f32.err || exit 1
-timeout -k 10 300 python bench.py --precision bf16 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_cfg3_bf16.json 2> gpurun_out/${TAG}_bench_cfg3_bf16.err || exit 1
 bash tools/profile_stats.sh bf16x3 $TAG > gpurun_out/${TAG}_stats.log 2>&1 || exit 1
 python3 tools/kernel_stats_md.py gpurun_out/${TAG}_kernel_stats.csv gpurun_out/${TAG}_kernel_stats.md 3 bf16x3
 bash tools/profile_traffic.sh > gpurun_out/${TAG}_traffic.log 2>&1 || exit 1
