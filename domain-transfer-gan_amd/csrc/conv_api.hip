@@ -1281,6 +1281,11 @@ static void wgrad_plan(const acg_conv_desc *d, int Cx, int Cg, long long Mtot, i
         target = 512;
         gran = 128;
     }
+    if (!wgrad_thin(d) && acg_wgrad_k4row_shape_ok(d->K, d->stride, d->pad, d->pad_mode == ACG_PAD_REFLECT, d->Wi, d->Wo, Cx, Cg)) {
+        nblk = 4LL * (*CiP / 128) * (*CoP / 128);   // wgrad_x3_k4row (conv_wgrad_k4.hip): four taps per workgroup, one workgroup per CU,
+        target = 256;                               // a stage is one output row
+        gran = d->Wo;
+    }
     if (wgrad_thin(d) && wgrad_thin_patch_splits(d) > 0) {   // one slab per persistent workgroup
         *nsplit = wgrad_thin_patch_splits(d);
         *mps = (Mtot + *nsplit - 1) / *nsplit;

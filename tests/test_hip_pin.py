@@ -391,3 +391,40 @@ def test_conv_transpose_at_full_width_matches_the_oracle(prec):
     if prec == "bf16x3":
         assert any(k.startswith("igemm_conv_ph4") for k in spy.kernels("acg_conv_transpose2d_fwd")), spy.seen
         assert any("NT=3" in k for k in spy.kernels("acg_conv_transpose2d_bwd_weight")), spy.seen
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# D_B's deep 4x4 layers (networks.py:321-338) at the maps of the 256 x 256 step: 128 -> 256 on 64 x 64 (63-wide output rows),
+# 256 -> 256 on 63-wide rows (62 out) — the kernel-row weight gradient wgrad_x3_k4row, plus other widths and stride 2
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", ["bf16x3", "f32"])
+@pytest.mark.parametrize("case", [(1, 128, 256, 1, 64, 64), (1, 256, 256, 1, 20, 63), (3, 128, 128, 2, 10, 40),
+                                  (1, 128, 128, 1, 5, 17), (5, 256, 128, 1, 7, 25), (2, 128, 128, 2, 9, 33),
+                                  (2, 128, 128, 1, 6, 49), (2, 128, 256, 2, 12, 128)],
+                         ids=lambda c: "n%d_%dto%d_s%d_%dx%d" % c)
+def test_discriminator_4x4_layers_match_the_oracle(case, prec):
+    from hip_util import precision, t, n, rel
+    from dtgan_amd import modules as M
+    N, Ci, Co, s, H, W = case
+    rs = np.random.RandomState(N * 100 + W + s)
+    x = rs.normal(0, 1, (N, Ci, H, W)); w = rs.normal(0, 0.05, (Co, Ci, 4, 4)); b = rs.normal(0, 0.5, (Co,))
+    with precision(prec):
+        m = M.Sequential(M.Conv2d(Ci, Co, 4, stride=s, padding=1, bias=True)).cuda()
+        conv = m[0]
+        with torch.no_grad():
+            conv.weight.copy_(t(w)); conv.bias.copy_(t(b))
+        M.mark_dirty(m)
+        xt = t(x, grad=True)
+        with Spy() as spy:
+            y = m(xt)
+            X, Wt, Bt = leaf(x), leaf(w), leaf(b)
+            yo = oops.conv2d(X, Wt, Bt, stride=s, pad=1)
+            rr = rs.normal(0, 1, yo.v.shape)
+            y.backward(t(rr))
+        backward(yo, seed=rr)
+    assert rel(n(y), yo.v) < 2e-5
+    assert rel(n(xt.grad), X.g) < 2e-5, "dgrad"
+    assert rel(n(conv.weight.grad), Wt.g) < 1e-4, "wgrad"
+    assert rel(n(conv.bias.grad), Bt.g) < 1e-4, "bias grad"
+    if prec == "bf16x3":
+        assert any(k == "wgrad_x3_k4row<%d>" % s for k in spy.kernels("acg_conv2d_bwd_weight")), spy.seen
