@@ -1281,10 +1281,10 @@ static void wgrad_plan(const acg_conv_desc *d, int Cx, int Cg, long long Mtot, i
         target = 512;
         gran = 128;
     }
-    if (!wgrad_thin(d) && acg_wgrad_k4row_shape_ok(d->K, d->stride, d->pad, d->pad_mode == ACG_PAD_REFLECT, d->Wi, d->Wo, Cx, Cg)) {
-        nblk = 4LL * (*CiP / 128) * (*CoP / 128);   // wgrad_x3_k4row (conv_wgrad_k4.hip): four taps per workgroup, one workgroup per CU,
-        target = 256;                               // a stage is one output row
-        gran = d->Wo;
+    if (!wgrad_thin(d) && acg_wgrad_krowg_shape_ok(d->K, d->stride, d->pad, d->pad_mode == ACG_PAD_REFLECT, d->Wi, d->Wo, Cx, Cg)) {
+        nblk = (long long)d->K * (*CiP / (Cx == 64 ? 64 : 128)) * (*CoP / 128);   // wgrad_x3_krowg (conv_wgrad_k4.hip): a kernel row per
+        target = 256;                                                             // workgroup, one workgroup per CU, whole output rows
+        gran = d->Wo;                                                             // per split
     }
     if (wgrad_thin(d) && wgrad_thin_patch_splits(d) > 0) {   // one slab per persistent workgroup
         *nsplit = wgrad_thin_patch_splits(d);

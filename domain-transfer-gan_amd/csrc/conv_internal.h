@@ -112,10 +112,10 @@ struct WGeom {
 int acg_wgrad_launch(const float *x, const float *dy, float *part, const WGeom &g, const Taps &t, hipStream_t st);
 void acg_wgrad_tiles(int Ci, int Co, int *bci, int *bco, int ntaps);
 int acg_wgrad_taps_per_wg(int Ci, int Co, int ntaps, int thin);
-// conv_wgrad_k4.hip: kernel-row weight gradient of the 4x4 zero-padded layers with 128-multiple channels (D_B)
-bool acg_wgrad_k4row_shape_ok(int K, int stride, int pad, int reflect, int Wi, int Wo, int Cx, int Cg);
-bool acg_wgrad_k4row_ok(const WGeom &g, const Taps &t);
-int acg_wgrad_k4row_launch(const float *x, const float *dy, float *part, const WGeom &g, hipStream_t st);
+// conv_wgrad_k4.hip: kernel-row weight gradient of the zero-padded 4x4 layers (D_B) and the stride-2 3x3 pair of the generators
+bool acg_wgrad_krowg_shape_ok(int K, int stride, int pad, int reflect, int Wi, int Wo, int Cx, int Cg);
+bool acg_wgrad_krowg_ok(const WGeom &g, const Taps &t);
+int acg_wgrad_krowg_launch(const float *x, const float *dy, float *part, const WGeom &g, const Taps &t, hipStream_t st);
 
 extern int g_acg_precision;
 extern int g_acg_conv_impl;

@@ -282,7 +282,7 @@ int acg_wgrad_launch(const float *x, const float *dy, float *part, const WGeom &
     acg_wgrad_tiles(g.Cin, g.Cg, &bci, &bco, g.thin ? 0 : t.n);
     int tpk, tpf;
     if (acg_wgrad_thin_patch_ok(g, t, &tpk, &tpf)) return acg_wgrad_thin_patch_launch(x, dy, part, g, t, st);
-    if (acg_wgrad_k4row_ok(g, t)) return acg_wgrad_k4row_launch(x, dy, part, g, st);
+    if (acg_wgrad_krowg_ok(g, t)) return acg_wgrad_krowg_launch(x, dy, part, g, t, st);
     if (acg_wgrad_krow_ok(g, t)) return acg_wgrad_krow_launch(x, dy, part, g, st);
     if (acg_wgrad_krow_s_ok(g, t)) return acg_wgrad_krow_s_launch(x, dy, part, g, st);
     if (g_acg_precision != ACG_PREC_F32 && !g.thin) return acg_wgrad_bf16_launch(x, dy, part, g, t, bci, bco, st);

@@ -4,7 +4,7 @@ HIP kernel).
 Round 3 added kernels that need whole 128-pixel row tiles (W % 128 == 0, H % 32 == 0): the un-padded reflect data gradient
 with its summed weight slabs and column-term GEMM (`Geom.unpad`, `dgrad_colfix_kernel`), the norm-backward sums and the ReLU
 sign bitmask out of `igemm_conv_x3_pre`'s epilogues, the pre-split kernel-row weight gradient, the four sub-pixel phases of
-a stride-2 data gradient in one tile (`igemm_conv_ph4`) and the three-tap weight gradient (`wgrad_bf16<64,128,NT=3>`).  The
+a stride-2 data gradient in one tile (`igemm_conv_ph4`) and the kernel-row weight gradient of the stride-2 pair (`wgrad_x3_krowg<NT=3,IS=2,BCI=64>`).  The
 golden fixtures stop at 64 x 64 images, so here the oracle itself (oracle/ops.py, fp64, plain C loops) runs the layers at
 the geometry bench.py times: a two-block residual trunk on a 128 x 128 x 128 map (N = 1), and single stride-2 /
 ConvTranspose layers at W = 256.  Every test records which C-ABI entry points and which kernels ran and asserts the ones it
@@ -360,7 +360,7 @@ def test_stride2_downsample_at_full_width_matches_the_oracle(N, H, W, prec):
     assert rel(n(conv.bias.grad), Bt.g) < 1e-4, "bias grad"
     if prec == "bf16x3":
         assert any(k.startswith("igemm_conv_ph4") for k in spy.kernels("acg_conv2d_bwd_data")), spy.seen
-        assert any("NT=3" in k for k in spy.kernels("acg_conv2d_bwd_weight")), spy.seen
+        assert any(k == "wgrad_x3_krowg<NT=3,IS=2,BCI=64>" for k in spy.kernels("acg_conv2d_bwd_weight")), spy.seen
 
 
 @pytest.mark.parametrize("prec", ["bf16x3", "f32"])
@@ -390,17 +390,18 @@ def test_conv_transpose_at_full_width_matches_the_oracle(prec):
     assert rel(n(m.bias.grad), Bt.g) < 1e-4
     if prec == "bf16x3":
         assert any(k.startswith("igemm_conv_ph4") for k in spy.kernels("acg_conv_transpose2d_fwd")), spy.seen
-        assert any("NT=3" in k for k in spy.kernels("acg_conv_transpose2d_bwd_weight")), spy.seen
+        assert any(k == "wgrad_x3_krowg<NT=3,IS=2,BCI=64>" for k in spy.kernels("acg_conv_transpose2d_bwd_weight")), spy.seen
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 # D_B's deep 4x4 layers (networks.py:321-338) at the maps of the 256 x 256 step: 128 -> 256 on 64 x 64 (63-wide output rows),
-# 256 -> 256 on 63-wide rows (62 out) — the kernel-row weight gradient wgrad_x3_k4row, plus other widths and stride 2
+# 256 -> 256 on 63-wide rows (62 out) — the kernel-row weight gradient wgrad_x3_krowg, plus other widths, stride 2 and the 64-channel
+# input tile of D_B's second layer
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("prec", ["bf16x3", "f32"])
 @pytest.mark.parametrize("case", [(1, 128, 256, 1, 64, 64), (1, 256, 256, 1, 20, 63), (3, 128, 128, 2, 10, 40),
                                   (1, 128, 128, 1, 5, 17), (5, 256, 128, 1, 7, 25), (2, 128, 128, 2, 9, 33),
-                                  (2, 128, 128, 1, 6, 49), (2, 128, 256, 2, 12, 128)],
+                                  (2, 128, 128, 1, 6, 49), (2, 128, 256, 2, 12, 128), (2, 64, 128, 2, 16, 128), (1, 64, 128, 2, 10, 48)],
                          ids=lambda c: "n%d_%dto%d_s%d_%dx%d" % c)
 def test_discriminator_4x4_layers_match_the_oracle(case, prec):
     from hip_util import precision, t, n, rel
@@ -427,4 +428,4 @@ def test_discriminator_4x4_layers_match_the_oracle(case, prec):
     assert rel(n(conv.weight.grad), Wt.g) < 1e-4, "wgrad"
     assert rel(n(conv.bias.grad), Bt.g) < 1e-4, "bias grad"
     if prec == "bf16x3":
-        assert any(k == "wgrad_x3_k4row<%d>" % s for k in spy.kernels("acg_conv2d_bwd_weight")), spy.seen
+        assert any(k.startswith("wgrad_x3_krowg<NT=4,IS=%d" % s) for k in spy.kernels("acg_conv2d_bwd_weight")), spy.seen
