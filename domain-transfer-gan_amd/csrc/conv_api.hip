@@ -572,14 +572,14 @@ static int colsum_launch(const float *dy, long long M, int C, int Cr, float *db,
 // (16 channels per block, 16 split-lanes each, fixed-order tree: deterministic).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int nsplit, int KK, int CiP, int CoP, int Or,
                                     int Ir, float *__restrict__ dw, int thin, int accumulate, int wblocks,
-                                    const float *__restrict__ bias_part, int Cp, int Cr, float *__restrict__ db)
+                                    const float *__restrict__ bias_part, int Cp, int Cr, float *__restrict__ db, int bias_slots)
 {
     if ((int)blockIdx.x >= wblocks) {
         __shared__ float red[256];
         const int c = ((int)blockIdx.x - wblocks) * 16 + (threadIdx.x & 15), k0 = threadIdx.x >> 4;
         float s = 0.f;
         if (c < Cr)
-            for (int k = k0; k < nsplit; k += 16) s += bias_part[(long long)k * Cp + c];
+            for (int k = k0; k < bias_slots; k += 16) s += bias_part[(long long)k * Cp + c];
         red[threadIdx.x] = s;
         __syncthreads();
         for (int st = 128; st >= 16; st >>= 1) {
@@ -1310,7 +1310,7 @@ static size_t wgrad_ws_bytes(const acg_conv_desc *d, int Cx, int Cg, long long M
     const size_t part = (size_t)ns * d->K * d->K * CiP * CoP * sizeof(float);
     const int Cmax = d->Ci > d->Co ? d->Ci : d->Co;
     const long long Mbig = (long long)d->N * (d->Hi > d->Ho ? d->Hi : d->Ho) * (d->Wi > d->Wo ? d->Wi : d->Wo);
-    const size_t bias_part = (size_t)ns * (CiP > CoP ? CiP : CoP) * sizeof(float);
+    const size_t bias_part = (size_t)ns * 2 * (CiP > CoP ? CiP : CoP) * sizeof(float);   // x-side sums: `stride` slots per split
     size_t total = acg_round_up(part, 256) + acg_round_up(colsum_ws_bytes(Mbig, Cmax) + bias_part, 256);
     if (thin_out(d) && d->stride == 1) { // wgrad_thin_out's partial buffer (its own split plan, <= 512 splits)
         const long long Mx = (long long)d->N * d->Hi * d->Wi;
@@ -1367,6 +1367,7 @@ static int wgrad_common(const acg_conv_desc *d, const float *x_side, const float
                     "wgrad: pre-split operands need the kernel-row geometry (query acg_conv2d_s16_supported)");
         rc = acg_wgrad_krow_s16_launch(x_side, g_side, (float *)ws, g, st);
     } else {
+        ACG_REQUIRE(g.bias_from != 2 || acg_wgrad_krowg_ok(g, t), "wgrad: x-side bias sums only in the kernel-row kernel");
         rc = acg_wgrad_launch(x_side, g_side, (float *)ws, g, t, st);
     }
     if (rc) return rc;
@@ -1374,7 +1375,7 @@ static int wgrad_common(const acg_conv_desc *d, const float *x_side, const float
     const long long total = (long long)t.n * Ir * Or;
     const int wblocks = acg_cdiv(total, 256);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + acg_cdiv(Cr, 16)), dim3(256), 0, st, (const float *)ws, g.nsplit,
-                       t.n, g.CiP, g.CoP, Or, Ir, dw, g.thin, accumulate, wblocks, (const float *)g.bias_part, Cp, Cr, db);
+                       t.n, g.CiP, g.CoP, Or, Ir, dw, g.thin, accumulate, wblocks, (const float *)g.bias_part, Cp, Cr, db, bias_from == 2 ? g.nsplit * g.is : g.nsplit);
     ACG_CHECK_LAUNCH("wgrad_reduce_kernel");
     return ACG_OK;
 }
@@ -1415,7 +1416,7 @@ static int wgrad_thin_out(const acg_conv_desc *d, const float *x, const float *d
     if (rc) return rc;
     const long long total = (long long)t.n * Ir * Or;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(acg_cdiv(total, 256)), dim3(256), 0, st, (const float *)ws, g.nsplit, t.n,
-                       g.CiP, g.CoP, Or, Ir, dw, 2, accumulate, acg_cdiv(total, 256), (const float *)nullptr, 0, 0, (float *)nullptr);
+                       g.CiP, g.CoP, Or, Ir, dw, 2, accumulate, acg_cdiv(total, 256), (const float *)nullptr, 0, 0, (float *)nullptr, 0);
     ACG_CHECK_LAUNCH("wgrad_reduce_kernel");
     return ACG_OK;
 }
@@ -1506,11 +1507,14 @@ extern "C" int acg_conv_transpose2d_bwd_weight(const acg_conv_desc *d, const flo
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     ACG_REQUIRE(ws != nullptr && ws_bytes >= acg_conv2d_bwd_weight_workspace_bytes(d), "acg_conv_transpose2d_bwd_weight: workspace too small");
-    // no bias fusion here: the bias sums the GATHERED-side operand (dy of the ConvTranspose), whose tap-0 gather
-    // visits only a strided subset of its pixels; one separate column-sum pass per generator is cheap.
-    const bool fused = false;
+    // the bias sums the GATHERED-side operand (dy of the ConvTranspose), whose tap-0 gather visits only a strided subset of
+    // its pixels: fused only in the kernel-row kernel (conv_wgrad_k4.hip), where kernel rows 1 .. stride visit every row
+    // once; otherwise one separate column-sum pass
+    const bool fused = dw != nullptr && db != nullptr && g_acg_conv_impl == ACG_IMPL_MFMA && d->stride <= 2 &&
+                       d->Hi == d->stride * d->Ho && d->Wi == d->stride * d->Wo &&
+                       acg_wgrad_krowg_shape_ok(d->K, d->stride, d->pad, d->pad_mode == ACG_PAD_REFLECT, d->Wi, d->Wo, d->Ci, d->Co);
     if (dw != nullptr) {
-        rc = wgrad_common(d, dy, x, dw, Or, Ir, ws, ws_bytes, st, accumulate, 0, nullptr);
+        rc = wgrad_common(d, dy, x, dw, Or, Ir, ws, ws_bytes, st, accumulate, fused ? 2 : 0, fused ? db : nullptr);
         if (rc) return rc;
     }
     if (db != nullptr && !fused) {

@@ -109,6 +109,9 @@ __global__ __launch_bounds__(512) void wgrad_x3_krowg(const float *__restrict__ 
     const int c8x = tid % L::UPP, pjx = tid / L::UPP;
     u32x4 rx[PF][FR + 1][2], rda[PF][2];
     const bool do_bias = g.bias_from == 1 && ky == 0 && tci == 0;
+    // ConvTranspose bias (column sums of the x side): kernel rows 1 .. IS visit every input row exactly once (iy = oy * IS +
+    // ky - 1), and window pixels 1 .. IS * KP of a run every column once
+    const bool do_xbias = g.bias_from == 2 && tco == 0 && ky >= 1 && ky <= IS;
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     auto load_stage = [&](auto PC) {
@@ -157,6 +160,17 @@ __global__ __launch_bounds__(512) void wgrad_x3_krowg(const float *__restrict__ 
         for (int r = 0; r < FR; ++r) put(base, base + XIMG, L::img_row(pjx + L::PPR * r) * PX + c8x * 16, rx[P][r]);
         if (wave == 0 && pjx < L::XTAIL) put(base, base + XIMG, L::img_row(pjx + L::PPR * FR) * PX + c8x * 16, rx[P][FR]);
         put(base + 2 * XIMG, base + 2 * XIMG + DIMG, pj * PD + c8 * 16, rda[P]);
+        if (do_xbias) {
+#pragma unroll
+            for (int r = 0; r <= FR; ++r) {
+                const int j = pjx + L::PPR * r;
+                if (j >= 1 && j <= IS * KP && (r < FR || (wave == 0 && pjx < L::XTAIL))) {
+                    const f32x4 a = __builtin_bit_cast(f32x4, rx[P][r][0]), c = __builtin_bit_cast(f32x4, rx[P][r][1]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bsum[e] += a[e]; bsum[4 + e] += c[e]; }
+                }
+            }
+        }
         if (do_bias) {
             const f32x4 a = __builtin_bit_cast(f32x4, rda[P][0]), c = __builtin_bit_cast(f32x4, rda[P][1]);
 #pragma unroll
@@ -233,6 +247,18 @@ __global__ __launch_bounds__(512) void wgrad_x3_krowg(const float *__restrict__ 
         }
     }
 
+    if (do_xbias) { // the PPR threads that share a channel group of the x tile
+        float *red = (float *)lds;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(pjx * L::UPP + c8x) * 8 + e] = bsum[e];
+        __syncthreads();
+        if (tid < BCI) {
+            float s = 0.f;
+            for (int r = 0; r < L::PPR; ++r) s += red[(r * L::UPP + (tid >> 3)) * 8 + (tid & 7)];
+            g.bias_part[((long long)split * IS + ky - 1) * g.CiP + ci0 + tid] = s;
+        }
+    }
+
     if (WKS == 2) { // the two waves of a (ci, co) position hold partial sums of the same outputs: fold them tap by tap through LDS
         float *red = (float *)lds;
         const int grp = wi * 2 + wj;
@@ -286,7 +312,8 @@ bool acg_wgrad_krowg_shape_ok(int K, int stride, int pad, int reflect, int Wi, i
 bool acg_wgrad_krowg_ok(const WGeom &g, const Taps &t)
 {
     const int K = t.n == 16 ? 4 : t.n == 9 ? 3 : 0;
-    if (g.thin || K == 0 || g.bias_from == 2 || g.CiP != g.Cin || g.CoP != g.Cg) return false;
+    if (g.thin || K == 0 || g.CiP != g.Cin || g.CoP != g.Cg) return false;
+    if (g.bias_from == 2 && (g.Hin != g.is * g.Hg || g.Win != g.is * g.Wg)) return false;   // x-side sums: every input pixel once
     if (!acg_wgrad_krowg_shape_ok(K, g.is, 1, g.reflect, g.Win, g.Wg, g.Cin, g.Cg) || g.m_per_split % g.Wg != 0) return false;
     for (int i = 0; i < t.n; ++i)
         if (t.dy[i] != i / K - 1 || t.dx[i] != i % K - 1) return false;
