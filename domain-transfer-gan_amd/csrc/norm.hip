@@ -511,6 +511,8 @@ static void launch_norm_apply(dim3 grid, hipStream_t st, const float *x, const f
     if (fmt) { // pre-split I/O: the combinations the residual trunk uses (ReLU; residual + bitmask, or neither)
         if (res && mask && fmt == 3) LA(ACG_ACT_RELU, true, true, 3);
         else if (res && fmt == 3) LA(ACG_ACT_RELU, true, false, 3);
+        else if (res && mask && fmt == 1) LA(ACG_ACT_RELU, true, true, 1);   // the LAST block of a trunk: residual pre-split, y fp32
+        else if (res && fmt == 1) LA(ACG_ACT_RELU, true, false, 1);
         else LA(ACG_ACT_RELU, false, false, 2);
         return;
     }
@@ -654,8 +656,8 @@ extern "C" int acg_norm_apply(const float *x, const float *mean, const float *rs
 {
     int rc = check_norm(G, P, C, "acg_norm_apply");
     if (rc) return rc;
-    ACG_REQUIRE(fmt == 0 || ((fmt == 2 || (fmt == 3 && res != nullptr)) && act == ACG_ACT_RELU && C % 8 == 0 && (mask == nullptr || res != nullptr)),
-                "acg_norm_apply: pre-split I/O (fmt %d) is implemented for ReLU with y pre-split and, if given, the residual too", fmt);
+    ACG_REQUIRE(fmt == 0 || ((fmt == 2 || ((fmt == 3 || fmt == 1) && res != nullptr)) && act == ACG_ACT_RELU && C % 8 == 0 && (mask == nullptr || res != nullptr)),
+                "acg_norm_apply: pre-split I/O (fmt %d) is implemented for ReLU: y pre-split (2), y and residual (3), residual only (1)", fmt);
     ACG_REQUIRE(gstride == 0 || (gstride >= C && gstride % 4 == 0), "acg_norm_apply: gstride must be 0 or a row stride >= C");
     ACG_REQUIRE(mask == nullptr || (res != nullptr && ((long long)P * (C / 4)) % 8 == 0 && (act == ACG_ACT_RELU || act == ACG_ACT_LRELU)),
                 "acg_norm_apply: the sign bitmask needs a residual, ReLU / LeakyReLU and P*C/4 %% 8 == 0");

@@ -333,11 +333,12 @@ def _act_of(m):
     return None
 
 
-def run_sequence(mods, x, C, z=None, res=None):
+def run_sequence(mods, x, C, z=None, res=None, last_block=False):
     """Interpret a reference-style layer list on an NHWC C16 tensor with peephole fusion:
          [ReflectionPad2d] Conv2d|ConvTranspose2d|MergeModule(conv, CondIN) [norm] [activation]
     `res`: residual input folded into the LAST norm of the list together with a ReLU
-    (ResnetBlock / CINResnetBlock: out = ReLU(x + conv_block(x)), modules.py:185-188, 232-235).
+    (ResnetBlock / CINResnetBlock: out = ReLU(x + conv_block(x)), modules.py:185-188, 232-235); `last_block`: no block
+    follows this one, so a pre-split block writes its output fp32 (what the layer behind the trunk reads).
     Returns (tensor, real channel count)."""
     i, n = 0, len(mods)
     last_norm = max([k for k, m in enumerate(mods) if isinstance(m, (InstanceNorm, CondInstanceNorm, BatchNorm2d))
@@ -349,7 +350,8 @@ def run_sequence(mods, x, C, z=None, res=None):
     # Pre-split ("S16") storage of the residual trunk (ops.S16Plan): the norm in front of the first block writes its
     # output pre-split when that block can take it, every tensor a 3x3 trunk convolution reads stays pre-split from there
     # (block outputs, conv + ReLU outputs, the gradients the norms and the fused data gradients write), and the first
-    # layer behind the last block gets it decoded.  s16 = this list is the inside of such a block.
+    # last block writes its output fp32 for the layer behind it (a block that cannot know it is last — called on its own —
+    # leaves a pre-split tensor, decoded here).  s16 = this list is the inside of such a block.
     s16 = res is not None and ops.is_s16(x)
     nconv = 0
     # ops.NormSums: a norm whose pre-split output goes to ONE trunk convolution (inside a block: the next convolution of the
@@ -363,7 +365,7 @@ def run_sequence(mods, x, C, z=None, res=None):
             i += 1
             continue
         if isinstance(m, (ResnetBlock, CINResnetBlock)):
-            x = m.forward_nhwc(x, z)
+            x = m.forward_nhwc(x, z, last=not (i + 1 < n and isinstance(mods[i + 1], (ResnetBlock, CINResnetBlock))))
             i += 1
             continue
         if res is None and ops.is_s16(x):
@@ -432,7 +434,7 @@ def run_sequence(mods, x, C, z=None, res=None):
                 raise NotImplementedError("residual fusion expects the block to end with its norm")
             # pre-split output: inside a pre-split block always (its consumer is a trunk convolution or the next block);
             # outside, when the next module is a block that can take it
-            emit = s16
+            emit = s16 and not (fuse_res and last_block)
             if not s16 and res is None and act == ACT_RELU and i < n and isinstance(mods[i], (ResnetBlock, CINResnetBlock)) \
                     and isinstance(norm, (InstanceNorm, CondInstanceNorm)):
                 emit = mods[i].s16_ok(x)
@@ -532,8 +534,8 @@ class CINResnetBlock(TwoInputModule):
     def s16_ok(self, x):
         return _block_s16_ok(self, x)
 
-    def forward_nhwc(self, x, z):
-        y, _ = run_sequence(list(self.conv_block._modules.values()), x, None, z, res=x)
+    def forward_nhwc(self, x, z, last=False):
+        y, _ = run_sequence(list(self.conv_block._modules.values()), x, None, z, res=x, last_block=last)
         return y
 
     def forward(self, x, noise):
@@ -560,8 +562,8 @@ class ResnetBlock(nn.Module):
     def s16_ok(self, x):
         return _block_s16_ok(self, x)
 
-    def forward_nhwc(self, x, z=None):
-        y, _ = run_sequence(list(self.conv_block._modules.values()), x, None, None, res=x)
+    def forward_nhwc(self, x, z=None, last=False):
+        y, _ = run_sequence(list(self.conv_block._modules.values()), x, None, None, res=x, last_block=last)
         return y
 
     def forward(self, x):

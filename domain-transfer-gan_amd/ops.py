@@ -788,8 +788,6 @@ class NormAct(torch.autograd.Function):
             mask = torch.empty((G * P * C + 31) // 32, device=x.device, dtype=torch.int32)
         # pre-split (S16) output for the convolution behind this norm; a residual that arrives tagged S16 is read that way
         fmt = (2 if s16_out else 0) | (1 if (res is not None and s16_res) else 0)
-        if fmt == 1:
-            raise _lib.AcgError("norm: a pre-split residual needs a pre-split output")
         _lib.call("acg_norm_apply", _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gp), _ptr(bp), gstride, _ptr(res), _ptr(y), _ptr(mask),
                   G, P, C, act, fmt, st)
         ctx.s16_dx = bool(s16_dx)
