@@ -158,7 +158,7 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
             if (++bt == taps.n) { bt = 0; bc0 += KC; }
         };
         static_assert(BL == 2, "the vmcnt immediates below count 2 * BL = 4 DMA pieces per stage");
-        f32x8 ra[ROWP ? 3 : AL]; // ROWP: up to 3 of the <= 160*4 patch units per thread
+        f32x8 ra[ROWP ? 3 : 2 * AL]; // ROWP: up to 3 of the <= 160*4 patch units per thread; else two stages of AL units in flight
         auto store_a = [&](int j, int a_at, __bf16 *As) {
             const float v[8] = {ra[j][0], ra[j][1], ra[j][2], ra[j][3], ra[j][4], ra[j][5], ra[j][6], ra[j][7]};
             acg_u32x4 hi, lo;
@@ -255,7 +255,8 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
             }
         } else {
             int st_t = 0, st_c0 = 0; // tap and first input channel of the next A stage to load
-            auto load_a_stage = [&]() {
+            auto load_a_stage = [&](auto PC) { // into register set PC::value
+                constexpr int P = decltype(PC)::value;
                 const int pk = tap_pk(st_t);
                 const int ty = (pk << 24) >> 24, tx = (pk << 16) >> 24;
 #pragma unroll
@@ -274,24 +275,36 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
                         ok = ok && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
                         pix = a_row[j] + ty * g.Win + tx;
                     }
-                    load_a(j, (unsigned)(pix * g.Cin + st_c0 + 8 * u) * 4u, ok);
+                    load_a(j + AL * P, (unsigned)(pix * g.Cin + st_c0 + 8 * u) * 4u, ok);
                 }
                 if (++st_t == taps.n) { st_t = 0; st_c0 += KC; }
             };
             static_assert(AL == 2, "the vmcnt immediates below count 2 * AL = 4 A loads per stage");
-            load_a_stage();
-            for (int s = 0; s < S; ++s) {
+            // A tiles travel TWO stages ahead in registers (set s & 1): a stage is 768 MFMA cycles per workgroup, shorter than the
+            // gather's latency — with one stage ahead the producers stood at the A wait every stage
+            const std::integral_constant<int, 0> c0;
+            const std::integral_constant<int, 1> c1;
+            load_a_stage(c0);
+            if (S > 1) load_a_stage(c1);
+            auto stage = [&](int s, auto PC) {
+                constexpr int P = decltype(PC)::value;
                 dma_b(s & 1);
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); // this stage's A tile (older than the DMA pieces)
+                // in flight, oldest first: A(s), A(s+1), the 4 DMA pieces of B(s)
+                if (s + 1 < S) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 #pragma unroll
-                for (int j = 0; j < AL; ++j) store_a(j, lds_at(u, rrow + RPP * j, APL), lds + L::a_off(s & 1));
-                if (s + 1 < S) {
-                    load_a_stage();
-                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); // the B pieces have landed; the next A tile stays in flight
+                for (int j = 0; j < AL; ++j) store_a(j + AL * P, lds_at(u, rrow + RPP * j, APL), lds + L::a_off(s & 1));
+                if (s + 2 < S) {
+                    load_a_stage(PC);
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); // the B pieces (and the older A(s+1)) have landed; A(s+2) stays in flight
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __syncthreads(); // buffers s&1 are full; the consumers have drained the others
+            };
+            for (int s = 0; s < S; s += 2) {
+                stage(s, c0);
+                if (s + 1 < S) stage(s + 1, c1);
             }
         }
         return;

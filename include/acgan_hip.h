@@ -221,7 +221,8 @@ int acg_norm_apply(const float *x, const float *mean, const float *rstd, const f
                    void *stream);
 /* fmt: 0 = fp32 tensors; bit 1 set: y is written pre-split (S16, see acg_s16_encode), bit 0 set: res is read pre-split
  * (fmt 2 or 3; ReLU, C % 8 == 0): the producer of a residual-block activation writes the operand form of the next
- * convolution once, instead of every convolution loader splitting it again. */
+ * convolution once, instead of every convolution loader splitting it again.  fmt 1 (res pre-split, y fp32) is the output
+ * norm of the LAST block of a trunk: the layer behind it reads fp32, so no acg_s16_decode pass is needed. */
 /* sign_mask (may be NULL; needs res, ReLU/LeakyReLU, P*C/4 % 8 == 0): ceil(G*P*C/32) words, bit e%32 of word e/32 =
  * (y[e] > 0).  acg_norm_bwd takes it in place of y: the backward of ReLU(x + IN(conv(..))) (modules.py:185-188, 232-235)
  * needs only the sign of y, and reads 1/32 of a tensor instead of the tensor, twice. */
