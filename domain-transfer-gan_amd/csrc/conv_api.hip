@@ -572,7 +572,8 @@ static int colsum_launch(const float *dy, long long M, int C, int Cr, float *db,
 // (16 channels per block, 16 split-lanes each, fixed-order tree: deterministic).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int nsplit, int KK, int CiP, int CoP, int Or,
                                     int Ir, float *__restrict__ dw, int thin, int accumulate, int wblocks,
-                                    const float *__restrict__ bias_part, int Cp, int Cr, float *__restrict__ db, int bias_slots)
+                                    const float *__restrict__ bias_part, int Cp, int Cr, float *__restrict__ db, int bias_slots,
+                                    int el_log2)
 {
     if ((int)blockIdx.x >= wblocks) {
         __shared__ float red[256];
@@ -589,22 +590,47 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
         if (threadIdx.x < 16 && c < Cr) db[c] = (accumulate ? db[c] : 0.f) + red[threadIdx.x];
         return;
     }
-    const long long total = (long long)KK * Ir * Or;
-    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    long long r = i;
-    const int o = (int)(r % Or); r /= Or;
-    const int ci = (int)(r % Ir); r /= Ir;
-    const int tap = (int)r;
-    float s = 0.f;
-    const long long stride = thin ? (long long)CiP * CoP : (long long)KK * CiP * CoP;
-    const float *p = thin == 2 ? part + ((long long)(tap * 4 + o)) * CoP + ci   // rows (tap, co), columns ci
-                   : thin == 1 ? part + ((long long)(tap * 4 + ci)) * CoP + o  // rows (tap, ci), columns co
-                               : part + ((long long)tap * CiP + ci) * CoP + o;
-#pragma unroll 8 // same summation order, eight loads in flight (the rolled loop paid one memory latency per split)
-    for (int k = 0; k < nsplit; ++k) s += p[k * stride];
-    float *dst = dw + ((long long)o * Ir + ci) * KK + tap;
-    *dst = (accumulate ? *dst : 0.f) + s;
+    // Weight part: a block is EL elements x (256 / EL) split-lanes; lane group kl sums the slabs k = kl, kl + KL, ... of its
+    // element (coalesced over the EL elements), the groups fold through LDS in fixed order: deterministic.  An element is four
+    // adjacent output channels where the layout allows (16-byte loads; the one-float-per-thread sequential version read a
+    // 50 MB trunk slab set at 3.8 TB/s, 128 launches = 1.7 ms per step), else one.  `el_log2` = 6 (64 elements x 4 lanes), or 4
+    // (16 x 16) when there are few elements and many slabs (the persistent thin-patch kernel leaves 768 of them).
+    __shared__ f32x4 red4[256];
+    const int EL = 1 << el_log2, KL = 256 >> el_log2;
+    const int el = threadIdx.x & (EL - 1), kl = threadIdx.x >> el_log2;
+    const bool quad = thin != 2 && (Or & 3) == 0 && (CoP & 3) == 0;
+    const int On = quad ? Or >> 2 : Or;
+    const long long total = (long long)KK * Ir * On;
+    const long long i = (long long)blockIdx.x * EL + el;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    int o = 0, ci = 0, tap = 0;
+    if (i < total) {
+        long long r = i;
+        o = (int)(r % On); r /= On;
+        ci = (int)(r % Ir); r /= Ir;
+        tap = (int)r;
+        const long long stride = thin ? (long long)CiP * CoP : (long long)KK * CiP * CoP;
+        const int oo = quad ? o * 4 : o;
+        const float *p = thin == 2 ? part + ((long long)(tap * 4 + oo)) * CoP + ci   // rows (tap, co), columns ci
+                       : thin == 1 ? part + ((long long)(tap * 4 + ci)) * CoP + oo  // rows (tap, ci), columns co
+                                   : part + ((long long)tap * CiP + ci) * CoP + oo;
+        if (quad) {
+#pragma unroll 4
+            for (int k = kl; k < nsplit; k += KL) sum += *(const f32x4 *)(p + k * stride);
+        } else {
+#pragma unroll 4
+            for (int k = kl; k < nsplit; k += KL) sum[0] += p[k * stride];
+        }
+    }
+    red4[threadIdx.x] = sum;
+    __syncthreads();
+    if (kl != 0 || i >= total) return;
+    for (int k = 1; k < KL; ++k) sum += red4[k * EL + el];
+    const int ne = quad ? 4 : 1;
+    for (int e = 0; e < ne; ++e) {
+        float *dst = dw + ((long long)((quad ? o * 4 : o) + e) * Ir + ci) * KK + tap;
+        *dst = (accumulate ? *dst : 0.f) + sum[e];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1372,10 +1398,13 @@ static int wgrad_common(const acg_conv_desc *d, const float *x_side, const float
     }
     if (rc) return rc;
     const int Cp = bias_from == 1 ? g.CoP : g.CiP, Cr = g.bias_from ? (bias_from == 1 ? Or : Ir) : 0;
-    const long long total = (long long)t.n * Ir * Or;
-    const int wblocks = acg_cdiv(total, 256);
+    const bool quad = g.thin != 2 && Or % 4 == 0 && g.CoP % 4 == 0;   // the kernel's four-channels-per-element path
+    const long long total = (long long)t.n * Ir * (quad ? Or / 4 : Or);
+    const int el_log2 = (total < 8192 && g.nsplit >= 64) ? 4 : 6;
+    const int wblocks = acg_cdiv(total, 1 << el_log2);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks + acg_cdiv(Cr, 16)), dim3(256), 0, st, (const float *)ws, g.nsplit,
-                       t.n, g.CiP, g.CoP, Or, Ir, dw, g.thin, accumulate, wblocks, (const float *)g.bias_part, Cp, Cr, db, bias_from == 2 ? g.nsplit * g.is : g.nsplit);
+                       t.n, g.CiP, g.CoP, Or, Ir, dw, g.thin, accumulate, wblocks, (const float *)g.bias_part, Cp, Cr, db,
+                       bias_from == 2 ? g.nsplit * g.is : g.nsplit, el_log2);
     ACG_CHECK_LAUNCH("wgrad_reduce_kernel");
     return ACG_OK;
 }
@@ -1415,8 +1444,10 @@ static int wgrad_thin_out(const acg_conv_desc *d, const float *x, const float *d
     int rc = acg_wgrad_launch(dy, x, (float *)ws, g, t, st);
     if (rc) return rc;
     const long long total = (long long)t.n * Ir * Or;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(acg_cdiv(total, 256)), dim3(256), 0, st, (const float *)ws, g.nsplit, t.n,
-                       g.CiP, g.CoP, Or, Ir, dw, 2, accumulate, acg_cdiv(total, 256), (const float *)nullptr, 0, 0, (float *)nullptr, 0);
+    const int el_log2 = (total < 8192 && g.nsplit >= 64) ? 4 : 6;
+    const int wblocks = acg_cdiv(total, 1 << el_log2);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wblocks), dim3(256), 0, st, (const float *)ws, g.nsplit, t.n,
+                       g.CiP, g.CoP, Or, Ir, dw, 2, accumulate, wblocks, (const float *)nullptr, 0, 0, (float *)nullptr, 0, el_log2);
     ACG_CHECK_LAUNCH("wgrad_reduce_kernel");
     return ACG_OK;
 }

@@ -18,7 +18,7 @@ for d in ("$R/gpurun_out/pmc_micro0", "$R/gpurun_out/pmc_micro1"):
     for f in glob.glob(d + "/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             k = r['Kernel_Name']
-            if 'igemm' in k or 'wgrad_f32' in k or 'wgrad_bf16' in k or 'wgrad_x3' in k or 'wgrad_reduce' in k:
+            if 'conv' in k or 'wgrad' in k:
                 agg[k.split('(')[0]][r['Counter_Name']].append(float(r['Counter_Value']))
                 agg[k.split('(')[0]]['dur_us'].append((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3)
 for k, v in agg.items():
