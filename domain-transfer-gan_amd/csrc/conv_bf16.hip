@@ -451,6 +451,7 @@ int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, fl
                     "igemm_conv_x3_ws: per-tile statistics of a phased launch");
         return acg_igemm_x3_ws_launch(in, wp, bias, out, g0, t, n_w_elems, st, g0.stats);
     }
+    if (split && acg_conv_rows_ok(g0, t)) return acg_conv_rows_launch(in, wp, bias, out, g0, t, n_w_elems, st);   // persistent row pipeline
     if (split && acg_conv_patchn_ok(g0, t))   // C4 output: the N-packed weights sit behind the regular hi + lo images
         return acg_conv_patchn_launch(in, (const __bf16 *)wp + 2 * n_w_elems, bias, out, g0, t, st);
     static const bool no_patch = acg_debug_switch("ACG_NO_PATCH"); // A/B switch

@@ -129,6 +129,10 @@ int acg_igemm_x3_pre_launch(const void *in, const void *wp, const float *bias, f
 bool acg_conv_patch16_ok(const Geom &g, const Taps &t);
 int acg_conv_patch16_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g, const Taps &t,
                             long long n_w_elems, hipStream_t st);
+// conv_rows.hip: persistent row pipeline for the full-resolution 3x3 stride-1 32 -> 64 channel layers
+bool acg_conv_rows_ok(const Geom &g, const Taps &t);
+int acg_conv_rows_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g, const Taps &t,
+                         long long n_w_elems, hipStream_t st);
 bool acg_conv_patchn_ok(const Geom &g, const Taps &t);   // ... with C4 output and N-packed weights (conv_patchn_x3)
 int acg_conv_patchn_launch(const float *in, const void *wn, const float *bias, float *out, const Geom &g, const Taps &t, hipStream_t st);
 bool acg_conv_thinrow_ok(const Geom &g, const Taps &t);  // C4 gathered tensor -> 32 channels, one K step per kernel row (conv_thinrow_x3)

@@ -63,6 +63,10 @@ CONV_CASES = [
     (3, 1, 1, "reflect", 64, 32, 2, 4, 128),
     (3, 1, 1, "zero", 64, 32, 2, 20, 128),       # several splits
     (3, 1, 1, "reflect", 32, 64, 1, 5, 256),
+    # persistent row pipeline (conv_rows.hip): zero-padded 3x3, 32 gathered -> 64 written channels, 128-pixel bands; forward of a
+    # 32 -> 64 layer (two bands, two row chunks per band, an odd chunk) and the data gradient of a 64 -> 32 layer
+    (3, 1, 1, "zero", 32, 64, 2, 21, 256),
+    (3, 1, 1, "zero", 64, 32, 1, 17, 128),
 ]
 
 
@@ -653,7 +657,8 @@ def test_stride2_phases_in_one_tile_match_the_fp32_kernels():
                                   ("conv", 32, 32, 3, 1, 32, 32), ("conv", 16, 32, 3, 2, 64, 64), ("conv", 32, 32, 3, 1, 8, 16),
                                   ("conv", 64, 128, 3, 2, 32, 32), ("convT", 128, 64, 3, 2, 32, 32), ("convT", 64, 32, 3, 2, 16, 32),
                                   ("convT", 128, 64, 3, 2, 8, 128),   # four phases in one tile (conv_ph4.hip)
-                                  ("stem", 3, 32, 7, 1, 24, 48)])       # C4 image -> 32 channels, 8 x 16 pixel tiles (conv_thinrow_x3)
+                                  ("stem", 3, 32, 7, 1, 24, 48),        # C4 image -> 32 channels, 8 x 16 pixel tiles (conv_thinrow_x3)
+                                  ("conv0", 32, 64, 3, 1, 21, 256)])    # zero padding: the persistent row pipeline (conv_rows_x3)
 def test_conv_epilogue_statistics_equal_the_statistics_pass(case):
     """Per-tile (mean, M2) from the convolution epilogues (generic bf16 tile, wave-specialised tile, the four phase launches
     of ConvTranspose2d) merged by acg_norm_stats_from_partials against acg_norm_stats on the stored output: the mean / rstd
@@ -680,8 +685,8 @@ def test_conv_epilogue_statistics_equal_the_statistics_pass(case):
             y2 = torch.empty_like(y)
             _lib.call("acg_conv2d_fwd", ctypes.byref(d), P(x), P(pk.wf), P(pk.bias), P(y2), 0, st)
             C = Co
-        elif kind == "conv":
-            d = ops.conv_desc(NB, H, W, Ci, Co, K, stride, 1, 1 if stride == 1 else 0, Ci, Co)
+        elif kind in ("conv", "conv0"):
+            d = ops.conv_desc(NB, H, W, Ci, Co, K, stride, 1, 1 if (stride == 1 and kind == "conv") else 0, Ci, Co)
             x = t(rs.normal(0.3, 1, (NB, H, W, Ci)))
             w = t(rs.normal(0, 0.2, (Co, Ci, K, K))); b = t(rs.normal(0, 1, Co))
             pk = ops.PackedConv(w, b, Ci, Co)
@@ -689,6 +694,8 @@ def test_conv_epilogue_statistics_equal_the_statistics_pass(case):
             assert _lib.query("acg_conv2d_fwd_stats_supported", ctypes.byref(d))
             part = torch.zeros((NB, d.Ho * d.Wo // 128, 2, Co), device="cuda")
             _lib.call("acg_conv2d_fwd_stats", ctypes.byref(d), P(x), P(pk.wf), P(pk.bias), P(y), P(part), st)
+            if kind == "conv0":
+                assert _lib.query("acg_last_kernel").decode().startswith("conv_rows_x3")
             y2 = torch.empty_like(y)
             _lib.call("acg_conv2d_fwd", ctypes.byref(d), P(x), P(pk.wf), P(pk.bias), P(y2), 0, st)
             C = Co
