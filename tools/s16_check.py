@@ -147,10 +147,10 @@ def run(N, H, W, C, time_it, iters):
             wait, work = raw[:, :4, 0], raw[:, :4, 1]
             print("%s consumer stamps: loop cycles per wave %.0f, barrier wait share %.1f %% (by wave %s)"
                   % (name, (wait + work).mean(), 100 * wait.sum() / (wait + work).sum(), np.round(100 * (wait / (wait + work)).mean(0), 1)))
-            ebuf = (ctypes.c_ulonglong * nwg)()
-            assert _lib.load().acg_debug_pre_epi(ebuf, nwg) == 0
-            epi = np.frombuffer(ebuf, dtype=np.uint64).astype(np.float64)
-            print("%s tile: set-up %.0f cycles (entry -> first stage), loop %.0f, epilogue %.0f" % (name, raw[:, :4, 2].mean(), (wait + work).mean(), epi.mean()))
+            ebuf = (ctypes.c_ulonglong * (nwg * 4))()   # acg_debug_pre_tile: (set-up, loop, epilogue, start time) per tile — see
+            assert _lib.load().acg_debug_pre_tile(ebuf, nwg * 4) == 0   # tools/dgrad_stamps.py for the per-launch-kind table
+            epi = np.frombuffer(ebuf, dtype=np.uint64).reshape(nwg, 4).astype(np.float64)
+            print("%s tile: set-up %.0f cycles (entry -> first stage), loop %.0f, epilogue %.0f" % (name, np.median(epi[:, 0]), np.median(epi[:, 1]), np.median(epi[:, 2])))
             pr = raw[:, 4:, :]
             tot = pr.sum(-1).mean()
             print("%s producer stamps: loop cycles per wave %.0f: issuing %.1f %%, waiting for the pieces to land %.1f %%, at the barrier %.1f %%"
