@@ -4,14 +4,15 @@
 // The generic tile (conv_bf16.hip) spends these layers' time on latency chains, not on bytes or MFMAs: a 128-pixel tile lives
 // three short stages, each of which loads its operands (74 KB of packed weights per tile among them), waits, splits, stores,
 // barriers and only then multiplies, with three workgroups per CU to hide it all behind: 0.31 ms for 805 MB and 77 GFLOP.
-// Here ONE 512-thread workgroup per CU walks down a 128-pixel-wide column band of an image, one output row per step:
+// Here ONE 768-thread workgroup per CU walks down a 128-pixel-wide column band of an image, one output row per step:
 //   * the packed weights of all nine taps (74 KB hi + lo) are copied into LDS once and stay there;
 //   * consecutive output rows share two of their three input rows: a ring of four row images (130 pixels x 32 channels,
 //     bf16 hi / lo planes of 8 channels) keeps them in LDS, so every input row is fetched ONCE per band — by the four
 //     producer waves, two rows ahead in registers (loads of row r+4 are in flight while row r+2 is split and stored);
-//   * the four consumer waves (32 pixels x 64 channels each) only read fragments and issue MFMAs: the weights are the
-//     MFMA A operand and the pixels the B operand, so a lane ends up with four consecutive CHANNELS of one pixel — its output
-//     leaves as 16-byte stores straight from the accumulators, no staging;
+//   * eight consumer waves (32 pixels x 32 channels each, two per SIMD: one alone cannot hide its LDS round trips behind its
+//     own MFMAs — 0.155 ms for 0.092 ms of MFMAs without anything else running) only read fragments and issue MFMAs: the
+//     weights are the MFMA A operand and the pixels the B operand, so a lane ends up with four consecutive CHANNELS of one
+//     pixel — its output leaves as 16-byte stores straight from the accumulators, no staging;
 //   * one raw s_barrier per row (lgkmcnt only): global loads and stores stay in flight across it.
 #include "common.h"
 #include "conv_internal.h"
@@ -37,7 +38,7 @@ __device__ __forceinline__ int rw_plane_off(int u) { return u * RW_PLANE + (u >>
 typedef __attribute__((address_space(3))) char lds_char;
 }
 
-__global__ __launch_bounds__(512) void conv_rows_x3(const float *__restrict__ in, const __bf16 *__restrict__ wp,
+__global__ __launch_bounds__(768) void conv_rows_x3(const float *__restrict__ in, const __bf16 *__restrict__ wp,
                                                     const float *__restrict__ bias, float *__restrict__ out, Geom g,
                                                     unsigned long long slabs, unsigned in_bytes, long long w_lo_elems, int R, int cpb, int abl)
 {
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(512) void conv_rows_x3(const float *__restrict__ in
     int rows = H - y0;
     rows = rows < R ? rows : R;           // output rows of this workgroup (> 0: the launcher sizes cpb that way)
     auto row_barrier = [&]() {
+        if (abl & 8) return;   // (timing ablation: no row barriers — wrong results)
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS traffic is done; vector memory stays in flight
         __builtin_amdgcn_s_barrier();
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(512) void conv_rows_x3(const float *__restrict__ in
     };
 
     // ---- the weights: [tap = ky * 3 + kx][plane][column][8], from the packed slabs [slab][Cin / 16][64][16] (hi, then lo)
-    for (int q = tid; q < 2 * 9 * 4 * 64; q += 512) {
+    for (int q = tid; q < 2 * 9 * 4 * 64; q += 768) {
         const int lo = q / (9 * 4 * 64), r = q - lo * (9 * 4 * 64);
         const int tap = r >> 8, plane = (r >> 6) & 3, col = r & 63;
         const int slab = (int)((slabs >> (4 * tap)) & 15ull);
@@ -69,9 +71,9 @@ __global__ __launch_bounds__(512) void conv_rows_x3(const float *__restrict__ in
         *(u32x4 *)(Wl + lo * RW_WIMG + ((tap * 4 + plane) * 64 + col) * 16) = *(const u32x4 *)(wp + e);
     }
 
-    if (wave >= 4) {
+    if (wave >= 8) {
         // ------------------------------------------------------------------------------------------------ producers
-        const int pt = tid - 256;
+        const int pt = tid - 512;
         const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, in_bytes, 0x00020000);
         u32x4 rx[2][RW_UPT][2];
         int u_px[RW_UPT], u_pl[RW_UPT];
@@ -142,19 +144,20 @@ __global__ __launch_bounds__(512) void conv_rows_x3(const float *__restrict__ in
     // ---------------------------------------------------------------------------------------------------- consumers
     __builtin_amdgcn_s_setprio(2);
     const int kg = lane >> 4, li = lane & 15;
-    const lds_char *wfrag = (const lds_char *)Wl + (kg * 64 + li) * 16;                                  // + tap * 4096 + cb * 256 (+ RW_WIMG)
-    const lds_char *pfrag = (const lds_char *)Al + rw_plane_off(kg) + (wave * 32 + li) * 16;             // + slot + pb * 256 + kx * 16 (+ RW_IMG)
-    f32x4 bv[4];
+    const int pw = wave & 3, ch = wave >> 2;     // pixels 32 pw .. + 31, channels 32 ch .. + 31 (column blocks 2 ch, 2 ch + 1)
+    const lds_char *wfrag = (const lds_char *)Wl + (kg * 64 + ch * 32 + li) * 16;                        // + tap * 4096 + cb * 256 (+ RW_WIMG)
+    const lds_char *pfrag = (const lds_char *)Al + rw_plane_off(kg) + (pw * 32 + li) * 16;               // + slot + pb * 256 + kx * 16 (+ RW_IMG)
+    f32x4 bv[2];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
+    for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bv[cb][r] = bias != nullptr ? bias[cb * 16 + 4 * kg + r] : 0.f;
+        for (int r = 0; r < 4; ++r) bv[cb][r] = bias != nullptr ? bias[(ch * 2 + cb) * 16 + 4 * kg + r] : 0.f;
     const int act = __builtin_amdgcn_readfirstlane(g.act);
-    // Fragments of tap t + 1 are read while the 24 MFMAs of tap t issue (two register sets, set = parity of the running tap
-    // count): one consumer wave per SIMD has nobody to hide its LDS latency behind.  The first tap of the NEXT row reads input
-    // row j, which is already in the ring, so the chain carries across the row barrier.
+    // Fragments of tap t + 1 are read while the 12 MFMAs of tap t issue (two register sets, set = parity of the running tap
+    // count).  The first tap of the NEXT row reads input row j, which is already in the ring, so the chain carries across
+    // the row barrier.
     typedef const __attribute__((address_space(3))) bf16x8 *frag_ptr;
-    bf16x8 ph[2][2], pl[2][2], wh[2][4], wl[2][4];
+    bf16x8 ph[2][2], pl[2][2], wh[2][2], wl[2][2];
     auto frags = [&](auto SC, int j, int tap) {   // row j, tap = ky * 3 + kx (compile-time after unrolling) into set SC
         constexpr int S = decltype(SC)::value;
         const int ky = tap / 3, kx = tap - ky * 3;
@@ -166,20 +169,20 @@ __global__ __launch_bounds__(512) void conv_rows_x3(const float *__restrict__ in
             pl[S][pb] = *(frag_ptr)(prow + RW_IMG + pb * 256 + kx * 16);
         }
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
+        for (int cb = 0; cb < 2; ++cb) {
             wh[S][cb] = *(frag_ptr)(wt + cb * 256);
             wl[S][cb] = *(frag_ptr)(wt + RW_WIMG + cb * 256);
         }
     };
-    f32x4 acc[4][2];
+    f32x4 acc[2][2];
     float *const stats = g.stats;
-    f32x4 sm1[4], sm2[4];
+    f32x4 sm1[2], sm2[2];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) sm1[cb] = sm2[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int cb = 0; cb < 2; ++cb) sm1[cb] = sm2[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     auto mfmas = [&](auto SC) {
         constexpr int S = decltype(SC)::value;
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+        for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb) {
                 acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[S][cb], ph[S][pb], acc[cb][pb], 0, 0, 0);
@@ -192,15 +195,12 @@ __global__ __launch_bounds__(512) void conv_rows_x3(const float *__restrict__ in
     auto row = [&](int j, auto PC) {   // PC: parity of the running tap count at the row's first tap
         constexpr int P = decltype(PC)::value;
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+        for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb) acc[cb][pb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            // The 12 fragment reads of tap t + 1 are ISSUED between the 24 MFMAs of tap t, one read per two MFMAs (scheduling
-            // groups): issued as a block in front of them they took as long as the MFMAs themselves — four waves saturate the
-            // LDS port, a wave stands at the issue of its reads — and the two phases alternated instead of overlapping
-            // (ablations: reads alone 79 us, MFMAs alone 92 us, both 171 us).
+            // the 8 fragment reads of tap t + 1 are ISSUED between the 12 MFMAs of tap t (scheduling groups)
             if (((t + P) & 1) == 0) {
                 if (t < 8) frags(s1, j, t + 1); else frags(s1, j + 1, 0);
                 mfmas(s0);
@@ -209,27 +209,29 @@ __global__ __launch_bounds__(512) void conv_rows_x3(const float *__restrict__ in
                 mfmas(s1);
             }
 #pragma unroll
-            for (int q = 0; q < 12; ++q) {
+            for (int q = 0; q < 4; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (stats != nullptr) {   // (wave-uniform) running sums of the bias-free outputs and of their squares: see the end
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
+            for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                 for (int pb = 0; pb < 2; ++pb) {
                     sm1[cb] += acc[cb][pb];
                     sm2[cb] += acc[cb][pb] * acc[cb][pb];
                 }
         }
-        // lane: pixel li of pixel block pb, channels cb * 16 + 4 kg .. + 3 (64 bytes per pixel from the four lanes that share li)
-        float *orow = out + (((long long)n * g.Hout + y0 + j) * g.Wout + x0 + wave * 32 + li) * 64 + 4 * kg;
+        // lane: pixel li of pixel block pb, channels (2 ch + cb) * 16 + 4 kg .. + 3 (16 bytes; 64 per pixel from the four lanes that share li)
+        float *orow = out + (((long long)n * g.Hout + y0 + j) * g.Wout + x0 + pw * 32 + li) * 64 + ch * 32 + 4 * kg;
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
+            for (int cb = 0; cb < 2; ++cb) {
                 f32x4 v = acc[cb][pb] + bv[cb];
                 if (act != ACG_ACT_NONE) {   // (wave-uniform; these layers are followed by a norm or are data gradients: rarely taken)
 #pragma unroll
@@ -249,11 +251,11 @@ __global__ __launch_bounds__(512) void conv_rows_x3(const float *__restrict__ in
     // Statistics for the InstanceNorm behind the layer (acg_conv2d_fwd_stats: one (mean, M2) entry per 128-pixel tile, merged
     // by Chan's formula with 128 pixels each).  The workgroup owns `rows` tiles of every channel: it forms their JOINT mean
     // and M2 — sums of the bias-free outputs (the bias is the pivot) over the lanes' 2 x rows values, the 16 lanes of a
-    // channel quad, the four waves — and writes the SAME entry (mean, M2 / rows) for each of its tiles: equal means add no
-    // between-tile term, so the merge reproduces the joint statistics exactly.  No per-row cross-lane work, no extra barrier
-    // in the loop (the producers have left; a barrier now counts the four consumer waves).
+    // channel quad, the four waves of a channel half — and writes the SAME entry (mean, M2 / rows) for each of its tiles: equal
+    // means add no between-tile term, so the merge reproduces the joint statistics exactly.  No per-row cross-lane work, no
+    // extra barrier in the loop (the producers have left; a barrier now counts the eight consumer waves).
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
+    for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -261,14 +263,14 @@ __global__ __launch_bounds__(512) void conv_rows_x3(const float *__restrict__ in
                 sm1[cb][r] += __shfl_xor(sm1[cb][r], m);
                 sm2[cb][r] += __shfl_xor(sm2[cb][r], m);
             }
-    float *red = (float *)Al;   // [wave][2][64]: the ring is no longer read for results (the last prefetch is discarded)
+    float *red = (float *)Al;   // [pixel quarter][2][64]: the ring is no longer read for results (the last prefetch is discarded)
     if (li == 0) {
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+        for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                red[(wave * 2 + 0) * 64 + cb * 16 + 4 * kg + r] = sm1[cb][r];
-                red[(wave * 2 + 1) * 64 + cb * 16 + 4 * kg + r] = sm2[cb][r];
+                red[(pw * 2 + 0) * 64 + (ch * 2 + cb) * 16 + 4 * kg + r] = sm1[cb][r];
+                red[(pw * 2 + 1) * 64 + (ch * 2 + cb) * 16 + 4 * kg + r] = sm2[cb][r];
             }
     }
     row_barrier();
@@ -336,7 +338,7 @@ int acg_conv_rows_launch(const float *in, const void *wp, const float *bias, flo
     cpb = (g.GH + R - 1) / R;
     const long long blocks = nimg * bands * cpb;
     static const int abl = getenv("ACG_ROWS_ABL") && acg_debug_switch("ACG_ROWS_ABL") ? atoi(getenv("ACG_ROWS_ABL")) : 0;   // timing ablations
-    hipLaunchKernelGGL(conv_rows_x3, dim3((unsigned)blocks), dim3(512), 0, st, in, (const __bf16 *)wp, bias, out, g, slabs,
+    hipLaunchKernelGGL(conv_rows_x3, dim3((unsigned)blocks), dim3(768), 0, st, in, (const __bf16 *)wp, bias, out, g, slabs,
                        (unsigned)in_bytes, n_w_elems, R, (int)cpb, abl);
     ACG_CHECK_LAUNCH("conv_rows_x3");
     acg_note_kernel("conv_rows_x3<32,64> (%d rows per workgroup)", R);
