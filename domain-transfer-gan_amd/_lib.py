@@ -89,6 +89,8 @@ SIGNATURES = {
     "acg_conv2d_bwd_data_s16_mask": (c_int, [_D, _P, _P, _P, _P, c_size_t, _P, _P]),
     "acg_conv2d_bwd_data_s16_sums_supported": (c_int, [_D]),
     "acg_conv2d_bwd_data_s16_sums": (c_int, [_D, _P, _P, _P, _P, c_size_t, _P, _P, ctypes.POINTER(NormSumsDesc), _P]),
+    "acg_conv2d_bwd_data_sums_supported": (c_int, [_D]),
+    "acg_conv2d_bwd_data_sums": (c_int, [_D, _P, _P, _P, _P, c_size_t, ctypes.POINTER(NormSumsDesc), _P]),
     "acg_conv2d_bwd_weight_s16": (c_int, [_D, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
     "acg_conv2d_bwd_weight_workspace_bytes": (c_size_t, [_D]),
     "acg_conv2d_bwd_weight": (c_int, [_D, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
@@ -142,7 +144,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 113   # include/acgan_hip.h ACG_VERSION this binding was written against
+ABI_VERSION = 114   # include/acgan_hip.h ACG_VERSION this binding was written against
 
 
 class AcgError(RuntimeError):

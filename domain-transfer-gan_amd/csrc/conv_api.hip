@@ -922,8 +922,8 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
             }
             return acg_igemm_x3_pre_launch(src, wb, bias, dst, g, t, g.w_elems, st);
         }
-        ACG_REQUIRE(ns == nullptr && relu_mask == nullptr,
-                    "dgrad: norm sums / a sign bitmask as the ReLU source need the un-padded pre-split path (query acg_conv2d_bwd_data_s16_sums_supported)");
+        ACG_REQUIRE((ns == nullptr || (!refl && !in_s16 && !out_s16 && addend == nullptr && relu_src == nullptr)) && relu_mask == nullptr,
+                    "dgrad: norm sums / a sign bitmask as the ReLU source need the un-padded pre-split path or the row pipeline (query acg_conv2d_bwd_data_s16_sums_supported / acg_conv2d_bwd_data_sums_supported)");
         t.n = 0;
         // zero pad: dy row = iy + p - kh ; reflect (padded grid): dy row = py - kh
         const int base = refl ? 0 : p;
@@ -945,6 +945,12 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
             g.out_s16 = out_s16; g.relu_s16 = relu_s16;
             rc = acg_igemm_x3_pre_launch(src, wb, bias, out, g, t, g.w_elems, st);
         } else {
+            if (ns != nullptr) {   // fp32 operands: only the persistent row pipeline (conv_rows.hip) emits the norm-backward sums
+                g.ns_x = ns->x; g.ns_mean = ns->mean; g.ns_rstd = ns->rstd; g.ns_gamma = ns->gamma; g.ns_beta = ns->beta;
+                g.ns_gstride = ns->gstride; g.ns_mask = ns->sign_mask; g.ns_act = ns->act; g.ns_part = ns->part;
+                ACG_REQUIRE(ns->part != nullptr && !thin_in_valu_dgrad(d) && acg_conv_rows_ok(g, t),
+                            "dgrad: norm sums on fp32 operands need the row-pipeline geometry (query acg_conv2d_bwd_data_sums_supported)");
+            }
             rc = thin_in_valu_dgrad(d) ? thin_out_launch(src, wb, bias, out, g, t, st) : acg_igemm_launch(src, wb, bias, out, g, t, st);
         }
         if (rc != ACG_OK) return rc;
@@ -1249,6 +1255,26 @@ extern "C" int acg_conv2d_bwd_data_s16_sums(const acg_conv_desc *d, const void *
     ACG_REQUIRE(ns->sign_mask == nullptr || ((long long)d->Hi * d->Wi * (d->Ci / 4)) % 8 == 0, "acg_conv2d_bwd_data_s16_sums: bitmask layout");
     return dgrad_igemm(d, (const float *)dy, wb, nullptr, dx, ACG_ACT_NONE, ws, ws_bytes, (hipStream_t)stream, addend, nullptr,
                        addend_mask, 1, 0, 0, nullptr, ns);
+}
+
+// The same on fp32 operands, where the data gradient runs on the persistent row pipeline (conv_rows_x3: zero-padded 3x3 stride 1,
+// 32 output and 64 input channels of the convolution, width a multiple of 128): part[N][Hi*Wi/128][2][Ci], summed over the
+// chunks by acg_norm_bwd_partials like the pre-split kernel's (the sums of a workgroup's rows sit in its first chunk)
+extern "C" int acg_conv2d_bwd_data_sums_supported(const acg_conv_desc *d)
+{
+    if (d == nullptr || g_acg_precision != ACG_PREC_BF16X3 || g_acg_conv_impl != ACG_IMPL_MFMA || acg_debug_switch("ACG_NO_ROWS")) return 0;
+    if (check_desc(d, "acg_conv2d_bwd_data_sums_supported") != ACG_OK) return 0;
+    return d->K == 3 && d->stride == 1 && d->pad == 1 && d->pad_mode != ACG_PAD_REFLECT && d->Co == 32 && d->Ci == 64 && d->Hi == d->Ho &&
+           d->Wi == d->Wo && d->Wi % 128 == 0 ? 1 : 0;
+}
+
+extern "C" int acg_conv2d_bwd_data_sums(const acg_conv_desc *d, const float *dy, const float *wb, float *dx, void *ws, size_t ws_bytes,
+                                        const acg_norm_sums *ns, void *stream)
+{
+    int rc = check_desc(d, "acg_conv2d_bwd_data_sums");
+    if (rc) return rc;
+    ACG_REQUIRE(ns != nullptr && ns->sign_mask == nullptr && acg_conv2d_bwd_data_sums_supported(d), "acg_conv2d_bwd_data_sums: unsupported shape or mode");
+    return dgrad_igemm(d, dy, wb, nullptr, dx, ACG_ACT_NONE, ws, ws_bytes, (hipStream_t)stream, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, ns);
 }
 
 // x and dy pre-split; dw / db fp32 as in acg_conv2d_bwd_weight (db = column sums of dy, produced by the same launch)

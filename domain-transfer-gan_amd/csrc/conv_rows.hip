@@ -43,6 +43,7 @@ __global__ __launch_bounds__(768) void conv_rows_x3(const float *__restrict__ in
                                                     unsigned long long slabs, unsigned in_bytes, long long w_lo_elems, int R, int cpb, int abl)
 {
     __shared__ __attribute__((aligned(256))) char lds[RW_LDS];
+    __shared__ __attribute__((aligned(16))) float ptab[64 * 4];   // norm sums: (mean, rstd, gamma, beta) of the 64 channels of image n
     char *const Wl = lds, *const Al = lds + 2 * RW_WIMG;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bands = g.GW / RW_PX;
@@ -69,6 +70,12 @@ __global__ __launch_bounds__(768) void conv_rows_x3(const float *__restrict__ in
         const int slab = (int)((slabs >> (4 * tap)) & 15ull);
         const long long e = (long long)lo * w_lo_elems + (((long long)slab * 2 + (plane >> 1)) * 64 + col) * 16 + (plane & 1) * 8;
         *(u32x4 *)(Wl + lo * RW_WIMG + ((tap * 4 + plane) * 64 + col) * 16) = *(const u32x4 *)(wp + e);
+    }
+
+    if (g.ns_part != nullptr && tid < 64) {
+        const bool aff = g.ns_act != ACG_ACT_NONE;
+        const int go = g.ns_gstride * n + tid;   // (gstride 0: shared affine parameters)
+        *(f32x4 *)&ptab[tid * 4] = (f32x4){g.ns_mean[n * 64 + tid], g.ns_rstd[n * 64 + tid], aff ? g.ns_gamma[go] : 1.f, aff ? g.ns_beta[go] : 1.f};
     }
 
     if (wave >= 8) {
@@ -176,6 +183,13 @@ __global__ __launch_bounds__(768) void conv_rows_x3(const float *__restrict__ in
     };
     f32x4 acc[2][2];
     float *const stats = g.stats;
+    // norm-backward sums (acg_conv2d_bwd_data_sums): this launch's output is the gradient w.r.t. the OUTPUT of a norm (+ ReLU)
+    // whose input is ns_x; the first pass of that norm's backward — sum gy and sum gy * xhat per channel, gy = dx * act'(y) —
+    // accumulates beside the statistics' registers (a launch has one or the other) and leaves like them, once per workgroup
+    const float *const nsx = g.ns_x;
+    const bool sums = g.ns_part != nullptr;
+    const int ns_relu = g.ns_act == ACG_ACT_RELU;
+    f32x4 xv[2][2];
     f32x4 sm1[2], sm2[2];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) sm1[cb] = sm2[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -194,6 +208,13 @@ __global__ __launch_bounds__(768) void conv_rows_x3(const float *__restrict__ in
     const std::integral_constant<int, 1> s1;
     auto row = [&](int j, auto PC) {   // PC: parity of the running tap count at the row's first tap
         constexpr int P = decltype(PC)::value;
+        const long long oidx = (((long long)n * g.Hout + y0 + j) * g.Wout + x0 + pw * 32 + li) * 64 + ch * 32 + 4 * kg;
+        if (sums) {   // the norm input at this lane's output positions: in flight under the row's MFMAs
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) xv[cb][pb] = *(const f32x4 *)(nsx + oidx + pb * 16 * 64 + cb * 16);
+        }
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -226,8 +247,24 @@ __global__ __launch_bounds__(768) void conv_rows_x3(const float *__restrict__ in
                     sm2[cb] += acc[cb][pb] * acc[cb][pb];
                 }
         }
+        if (sums) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const f32x4 pr = *(const f32x4 *)&ptab[((ch * 2 + cb) * 16 + 4 * kg + r) * 4];   // mean, rstd, gamma, beta
+#pragma unroll
+                    for (int pb = 0; pb < 2; ++pb) {
+                        const float xh = (xv[cb][pb][r] - pr[0]) * pr[1];
+                        const float v = acc[cb][pb][r] + bv[cb][r];
+                        const float gy = (ns_relu && !(xh * pr[2] + pr[3] > 0.f)) ? 0.f : v;   // same expression as norm_apply_kernel
+                        sm1[cb][r] += gy;
+                        sm2[cb][r] += gy * xh;
+                    }
+                }
+        }
         // lane: pixel li of pixel block pb, channels (2 ch + cb) * 16 + 4 kg .. + 3 (16 bytes; 64 per pixel from the four lanes that share li)
-        float *orow = out + (((long long)n * g.Hout + y0 + j) * g.Wout + x0 + pw * 32 + li) * 64 + ch * 32 + 4 * kg;
+        float *orow = out + oidx;
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
@@ -247,7 +284,7 @@ __global__ __launch_bounds__(768) void conv_rows_x3(const float *__restrict__ in
         row(j, s0);                       // nine taps: the next row starts on the other set
         if (j + 1 < rows) row(j + 1, s1);
     }
-    if (stats == nullptr) return;
+    if (stats == nullptr && !sums) return;
     // Statistics for the InstanceNorm behind the layer (acg_conv2d_fwd_stats: one (mean, M2) entry per 128-pixel tile, merged
     // by Chan's formula with 128 pixels each).  The workgroup owns `rows` tiles of every channel: it forms their JOINT mean
     // and M2 — sums of the bias-free outputs (the bias is the pivot) over the lanes' 2 x rows values, the 16 lanes of a
@@ -279,6 +316,14 @@ __global__ __launch_bounds__(768) void conv_rows_x3(const float *__restrict__ in
         float a = 0.f, q = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) { a += red[(w * 2 + 0) * 64 + c]; q += red[(w * 2 + 1) * 64 + c]; }
+        if (sums) {   // additive: the workgroup's sums go to its first tile's entry, zeros to the others (acg_norm_bwd_partials adds them up)
+            for (int j = 0; j < rows; ++j) {
+                float *o = g.ns_part + (((long long)n * H * bands + (long long)(y0 + j) * bands + band) * 2) * 64 + c;
+                o[0] = j == 0 ? a : 0.f;
+                o[64] = j == 0 ? q : 0.f;
+            }
+            return;
+        }
         const float cnt = (float)rows * RW_PX;
         const float mu = a / cnt;
         const float m2 = (q - a * mu) / (float)rows;      // this tile's share of sum (x - mean)^2
@@ -314,6 +359,9 @@ bool acg_conv_rows_ok(const Geom &g, const Taps &t)
     static const bool off = acg_debug_switch("ACG_NO_ROWS"); // A/B switch
     if (off || g_acg_precision != ACG_PREC_BF16X3 || g_acg_conv_impl != ACG_IMPL_MFMA || g.thin || g.nphase || g.fold_p) return false;
     if (g.stats != nullptr && (g.act != ACG_ACT_NONE || g.stats_chunk0 != 0 || (long long)g.stats_cpi * 128 != (long long)g.GH * g.GW)) return false;
+    if (g.ns_part != nullptr && (g.stats != nullptr || g.ns_x == nullptr || g.ns_mask != nullptr || (g.ns_act != ACG_ACT_NONE && g.ns_act != ACG_ACT_RELU) ||
+                                 (g.ns_gstride != 0 && g.ns_gstride < 64)))
+        return false;
     if (g.reflect || g.addend || g.relu_src || g.out_s16 || g.unpad || g.is != 1 || g.os != 1 || g.oy0 || g.ox0) return false;
     if (g.Cin != 32 || g.Cout != 64 || g.ncols_pad != 64) return false;
     if (g.GH != g.Hin || g.GW != g.Win || g.GH != g.Hout || g.GW != g.Wout || g.GW % RW_PX != 0 || g.GH < 1) return false;

@@ -8,6 +8,8 @@ activation in one kernel; norm + activation (+ residual add) in one pass).
 """
 import functools  # noqa: F401  (kept: reference modules export it implicitly via networks)
 
+import ctypes
+
 import torch
 import torch.nn as nn
 from torch.nn.parameter import Parameter
@@ -88,6 +90,15 @@ class Conv2d(nn.Conv2d, _Cached):
             if s16.y:
                 ops.tag_s16(out[0] if want_identity else out)
         return out
+
+    def dgrad_sums_ok(self, x):
+        """does this (zero-padded) convolution's data gradient, for an NHWC input of x's shape, emit the backward sums of a norm
+        in front of it (acg_conv2d_bwd_data_sums: the persistent row pipeline)?"""
+        pk = self.packed()
+        if x.dim() != 4 or x.shape[-1] != pk.Cis:
+            return False
+        d = ops.conv_desc(x.shape[0], x.shape[1], x.shape[2], pk.Cis, pk.Cos, pk.K, self.stride[0], self.padding[0], PAD_ZERO, pk.Ir, pk.Or)
+        return bool(ops._lib.query("acg_conv2d_bwd_data_sums_supported", ctypes.byref(d)))
 
     def forward(self, input):
         return ops.ToNCHW.apply(self.forward_nhwc(ops.ToNHWC.apply(input, True)), self.out_channels)
@@ -420,7 +431,11 @@ def run_sequence(mods, x, C, z=None, res=None, last_block=False):
                 if nconv == 0 and not skip_here:
                     raise NotImplementedError("pre-split trunk: the block's first layer must be its first convolution")
             nconv += 1
-            ns_conv, ns_prev = (ns_prev if (plan is not None and (skip_here or nconv > 1)) else None), None
+            # (outside the trunk: a norm + ReLU whose output goes to this convolution alone left its slot on the tensor — taken
+            # where the data gradient runs on the row pipeline, acg_conv2d_bwd_data_sums_supported)
+            if plan is None and res is None and ns_prev is None:
+                ns_prev = getattr(x, "_acg_ns", None)
+            ns_conv, ns_prev = (ns_prev if ((plan is not None and (skip_here or nconv > 1)) or (plan is None and res is None)) else None), None
             x = conv.forward_nhwc(x, cact, reflect, stats, skip_here, link_out, link_in, skip_grad if skip_here else None, plan,
                                   ns_conv)
             if skip_here:  # the skip connection continues from the conv's identity output: its gradient is added
@@ -438,12 +453,17 @@ def run_sequence(mods, x, C, z=None, res=None, last_block=False):
             if not s16 and res is None and act == ACT_RELU and i < n and isinstance(mods[i], (ResnetBlock, CINResnetBlock)) \
                     and isinstance(norm, (InstanceNorm, CondInstanceNorm)):
                 emit = mods[i].s16_ok(x)
+            # outside the trunk: the next layer is a zero-padded convolution whose data gradient (the gradient w.r.t. this norm's
+            # output) can leave the norm's backward sums (ops.NormSums on fp32 tensors)
+            rows_ns = (not s16 and res is None and not emit and ops.NORM_SUMS and act in (ACT_NONE, ACT_RELU) and i < n
+                       and isinstance(mods[i], Conv2d) and isinstance(norm, (InstanceNorm, CondInstanceNorm))
+                       and mods[i].dgrad_sums_ok(x))
             if isinstance(norm, CondInstanceNorm):
                 if fuse_res:
                     raise NotImplementedError("residual after CondInstanceNorm")
                 if s16 and act != ACT_RELU:
                     raise NotImplementedError("pre-split trunk: CondInstanceNorm without ReLU")
-                ns_prev = ops.NormSums() if emit else None
+                ns_prev = ops.NormSums() if (emit or rows_ns) else None
                 x = norm.forward_act(x, z, act, stats.part if stats is not None else None, emit, s16, ns_prev)
                 if ns_prev is not None:
                     x._acg_ns = ns_prev
@@ -452,7 +472,7 @@ def run_sequence(mods, x, C, z=None, res=None, last_block=False):
                 # convolution's data-gradient epilogue and nowhere else -> it may stay un-materialised (ops.NormAct lazy_dres)
                 if s16 and not (fuse_res and skip_routed):
                     raise NotImplementedError("pre-split trunk: InstanceNorm that is not the block output")
-                ns_prev = ops.NormSums() if emit else None
+                ns_prev = ops.NormSums() if (emit or rows_ns) else None
                 x = norm.forward_act(x, ACT_RELU if fuse_res else act, res if fuse_res else None,
                                      skip_grad if (fuse_res and skip_routed) else None, stats.part if stats is not None else None,
                                      emit, s16, ns_prev)

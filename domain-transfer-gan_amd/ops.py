@@ -500,7 +500,7 @@ class Conv2dFn(torch.autograd.Function):
         ctx.link_out, ctx.link_in = (link_out if act == ACT_RELU else None), link_in
         ctx.skip_grad = skip_grad
         ctx.s16 = s16 if (s16 is not None and s16.x) else None
-        ctx.norm_sums = norm_sums if (NORM_SUMS and ctx.s16 is not None) else None
+        ctx.norm_sums = norm_sums if NORM_SUMS else None
         ctx.save_for_backward(x, y if (act != ACT_NONE and ctx.s16 is None) else None)
         if want_identity:
             return y, x.view_as(x)
@@ -544,6 +544,15 @@ class Conv2dFn(torch.autograd.Function):
                 _fused("dgrad_relu_link")
                 _lib.call("acg_conv2d_bwd_data_relu", ctypes.byref(d), _ptr(g), _ptr(pk.wb), _ptr(x), _ptr(dx), _ptr(ws), nb, st)
                 ctx.link_in.done = True
+            elif (dskip is None and ctx.norm_sums is not None and ctx.norm_sums.x is not None and ctx.norm_sums.mask is None and
+                  tuple(ctx.norm_sums.x.shape) == tuple(dx.shape) and _lib.query("acg_conv2d_bwd_data_sums_supported", ctypes.byref(d))):
+                # dx is the gradient w.r.t. the output of the norm in front: the row pipeline leaves that norm's backward sums
+                ns = ctx.norm_sums
+                part = torch.empty((d.N, (d.Hi * d.Wi) // STATS_ROWS, 2, d.Ci), device=dx.device, dtype=torch.float32)
+                desc = ns.desc(part)
+                _fused("dgrad_rows_norm_sums")
+                _lib.call("acg_conv2d_bwd_data_sums", ctypes.byref(d), _ptr(g), _ptr(pk.wb), _ptr(dx), _ptr(ws), nb, ctypes.byref(desc), st)
+                ns.part, ns.dx = part, dx
             else:
                 _lib.call("acg_conv2d_bwd_data", ctypes.byref(d), _ptr(g), _ptr(pk.wb), _ptr(dx), _ptr(ws), nb, st)
                 if dskip is not None:

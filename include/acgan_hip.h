@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ACG_VERSION 113
+#define ACG_VERSION 114
 
 typedef enum {
     ACG_OK = 0,
@@ -166,6 +166,11 @@ int acg_conv2d_bwd_data_s16_sums_supported(const acg_conv_desc *d);
 int acg_conv2d_bwd_data_s16_sums(const acg_conv_desc *d, const void *dy_s16, const float *wb, float *dx, void *ws,
                                  size_t ws_bytes, const float *addend, const unsigned *addend_sign_mask,
                                  const acg_norm_sums *ns, void *stream);
+/* ... and on fp32 operands where the data gradient runs on the persistent row pipeline (zero-padded 3x3 stride 1, Co == 32,
+ * Ci == 64, Wi % 128 == 0): ns->sign_mask must be NULL (the activation mask is recomputed from ns->x) */
+int acg_conv2d_bwd_data_sums_supported(const acg_conv_desc *d);
+int acg_conv2d_bwd_data_sums(const acg_conv_desc *d, const float *dy, const float *wb, float *dx, void *ws, size_t ws_bytes,
+                             const acg_norm_sums *ns, void *stream);
 /* conv + ReLU with S16 output that also stores (y > 0) as a sign bitmask (layout of acg_norm_apply's: bit e % 32 of word e / 32
  * for float index e; Co % 32 == 0), and the S16-output data gradient of the convolution BEHIND it masked by that bitmask
  * instead of by the sign of its S16 input (where acg_conv2d_bwd_data_s16_sums_supported(d)): the pad-conv-ReLU-pad-conv chain
