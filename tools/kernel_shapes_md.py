@@ -13,7 +13,11 @@ def main():
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(src)):
-        name = re.sub(r"\(.*", "", r["Kernel_Name"])[:80]
+        name = r["Kernel_Name"]
+        mz = re.match(r"_Z(\d+)", name)   # left mangled by rocprofv3: keep the function name
+        if mz:
+            name = name[mz.end():mz.end() + int(mz.group(1))]
+        name = re.sub(r"\(.*", "", name)[:80]
         wg = int(r["Workgroup_Size_X"])
         agg[(name, int(r["Grid_Size_X"]) // wg, wg)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     rows = sorted(agg.items(), key=lambda kv: -sum(kv[1]))

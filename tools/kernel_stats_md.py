@@ -7,6 +7,9 @@ import sys
 
 
 def short(name):
+    m = re.match(r"_Z(\d+)", name)            # a name rocprofv3 left mangled (its demangler stops at __bf16 parameters of plain functions)
+    if m:
+        name = name[m.end():m.end() + int(m.group(1))]
     name = re.sub(r"\(.*", "", name)          # drop the argument list
     return name[:95]
 

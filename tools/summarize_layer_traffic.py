@@ -8,6 +8,7 @@ The microbenchmark brackets every (layer, pass) segment with pad_vector_kernel l
 (HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced
 streaming read (x2); WRITE_SIZE is exact."""
 import csv
+import re
 import glob
 import json
 import os
@@ -46,7 +47,10 @@ def main():
         iters = 3
         fetch = sum(float(r["Counter_Value"]) for r in res["FETCH_SIZE"][i]) / iters * 1024.0
         write = sum(float(r["Counter_Value"]) for r in res["WRITE_SIZE"][i]) / iters * 1024.0
-        kernels = sorted(set(r["Kernel_Name"].split("(")[0][:80] for r in res["FETCH_SIZE"][i]))
+        def kname(k):   # (names rocprofv3 left mangled: the function name)
+            m = re.match(r"_Z(\d+)", k)
+            return k[m.end():m.end() + int(m.group(1))] if m else k.split("(")[0][:80]
+        kernels = sorted(set(kname(r["Kernel_Name"]) for r in res["FETCH_SIZE"][i]))
         hbm = 2.0 * fetch + write
         rows.append(dict(layer=seg["layer"], what=seg["what"], ms=round(seg["ms"], 4),
                          algorithmic_bytes=seg["algorithmic_bytes"], stored_bytes=seg["stored_bytes"],
