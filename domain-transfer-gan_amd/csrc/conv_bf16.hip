@@ -446,6 +446,10 @@ int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, fl
         if (g.reflect) launch_bf16_kc<KCV, true, SP>(bn, grid, st, in, w, bias, out, g, t, inb, wb, wlo);   \
         else launch_bf16_kc<KCV, false, SP>(bn, grid, st, in, w, bias, out, g, t, inb, wb, wlo);            \
     } while (0)
+    // only the row pipeline (and the pre-split trunk kernels, which do not come through here) emits norm-backward sums: a launch
+    // that asked for them must not land on a kernel that ignores Geom.ns_part (the caller's `part` buffer is uninitialised)
+    ACG_REQUIRE(g0.ns_part == nullptr || (split && !acg_igemm_uses_ws(g0) && acg_conv_rows_ok(g0, t)),
+                "igemm_conv_bf16: norm-backward sums requested on a geometry the row pipeline does not take");
     if (acg_igemm_uses_ws(g0)) {
         ACG_REQUIRE(g0.stats == nullptr || (g0.stats_chunk0 == 0 && g0.stats_cpi == (int)(((long long)g0.GH * g0.GW) / 128)),
                     "igemm_conv_x3_ws: per-tile statistics of a phased launch");

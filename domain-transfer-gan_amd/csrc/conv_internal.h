@@ -126,6 +126,11 @@ bool acg_igemm_uses_ws(const Geom &g);
 bool acg_igemm_x3_pre_ok(const Geom &g, const Taps &t);
 int acg_igemm_x3_pre_launch(const void *in, const void *wp, const float *bias, float *out, const Geom &g, const Taps &t,
                             long long n_w_elems, hipStream_t st, float *stats = nullptr);
+// conv_x3_pp.hip: its persistent form (one workgroup per CU walks over its tiles; the epilogue of a tile is drained by two
+// dedicated waves during the next tile's loop)
+bool acg_igemm_x3_pp_ok(const Geom &g, const Taps &t);
+int acg_igemm_x3_pp_launch(const void *in, const void *wp, const float *bias, float *out, const Geom &g, const Taps &t,
+                           long long n_w_elems, hipStream_t st, float *stats = nullptr);
 bool acg_conv_patch16_ok(const Geom &g, const Taps &t);
 int acg_conv_patch16_launch(const float *in, const void *wp, const float *bias, float *out, const Geom &g, const Taps &t,
                             long long n_w_elems, hipStream_t st);

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(768) void conv_rows_x3(const float *__restrict__ in
 #pragma unroll
             for (int k = 0; k < RW_UPT; ++k) {
                 if (k == RW_UPT - 1 && pt + 256 * k >= RW_UNITS) continue;   // (wave-uniform for whole waves past the end)
-                const unsigned off = (unsigned)((((n * H + iy) * W + x0 - 1 + u_px[k]) * 32 + 8 * u_pl[k]) * 4);
+                const unsigned off = ((unsigned)((n * H + iy) * W + x0 - 1 + u_px[k]) * 32u + 8u * (unsigned)u_pl[k]) * 4u;   // (in_bytes < 4 GiB: unsigned arithmetic)
                 const unsigned o = acg_masked_off(off, rowok && u_ok[k]);
                 rx[P][k][0] = __builtin_amdgcn_raw_buffer_load_b128(rin, o, 0, 0);
                 rx[P][k][1] = __builtin_amdgcn_raw_buffer_load_b128(rin, o, 16, 0);

@@ -683,6 +683,7 @@ int acg_igemm_x3_pre_launch(const void *in, const void *wp, const float *bias, f
 {
     Geom g = g0;
     g.thin = 0;
+    if (acg_igemm_x3_pp_ok(g, t)) return acg_igemm_x3_pp_launch(in, wp, bias, out, g, t, n_w_elems, st, stats);   // the persistent form
     int kdim = 0, dxmin = 0, kstep = 1;
     ACG_REQUIRE(acg_igemm_x3_pre_ok(g, t) && pre_rowp(g, t, &kdim, &dxmin, &kstep), "igemm_conv_x3_pre: unsupported geometry");
     dim3 grid(acg_cdiv(g.Mtot, BM) * (g.ncols_pad / BN));

@@ -377,6 +377,7 @@ def run_sequence(mods, x, C, z=None, res=None, last_block=False):
             continue
         if isinstance(m, (ResnetBlock, CINResnetBlock)):
             x = m.forward_nhwc(x, z, last=not (i + 1 < n and isinstance(mods[i + 1], (ResnetBlock, CINResnetBlock))))
+            ns_prev = None   # (the slot of the norm in front of the trunk belongs to the first block's first convolution)
             i += 1
             continue
         if res is None and ops.is_s16(x):

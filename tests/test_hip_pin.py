@@ -219,8 +219,9 @@ def test_trunk_at_bench_geometry_matches_the_oracle(kind, prec):
         assert "acg_conv2d_fwd_s16" in ents and "acg_conv2d_bwd_weight_s16" in ents and "acg_conv2d_bwd_data_s16_sums" in ents, ents
         if kind == "plain":
             assert "acg_conv2d_fwd_s16_mask" in ents and "acg_conv2d_bwd_data_s16_mask" in ents, ents
-        assert any(k.startswith("igemm_conv_x3_pre<REFLECT=1") for k in kerns), kerns
-        assert any("SUMS=1" in k for k in kerns), kerns
+        # (igemm_conv_x3_pre, or its persistent form igemm_conv_x3_pp where that is dispatched: conv_x3_pp.hip)
+        assert any(k.startswith("igemm_conv_x3_pre<REFLECT=1") or k.startswith("igemm_conv_x3_pp<REFLECT=1") for k in kerns), kerns
+        assert any("SUMS" in k for k in kerns), kerns
         assert "wgrad_x3_krow_s16" in kerns, kerns
         # the norm in front of the first block, the first block's output norm, and in a CINResnetBlock its conditional norm
         assert used == (2 if kind == "plain" else 4), used
@@ -288,7 +289,7 @@ def test_presplit_kernels_at_bench_geometry_match_the_oracle():
         y = torch.empty((N, H, W, Cn), device="cuda")
         part = torch.empty((N, H * W // 128, 2, Cn), device="cuda")
         _lib.call("acg_conv2d_fwd_s16", D, P(xs), P(pk.wf), P(pk.bias), P(y), 0, P(part), 0, st)
-        assert _lib.query("acg_last_kernel").decode().startswith("igemm_conv_x3_pre<REFLECT=1,STATS=1")
+        assert _lib.query("acg_last_kernel").decode() in ("igemm_conv_x3_pp<REFLECT=1,STATS>", "igemm_conv_x3_pre<REFLECT=1,STATS=1>")
         assert rel(nchw(n(y)), yo.v) < 2e-5, "forward"
         yt = nhwc(yo.v).reshape(N, H * W // 128, 128, Cn)
         assert rel(n(part)[:, :, 0], yt.mean(2)) < 1e-5 and rel(n(part)[:, :, 1], ((yt - yt.mean(2, keepdims=True)) ** 2).sum(2)) < 1e-4, "tile statistics"
@@ -311,7 +312,7 @@ def test_presplit_kernels_at_bench_geometry_match_the_oracle():
         ns.x, ns.mean, ns.rstd, ns.gamma, ns.beta, ns.gstride = P(xn_t), P(mean_t), P(rstd_t), None, None, 0
         ns.sign_mask, ns.act, ns.part = P(nb_t), ops.ACT_RELU, P(psum)
         _lib.call("acg_conv2d_bwd_data_s16_sums", D, P(dys), P(pk.wb), P(dx), P(ws), nbw, P(skip_t), P(sb_t), ctypes.byref(ns), st)
-        assert "SUMS=1" in _lib.query("acg_last_kernel").decode()
+        assert _lib.query("acg_last_kernel").decode() in ("igemm_conv_x3_pp<REFLECT=0,SUMS>", "igemm_conv_x3_pre<REFLECT=0,STATS=0,SUMS=1>")
         dx_o = X.g + skip * skip_bits
         assert rel(nchw(n(dx)), dx_o) < 2e-5, "data gradient + masked skip addend"
         gy = nhwc(dx_o * norm_bits).reshape(N, H * W // 128, 128, Cn)
@@ -327,6 +328,65 @@ def test_presplit_kernels_at_bench_geometry_match_the_oracle():
                   _lib.query("acg_conv2d_bwd_weight_workspace_bytes", D), 0, st)
         assert _lib.query("acg_last_kernel").decode() == "wgrad_x3_krow_s16"
         assert rel(n(dw), Wt.g) < 1e-4 and rel(n(db), Bt.g) < 1e-4, "weight / bias gradient"
+
+
+@pytest.mark.parametrize("case", ["relu_shared", "none_shared", "relu_per_sample"])
+def test_row_pipeline_data_gradient_sums_match_the_oracle(case):
+    """acg_conv2d_bwd_data_sums (conv_rows_x3: the fp32-operand twin of the trunk's ..._s16_sums) through the C ABI at N = 2,
+    64 -> 32 channels, 21 x 256 (21 rows: two row chunks per (image, band), an odd last chunk; two 128-pixel bands): the data
+    gradient against the oracle's convolution adjoint (2e-5) and the sums of the norm in front of the layer — S1 = sum gy,
+    S2 = sum gy * xhat with gy = dx * [norm output > 0] (modules.py:83-97 behind networks.py:183) — against fp64 (1e-4), with
+    `part` pre-filled with NaN (every chunk entry has to be written), ReLU and no activation, shared (gstride 0) and
+    per-sample (gstride 64) affine parameters."""
+    import ctypes
+    from dtgan_amd import ops, _lib
+    from hip_util import precision, t, n, rel
+    P = ops._ptr
+    N, H, W, Ci, Co = 2, 21, 256, 64, 32
+    rs = np.random.RandomState(11)
+    w = rs.normal(0, 0.06, (Co, Ci, 3, 3))
+    dy = rs.normal(0, 1e-2, (N, Co, H, W))
+    xn = rs.normal(0.2, 1.1, (N, Ci, H, W))                       # the input of the norm whose output this layer reads
+    mean = rs.normal(0.2, 0.1, (N, Ci)); rstd = rs.uniform(0.6, 1.4, (N, Ci))
+    per_sample = case == "relu_per_sample"
+    act = ops.ACT_NONE if case == "none_shared" else ops.ACT_RELU
+    gamma = rs.normal(1.0, 0.4, (N if per_sample else 1, Ci)); beta = rs.normal(0.0, 0.5, (N if per_sample else 1, Ci))
+    nhwc = lambda a: np.ascontiguousarray(np.transpose(a, (0, 2, 3, 1)))
+    nchw = lambda a: np.transpose(a, (0, 3, 1, 2))
+    with precision("bf16x3"):
+        st = ops._stream()
+        d = ops.conv_desc(N, H, W, Ci, Co, 3, 1, 1, 0, Ci, Co)
+        D = ctypes.byref(d)
+        assert _lib.query("acg_conv2d_bwd_data_sums_supported", D)
+        pk = ops.PackedConv(t(w), t(np.zeros(Co)), Ci, Co)
+        # oracle: adjoint of the zero-padded 3x3 convolution for the gradient dy
+        X, Wt = leaf(np.zeros((N, Ci, H, W))), leaf(w)
+        backward(oops.conv2d(X, Wt, None, pad=1), seed=dy.astype(np.float32).astype(np.float64))
+        xh = (xn.astype(np.float32).astype(np.float64) - mean[:, :, None, None]) * rstd[:, :, None, None]
+        g_b = np.broadcast_to(gamma, (N, Ci))[:, :, None, None]; b_b = np.broadcast_to(beta, (N, Ci))[:, :, None, None]
+        live = (xh * g_b + b_b > 0) if act == ops.ACT_RELU else np.ones_like(xh, dtype=bool)
+        # (units whose norm output is within rounding of zero may fall on either side in fp32: leave them out of the sums' bar)
+        edge = (np.abs(xh * g_b + b_b) < 1e-5) if act == ops.ACT_RELU else np.zeros_like(live)
+        gy = X.g * live
+        nbw = _lib.query("acg_conv2d_bwd_data_workspace_bytes", D)
+        ws = ops.workspace(max(nbw, 1))
+        dx = torch.full((N, H, W, Ci), float("nan"), device="cuda")
+        nch = H * W // 128
+        psum = torch.full((N, nch, 2, Ci), float("nan"), device="cuda")
+        ns = _lib.NormSumsDesc()
+        xn_t, mean_t, rstd_t, g_t, b_t = t(nhwc(xn)), t(mean.reshape(-1)), t(rstd.reshape(-1)), t(gamma.reshape(-1)), t(beta.reshape(-1))
+        ns.x, ns.mean, ns.rstd, ns.gamma, ns.beta = P(xn_t), P(mean_t), P(rstd_t), P(g_t), P(b_t)
+        ns.gstride, ns.sign_mask, ns.act, ns.part = (Ci if per_sample else 0), None, act, P(psum)
+        _lib.call("acg_conv2d_bwd_data_sums", D, P(t(nhwc(dy))), P(pk.wb), P(dx), P(ws), nbw, ctypes.byref(ns), st)
+        assert _lib.query("acg_last_kernel").decode().startswith("conv_rows_x3<32,64>")
+        assert rel(nchw(n(dx)), X.g) < 2e-5, "data gradient"
+        got = n(psum)
+        assert np.isfinite(got).all(), "a chunk entry of the sums was not written"
+        s1, s2 = got[:, :, 0].sum(1), got[:, :, 1].sum(1)          # acg_norm_bwd_partials adds the chunk entries up
+        assert edge.mean() < 1e-4
+        gy_k = nchw(n(dx)).astype(np.float64) * live              # the kernel's own dx under the oracle's mask: isolates the sums
+        assert rel(s1, gy_k.sum((2, 3))) < 1e-4 and rel(s2, (gy_k * xh).sum((2, 3))) < 1e-4, "norm backward sums (kernel dx)"
+        assert rel(s1, gy.sum((2, 3))) < 2e-4 and rel(s2, (gy * xh).sum((2, 3))) < 2e-4, "norm backward sums (oracle dx)"
 
 
 # ---------------------------------------------------------------------------------------------------------------------
