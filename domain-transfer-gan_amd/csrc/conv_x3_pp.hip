@@ -33,6 +33,15 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef PP_DMA_SPLIT
 #define PP_DMA_SPLIT 1
 #endif
+#ifndef PP_DRAIN_DELAY
+#define PP_DRAIN_DELAY 0   // s_sleep units (64 cycles) between a stage's barrier and the drain's slice
+#endif
+#ifndef PP_A_DELAY
+#define PP_A_DELAY 0       // ... and the row-patch DMA issue
+#endif
+#ifndef PP_DRAIN_PRIO
+#define PP_DRAIN_PRIO 0
+#endif
 #ifndef PP_N1
 #define PP_N1 9      // fragment reads of the next stage issued beside the first twelve MFMAs (the rest beside the next ones)
 #endif
@@ -66,6 +75,11 @@ extern "C" int acg_debug_pp_stamps(unsigned long long *host, size_t n)
 {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pp_stamps), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
+__device__ unsigned long long g_pp_hist[256 * 36];         // [workgroup][stage of the tile]: cycles between barrier exits, MFMA wave 0, summed over tiles
+extern "C" int acg_debug_pp_hist(unsigned long long *host, size_t n)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pp_hist), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
 #endif
 
 template <bool REFLECT, int MODE>
@@ -98,7 +112,8 @@ igemm_conv_x3_pp(const char *__restrict__ in, const __bf16 *__restrict__ wp, con
     };
     if (nt == 0) return;
 #ifdef ACG_STAMP
-    unsigned long long st_wait = 0, st_work = 0, st_t = __builtin_amdgcn_s_memtime();
+    unsigned long long st_wait = 0, st_work = 0, st_t = __builtin_amdgcn_s_memtime(), hist_t = 0;
+    if (tid < 36 && blockIdx.x < 256) g_pp_hist[blockIdx.x * 36 + tid] = 0;
 #define PP_STAMP(acc) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - st_t; st_t = t_; }
 #define PP_STAMP_END() if (lane == 0 && blockIdx.x < 256) { g_pp_stamps[(blockIdx.x * 14 + wave) * 4] = st_wait; g_pp_stamps[(blockIdx.x * 14 + wave) * 4 + 1] = st_work; }
 #else
@@ -205,6 +220,13 @@ igemm_conv_x3_pp(const char *__restrict__ in, const __bf16 *__restrict__ wp, con
                         PP_STAMP(st_work)
                         bar();                               // barrier of stage s: stage s+1 is complete in LDS, everybody has
                         PP_STAMP(st_wait)                    // read stage s into registers (its B buffer is free)
+#ifdef ACG_STAMP
+                        if (wave == 0 && lane == 0 && blockIdx.x < 256 && S == 36) {
+                            const int sidx = (it * 6 + k + 35) % 36;   // the stage that just ended
+                            if (tk > 0 || it * 6 + k > 0) g_pp_hist[blockIdx.x * 36 + sidx] += st_t - hist_t;
+                            hist_t = st_t;
+                        }
+#endif
                         // The weight tile of stage s+3.  Issuing a DMA piece stalls the wave for 60-185 cycles: the OLDER wave of a
                         // SIMD (waves 0-3) issues at the head of the stage, while its partner feeds the matrix pipe; the partner
                         // issues in the middle, behind its first twelve MFMAs
@@ -352,6 +374,7 @@ igemm_conv_x3_pp(const char *__restrict__ in, const __bf16 *__restrict__ wp, con
                     PP_STAMP(st_wait)
                     if (k % 3 == 2) {
                         // every MFMA wave has read the last stage of the row two back: its buffer takes the row after next
+                        if (PP_A_DELAY > 0) __builtin_amdgcn_s_sleep(PP_A_DELAY);
                         if (a_rr == rows) { a_rr = 0; ++a_k; if (a_k < nt) geom(a_k); }
                         if (a_k < nt && !(abl & 8)) dma_a(a_rr, k / 3);
                         ++a_rr;
@@ -367,6 +390,7 @@ igemm_conv_x3_pp(const char *__restrict__ in, const __bf16 *__restrict__ wp, con
 
     // ---------------------------------------------------------------------------------------------------- drain waves
     {
+        __builtin_amdgcn_s_setprio(PP_DRAIN_PRIO);
         const int dt = tid - 512;             // 0 .. 255
         float *const T = (float *)(lds + A_BYTES + B_BYTES);
         float *const red = (float *)(lds + A_BYTES + B_BYTES + T_BYTES);   // [2][256]
@@ -417,6 +441,8 @@ igemm_conv_x3_pp(const char *__restrict__ in, const __bf16 *__restrict__ wp, con
         f32x4 bias8a = z4, bias8b = z4;
         if (bias != nullptr && MODE == PP_S16) { bias8a = *(const f32x4 *)(bias + c8 * 8); bias8b = *(const f32x4 *)(bias + c8 * 8 + 4); }
         u32x4 sv[3] = {zu, zu, zu};
+        float pv8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // an item between its two halves
+        f32x4 pv4 = z4;
 
         // one slice of the drain per stage.  tl: the tile being drained (valid if `live`); tn: the tile to drain next (valid if
         // `next`: its first loads go out here); s = 12 m + K, K at compile time
@@ -450,40 +476,52 @@ igemm_conv_x3_pp(const char *__restrict__ in, const __bf16 *__restrict__ wp, con
                 }
             }
             if (MODE == PP_S16) {
+                // item u in two halves, so that no stage carries a whole item: stage 4 u + 2 reads the tile, applies bias,
+                // activation and the ReLU sign; stage 4 u + 3 forms the sign bitmask and the pre-split halves and stores them
                 if (K % 4 == 2) {
-                    // stage 4 ul - 2: the sign source of item ul (of the next tile to drain in stage 34) into slot ul % 3
-                    constexpr int SLOT = ((K + 2) / 4) % 3;
-                    const int ul = (s + 2) >> 2;          // 1 .. 9
-                    const bool nx = ul == 9 && next, on = (ul < 8 && live) || nx;
-                    const unsigned boff = (unsigned)((nx ? tn : tl) * BM + rg16 + 16 * (nx ? 0 : ul)) * (unsigned)(g.Cout * 4) + (unsigned)c8 * 32u;
-                    u32x4 v = zu;
-                    if (g.relu_mask != nullptr) v[0] = __builtin_amdgcn_raw_buffer_load_b32(r_rm, acg_masked_off((boff >> 7) << 2, on && sd), 0, 0);
-                    else v = __builtin_amdgcn_raw_buffer_load_b128(r_rs, acg_masked_off(boff, on && sd), 0, 0);
-                    sv[SLOT] = v;
+                    {   // first half of item u = (s - 2) / 4 from sign slot u % 3
+                        constexpr int SLOT = ((K - 2) / 4) % 3;
+                        const int u = s >> 2;
+                        const u32x4 sg = sv[SLOT];
+                        const int row = rg16 + 16 * (u & 7);
+                        const f32x4 t0 = *(const f32x4 *)&T[t_at(row, 2 * c8)] + bias8a, t1 = *(const f32x4 *)&T[t_at(row, 2 * c8 + 1)] + bias8b;
+                        float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = acg_apply_act(v[q], act);
+                        if (g.relu_mask != nullptr && sd) {
+                            const unsigned bits = sg[0] >> (8 * (c8 & 3));
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) v[q] = (bits >> q) & 1u ? v[q] : 0.f;
+                        } else if (g.relu_src != nullptr && sd) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const unsigned a = sg[q] & 0xffffu, b = sg[q] >> 16;
+                                v[2 * q] = (a - 1u) < 0x7fffu ? v[2 * q] : 0.f;         // positive, non-zero bf16
+                                v[2 * q + 1] = (b - 1u) < 0x7fffu ? v[2 * q + 1] : 0.f;
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) pv8[q] = v[q];
+                    }
+                    {   // stage 4 ul - 2: the sign source of item ul (of the next tile to drain in stage 34) into slot ul % 3
+                        constexpr int SLOT = ((K + 2) / 4) % 3;
+                        const int ul = (s + 2) >> 2;          // 1 .. 9
+                        const bool nx = ul == 9 && next, on = ((ul < 8 && live) || nx) && !(abl & 64);
+                        const unsigned boff = (unsigned)((nx ? tn : tl) * BM + rg16 + 16 * (nx ? 0 : ul)) * (unsigned)(g.Cout * 4) + (unsigned)c8 * 32u;
+                        u32x4 v = zu;
+                        if (g.relu_mask != nullptr) v[0] = __builtin_amdgcn_raw_buffer_load_b32(r_rm, acg_masked_off((boff >> 7) << 2, on && sd), 0, 0);
+                        else v = __builtin_amdgcn_raw_buffer_load_b128(r_rs, acg_masked_off(boff, on && sd), 0, 0);
+                        sv[SLOT] = v;
+                    }
                 } else if (K % 4 == 3) {
-                    // stage 4 u + 3: item u from slot u % 3
-                    constexpr int SLOT = (K / 4) % 3;
+                    // second half of item u = (s - 3) / 4
                     const int u = s >> 2;
                     const bool on = u < 8 && live;
-                    const u32x4 sg = sv[SLOT];
                     const int row = rg16 + 16 * (u & 7);
                     const unsigned boff = (unsigned)(m0 + row) * (unsigned)(g.Cout * 4) + (unsigned)c8 * 32u;
-                    const f32x4 t0 = *(const f32x4 *)&T[t_at(row, 2 * c8)] + bias8a, t1 = *(const f32x4 *)&T[t_at(row, 2 * c8 + 1)] + bias8b;
-                    float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+                    float v[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = acg_apply_act(v[q], act);
-                    if (g.relu_mask != nullptr && sd) {
-                        const unsigned bits = sg[0] >> (8 * (c8 & 3));
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) v[q] = (bits >> q) & 1u ? v[q] : 0.f;
-                    } else if (g.relu_src != nullptr && sd) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const unsigned a = sg[q] & 0xffffu, b = sg[q] >> 16;
-                            v[2 * q] = (a - 1u) < 0x7fffu ? v[2 * q] : 0.f;         // positive, non-zero bf16
-                            v[2 * q + 1] = (b - 1u) < 0x7fffu ? v[2 * q + 1] : 0.f;
-                        }
-                    }
+                    for (int q = 0; q < 8; ++q) v[q] = pv8[q];
                     // (value > 0) bits of these 8 channels; the four lanes of a 32-channel word meet by shuffle
                     unsigned w = 0u;
 #pragma unroll
@@ -494,18 +532,55 @@ igemm_conv_x3_pp(const char *__restrict__ in, const __bf16 *__restrict__ wp, con
                     __builtin_amdgcn_raw_buffer_store_b32(w, r_mo, acg_masked_off((boff >> 7) << 2, on && (c8 & 3) == 0), 0, 0);
                     acg_u32x4 hi, lo;
                     acg_split8(v, hi, lo);
-                    const unsigned so = acg_masked_off(boff, on);
+                    const unsigned so = acg_masked_off(boff, on && !(abl & 128));
                     __builtin_amdgcn_raw_buffer_store_b128(hi, r_dst, so, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b128(lo, r_dst, so, 16, 0);
                 }
                 return;
             }
             if (K % 2 == 0) {
-                // even stage: the side loads of item s / 2 + 2 (of the next tile to drain from stage 32 on) into slot (K / 2 + 2) % 3
+                if (MODE == PP_SUMS) {
+                    // even stage 2 u + 2: the norm-backward sums of item u, stored in the stage before (half of an item's work per
+                    // stage: a whole item in one stage made the drain waves the last to reach that stage's barrier)
+                    constexpr int PS = (K / 2 + 2) % 3;       // slot (u % 3) of item u = s / 2 - 1
+                    const int u = (s >> 1) - 1;
+                    const bool on = u >= 0 && u < 16 && live;
+                    const int row = rg + 8 * (u & 15);
+                    const unsigned ob = (unsigned)(m0 + row) * (unsigned)(g.Cout * 4) + (unsigned)cq * 16u;
+                    const int sh = 4 * (int)((ob >> 4) & 7u);
+                    f32x4 gy = pv4;
+                    const f32x4 xh = (s_xv[PS] - mu) * rs;
+                    if (remask) {   // no stored sign bitmask (rare): the mask from the norm's own expression (norm_apply_kernel)
+                        const int img = m0 / GHW;
+                        const f32x4 ga = *(const f32x4 *)(g.ns_gamma + (size_t)img * g.ns_gstride + cq * 4);
+                        const f32x4 be = *(const f32x4 *)(g.ns_beta + (size_t)img * g.ns_gstride + cq * 4);
+                        const f32x4 yy = xh * ga + be;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) gy[q] = yy[q] > 0.f ? gy[q] : 0.f;
+                    } else if (nact_on) {
+                        const unsigned nm = s_nw[PS] >> sh;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) gy[q] = keep(gy[q], nm, q);
+                    }
+                    // u % 2: conv_x3_pre.hip's row group rg + 8 (u % 2), whose rows it sums in this order (fused multiply-adds, as there)
+                    if (on) {
+                        if (u & 1) {
+                            s1b += gy;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) s2b[q] = __builtin_fmaf(gy[q], xh[q], s2b[q]);
+                        } else {
+                            s1a += gy;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) s2a[q] = __builtin_fmaf(gy[q], xh[q], s2a[q]);
+                        }
+                    }
+                }
+                // the side loads of item s / 2 + 2 (of the next tile to drain from stage 32 on) into slot (K / 2 + 2) % 3 — the one
+                // the sums above have just read
                 if (MODE == PP_SUMS || MODE == PP_F32) {
                     constexpr int SLOT = (K / 2 + 2) % 3;
                     const int ul = (s >> 1) + 2;
-                    const bool nx = ul >= 18 && next, on = ((ul < 16 && live) || nx) && sd;
+                    const bool nx = ul >= 18 && next, on = ((ul < 16 && live) || nx) && sd && !(abl & 64);
                     const unsigned bo = (unsigned)((nx ? tn : tl) * BM + rg + 8 * (nx ? ul - 18 : ul)) * (unsigned)(g.Cout * 4) + (unsigned)cq * 16u;
                     const unsigned mo = acg_masked_off((bo >> 7) << 2, on);   // float index bo / 4, word index / 32, byte offset * 4
                     s_av[SLOT] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_add, acg_masked_off(bo, on), 0, 0));
@@ -529,39 +604,9 @@ igemm_conv_x3_pp(const char *__restrict__ in, const __bf16 *__restrict__ wp, con
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[q] += keep(s_av[PS][q], nb, q);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_dst, acg_masked_off(ob, on), 0, 0);
-                    if (MODE == PP_SUMS) {
-                        f32x4 gy = v;
-                        const f32x4 xh = (s_xv[PS] - mu) * rs;
-                        if (remask) {   // no stored sign bitmask (rare): the mask from the norm's own expression (norm_apply_kernel)
-                            const int img = m0 / GHW;
-                            const f32x4 ga = *(const f32x4 *)(g.ns_gamma + (size_t)img * g.ns_gstride + cq * 4);
-                            const f32x4 be = *(const f32x4 *)(g.ns_beta + (size_t)img * g.ns_gstride + cq * 4);
-                            const f32x4 yy = xh * ga + be;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) gy[q] = yy[q] > 0.f ? gy[q] : 0.f;
-                        } else if (nact_on) {
-                            const unsigned nm = s_nw[PS] >> sh;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) gy[q] = keep(gy[q], nm, q);
-                        }
-                        // u % 2: conv_x3_pre.hip's row group rg + 8 (u % 2), whose rows it sums in this order (fused multiply-adds,
-                        // as there)
-                        if (on) {
-                            if (u & 1) {
-                                s1b += gy;
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) s2b[q] = __builtin_fmaf(gy[q], xh[q], s2b[q]);
-                            } else {
-                                s1a += gy;
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) s2a[q] = __builtin_fmaf(gy[q], xh[q], s2a[q]);
-                            }
-                        }
-                    }
-                } else {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_dst, acg_masked_off(ob, on), 0, 0);
                 }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_dst, acg_masked_off(ob, on && !(abl & 128)), 0, 0);
+                pv4 = v;
             }
             if (MODE == PP_STATS && live) {
                 // column sc_c, rows 64 sc_h + 4 (s - 1) .. + 3 in stages 1 .. 16 (sums); the halves meet in stage 17 / 18; rows
@@ -618,7 +663,7 @@ igemm_conv_x3_pp(const char *__restrict__ in, const __bf16 *__restrict__ wp, con
             const int tl = tk > 0 ? tile_of(tk - 1) : 0, tn = tk < nt ? tile_of(tk) : 0;
             const bool live = tk > 0, next = tk < nt;
             for (int s12 = 0; s12 < S; s12 += 12) {
-#define PP_STEP(KK) PP_STAMP(st_work) bar(); PP_STAMP(st_wait) if (!(abl & 4)) step(tl, live, tn, next, s12 + KK, std::integral_constant<int, KK>{});
+#define PP_STEP(KK) PP_STAMP(st_work) bar(); PP_STAMP(st_wait) if (PP_DRAIN_DELAY > 0) __builtin_amdgcn_s_sleep(PP_DRAIN_DELAY); if (!(abl & 4)) step(tl, live, tn, next, s12 + KK, std::integral_constant<int, KK>{});
                 PP_STEP(0) PP_STEP(1) PP_STEP(2) PP_STEP(3) PP_STEP(4) PP_STEP(5)
                 PP_STEP(6) PP_STEP(7) PP_STEP(8) PP_STEP(9) PP_STEP(10) PP_STEP(11)
 #undef PP_STEP
@@ -690,7 +735,7 @@ int acg_igemm_x3_pp_launch(const void *in, const void *wp, const float *bias, fl
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
         n_cu = v;
     }
-    // timing ablations (wrong results): 1 no weight DMA, 4 no drain, 8 no row-patch DMA, 32 all weight DMA at the stage head
+    // timing ablations (wrong results): 1 no weight DMA, 4 no drain, 8 no row-patch DMA, 32 all weight DMA at the stage head, 64 drain loads masked off, 128 drain stores masked off
     const int abl = (getenv("ACG_PP_ABL") && acg_debug_switch("ACG_PP_ABL")) ? atoi(getenv("ACG_PP_ABL")) : 0;
     const int ntiles = (int)(g.Mtot / BM);
     const int grid = ntiles < n_cu ? ntiles : n_cu;

@@ -59,3 +59,33 @@ class precision(object):
     def __exit__(self, *a):
         from dtgan_amd import ops
         ops.set_precision(self.before)
+
+
+class Spy(object):
+    """records (C-ABI entry point, kernel the dispatcher launched for it) while active"""
+
+    def __enter__(self):
+        from dtgan_amd import ops
+        self.ops = ops
+        self.real = ops._lib.call
+        self.seen = []
+
+        def call(name, *a):
+            r = self.real(name, *a)
+            if name.startswith("acg_conv"):
+                self.seen.append((name, ops._lib.query("acg_last_kernel").decode()))
+            else:
+                self.seen.append((name, ""))
+            return r
+        ops._lib.call = call
+        return self
+
+    def __exit__(self, *a):
+        self.ops._lib.call = self.real
+
+    def entries(self):
+        return set(n for n, _ in self.seen)
+
+    def kernels(self, entry=None):
+        """kernels of the launches whose entry point starts with `entry` (all convolution launches if None)"""
+        return [k for n, k in self.seen if k and (entry is None or n.startswith(entry))]

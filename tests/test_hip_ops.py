@@ -103,11 +103,47 @@ CONV_MODES = ["mfma-bf16x3", "mfma-f32", "direct"]
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "k%ds%dp%d%s_%dto%d_%dx%dx%d" % c)
 def test_conv2d_fwd_bwd(case, impl):
     with _conv_mode(impl):
-        _conv2d_fwd_bwd(case)
+        _conv2d_fwd_bwd(case, check_kernels=impl == "mfma-bf16x3")
 
 
-def _conv2d_fwd_bwd(case):
-    from hip_util import t, n, rel
+# Kernels the rows above are ABOUT (bf16x3 MFMA mode): {case: (forward, data gradient, weight gradient)}, each a substring of
+# the kernel name the dispatcher reports (acg_last_kernel) or None.  A row whose dispatch predicate silently stops matching
+# would otherwise turn into a second test of the generic tile.
+CONV_KERNELS = {
+    # thin layers (C4 tensors): N-packed / row-packed patch kernels, persistent thin weight gradient
+    (4, 1, 0, "zero", 32, 1, 3, 6, 6): ("conv_patchn_x3", "conv_thinrow_x3", None),
+    (7, 1, 3, "reflect", 32, 3, 2, 20, 37): ("conv_patchn_x3<REFLECT=1> (7x7", "conv_thinrow_x3", None),
+    (7, 1, 3, "zero", 32, 3, 1, 9, 18): ("conv_patchn_x3<REFLECT=0> (7x7", "conv_thinrow_x3", "wgrad_thin_patch_x3<K=7,flip=1>"),
+    (7, 1, 3, "reflect", 3, 32, 2, 18, 21): ("conv_thinrow_x3<REFLECT=1> (7x7", "conv_patchn_x3", "wgrad_thin_patch_x3<K=7,flip=0>"),
+    (3, 1, 1, "zero", 32, 3, 1, 10, 10): ("conv_patchn_x3<REFLECT=0> (3x3", "conv_thinrow_x3", "wgrad_thin_patch_x3<K=3,flip=1>"),
+    # wave-specialised kernel, row-patch stages
+    (3, 1, 1, "reflect", 128, 128, 1, 16, 16): ("igemm_conv_x3_ws<REFLECT=1,STATS=0,ROWP=1>", "igemm_conv_x3_ws<REFLECT=0,STATS=0,ROWP=1>", None),
+    (3, 1, 1, "zero", 128, 128, 2, 8, 32): ("igemm_conv_x3_ws<REFLECT=0,STATS=0,ROWP=1>", "igemm_conv_x3_ws<REFLECT=0,STATS=0,ROWP=1>", "wgrad_x3_krow"),
+    (3, 1, 1, "reflect", 64, 128, 1, 4, 64): ("igemm_conv_x3_ws<REFLECT=1,STATS=0,ROWP=1>", None, "wgrad_bf16<64,128,SPLIT=1,NT=3>"),
+    (4, 1, 1, "zero", 128, 128, 1, 17, 17): ("igemm_conv_x3_ws<REFLECT=0,STATS=0,ROWP=1>", "igemm_conv_x3_ws<REFLECT=0,STATS=0,ROWP=1>", "wgrad_x3_krowg<NT=4,IS=1,BCI=128>"),
+    (3, 1, 1, "reflect", 128, 256, 1, 2, 128): ("igemm_conv_x3_ws<REFLECT=1,STATS=0,ROWP=1>", "igemm_conv_x3_ws<REFLECT=0,STATS=0,ROWP=1>", "wgrad_x3_krow"),
+    (4, 1, 1, "zero", 128, 128, 2, 16, 32): ("igemm_conv_x3_ws<REFLECT=0,STATS=0,ROWP=1>", "igemm_conv_x3_ws<REFLECT=0,STATS=0,ROWP=1>", "wgrad_x3_krowg<NT=4,IS=1,BCI=128>"),
+    (3, 1, 1, "zero", 128, 128, 3, 9, 13): ("igemm_conv_x3_ws<REFLECT=0,STATS=0,ROWP=1>", "igemm_conv_x3_ws<REFLECT=0,STATS=0,ROWP=1>", None),
+    (3, 1, 1, "reflect", 160, 128, 2, 11, 130): ("igemm_conv_x3_ws<REFLECT=1,STATS=0,ROWP=1>", "igemm_conv_x3_ws<REFLECT=0,STATS=0,ROWP=1>", None),
+    # kernel-row weight gradients
+    (3, 1, 1, "reflect", 128, 128, 2, 6, 32): (None, None, "wgrad_x3_krow"),
+    (3, 1, 1, "zero", 128, 256, 1, 5, 64): (None, None, "wgrad_x3_krow"),
+    (3, 1, 1, "zero", 256, 128, 3, 4, 32): (None, None, "wgrad_x3_krow"),
+    (3, 1, 1, "reflect", 128, 128, 1, 40, 96): (None, None, "wgrad_x3_krow"),
+    (3, 1, 1, "reflect", 64, 32, 2, 4, 128): ("RP=1", None, "wgrad_x3_krow_s<64,32>"),
+    (3, 1, 1, "reflect", 32, 64, 1, 5, 256): ("RP=1", None, "wgrad_x3_krow_s<32,64>"),
+    # persistent row pipeline (32 gathered -> 64 written channels) and the generic row-patch tile on its mirror shape
+    (3, 1, 1, "zero", 32, 64, 1, 3, 128): ("conv_rows_x3<32,64>", "RP=1", "wgrad_x3_krow_s<32,64>"),
+    (3, 1, 1, "zero", 64, 32, 2, 20, 128): ("RP=1", "conv_rows_x3<32,64>", "wgrad_x3_krow_s<64,32>"),
+    (3, 1, 1, "zero", 32, 64, 2, 21, 256): ("conv_rows_x3<32,64>", "RP=1", "wgrad_x3_krow_s<32,64>"),
+    (3, 1, 1, "zero", 64, 32, 1, 17, 128): ("RP=1", "conv_rows_x3<32,64>", "wgrad_x3_krow_s<64,32>"),
+}
+assert all(c in CONV_CASES for c in CONV_KERNELS)
+
+
+def _conv2d_fwd_bwd(case, check_kernels=False):
+    from hip_util import t, n, rel, Spy
+    import os
     K, stride, pad, mode, Ci, Co, N, H, W = case
     rs = np.random.RandomState(sum(c if isinstance(c, int) else len(c) for c in case))
     x = rs.normal(0, 1, (N, Ci, H, W))
@@ -118,14 +154,21 @@ def _conv2d_fwd_bwd(case):
     with torch.no_grad():
         conv.weight.copy_(t(w)); conv.bias.copy_(t(b))
     xt = t(x, grad=True)
-    y = m(xt)
     X, Wt, Bt = leaf(x), leaf(w), leaf(b)
     yo = oops.conv2d(X, Wt, Bt, stride=stride, pad=pad, pad_mode=mode)
+    r = rs.normal(0, 1, yo.v.shape)
+    with Spy() as spy:
+        y = m(xt)
+        y.backward(t(r))
     assert y.shape == yo.v.shape
     assert rel(n(y), yo.v) < 2e-5
-    r = rs.normal(0, 1, yo.v.shape)
-    y.backward(t(r))
     backward(yo, seed=r)
+    if check_kernels:
+        got = (spy.kernels("acg_conv2d_fwd"), spy.kernels("acg_conv2d_bwd_data"), spy.kernels("acg_conv2d_bwd_weight"))
+        if os.environ.get("ACG_PRINT_KERNELS"):
+            print("KERNELS", case, got)
+        for want, have, what in zip(CONV_KERNELS.get(case, (None, None, None)), got, ("forward", "data gradient", "weight gradient")):
+            assert want is None or any(want in k for k in have), (what, want, have)
     assert rel(n(xt.grad), X.g) < 2e-5, "dgrad"
     assert rel(n(conv.weight.grad), Wt.g) < 1e-4, "wgrad"
     assert rel(n(conv.bias.grad), Bt.g) < 1e-4, "bias grad"

@@ -31,36 +31,10 @@ import torch.nn as nn
 pytestmark = pytest.mark.gpu
 
 from oracle import ops as oops  # noqa: E402
-from oracle.tape import backward, leaf  # noqa: E402
+from oracle.tape import T, backward, leaf  # noqa: E402
 
 
-class Spy(object):
-    """records (C-ABI entry point, kernel the dispatcher launched for it) while active"""
-
-    def __enter__(self):
-        from dtgan_amd import ops
-        self.ops = ops
-        self.real = ops._lib.call
-        self.seen = []
-
-        def call(name, *a):
-            r = self.real(name, *a)
-            if name.startswith("acg_conv"):
-                self.seen.append((name, ops._lib.query("acg_last_kernel").decode()))
-            else:
-                self.seen.append((name, ""))
-            return r
-        ops._lib.call = call
-        return self
-
-    def __exit__(self, *a):
-        self.ops._lib.call = self.real
-
-    def entries(self):
-        return set(n for n, _ in self.seen)
-
-    def kernels(self, entry=None):
-        return [k for n, k in self.seen if k and (entry is None or n == entry)]
+from hip_util import Spy  # noqa: E402
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -102,10 +76,24 @@ def _trunk_values(kind):
     return v, x, z, r
 
 
-def _oracle_trunk(kind):
-    """fp64 oracle of stem conv + norm + ReLU, then two (CIN)ResnetBlocks (modules.py:148-188, 199-235); cached per kind"""
-    if kind in _ORACLE:
+def _relu_given(x, m):
+    """ReLU with the activation pattern GIVEN (m: bool array): forward x * m, adjoint g * m.  With m taken from the HIP
+    forward the oracle differentiates the same piecewise-linear function the kernels did: no unit lands on the other side."""
+    return T(np.where(m, x.v, 0).astype(x.v.dtype), (x,), lambda g: (g * m,))
+
+
+def _oracle_trunk(kind, masks=None):
+    """fp64 oracle of stem conv + norm + ReLU, then two (CIN)ResnetBlocks (modules.py:148-188, 199-235); cached per kind.
+    masks: the activation patterns of the five ReLU layers (stem, block 0 inner / output, block 1 inner / output) to use
+    instead of the oracle's own (not cached)"""
+    if masks is None and kind in _ORACLE:
         return _ORACLE[kind]
+    it = iter(masks) if masks is not None else None
+    pats = []                                  # the oracle's own activation patterns (pre-activation > 0), layer by layer
+
+    def relu(h):
+        pats.append(h.v > 0)
+        return _relu_given(h, next(it)) if masks is not None else oops.relu(h)
     v, x, z, r = _trunk_values(kind)
     P = {k: leaf(np.asarray(a, np.float64)) for k, a in v.items()}
     X, Z = leaf(np.asarray(x, np.float64)), leaf(np.asarray(z, np.float64))
@@ -119,19 +107,77 @@ def _oracle_trunk(kind):
         return oops.instance_norm(h, P[name + ".scale"], P[name + ".shift"])
 
     h = oops.conv2d(X, P["stem.weight"], P["stem.bias"], pad=1)
-    h = oops.relu(inn(h, "stem_norm") if kind == "plain" else cn(h, "stem_norm"))
+    h = relu(inn(h, "stem_norm") if kind == "plain" else cn(h, "stem_norm"))
     for b in range(2):
         o = oops.conv2d(h, P["b%d.c1.weight" % b], P["b%d.c1.bias" % b], pad=1, pad_mode="reflect")
         if kind == "cin":
             o = cn(o, "b%d.n1" % b)
-        o = oops.relu(o)
+        o = relu(o)
         o = oops.conv2d(o, P["b%d.c2.weight" % b], P["b%d.c2.bias" % b], pad=1, pad_mode="reflect")
         o = inn(o, "b%d.n2" % b)
-        h = oops.relu(oops.add(h, o))
+        h = relu(oops.add(h, o))
     backward(h, seed=np.asarray(r, np.float64))
-    out = dict(y=h.v, gx=X.g, gz=Z.g, grads={k: p.g for k, p in P.items()})
-    _ORACLE[kind] = out
+    out = dict(y=h.v, gx=X.g, gz=Z.g, grads={k: p.g for k, p in P.items()}, acts=pats)
+    if masks is None:
+        _ORACLE[kind] = out
     return out
+
+
+class _MaskTap(object):
+    """collects, in order of first use, the sign-bitmask tensors (the only int32 tensors the ops hand to the library) while
+    active: what the fused forward itself recorded about its ReLU layers (norm.hip layout: bit e % 32 of word e / 32, NHWC)"""
+
+    def __enter__(self):
+        from dtgan_amd import ops
+        self.ops, self.real, self.seen, self.ids = ops, ops._ptr, [], set()
+
+        def ptr(t):
+            if t is not None and t.dtype == torch.int32 and t.data_ptr() not in self.ids:
+                self.ids.add(t.data_ptr())
+                self.seen.append(t)
+            return self.real(t)
+        ops._ptr = ptr
+        return self
+
+    def __exit__(self, *a):
+        self.ops._ptr = self.real
+
+    def patterns(self, shape):
+        """bool NCHW arrays of the masks that cover a tensor of `shape` (N, C, H, W)"""
+        N, Cn, H, W = shape
+        out = []
+        for t in self.seen:
+            if t.numel() * 32 != N * Cn * H * W:
+                continue
+            w = t.detach().cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+            b = ((w[:, None] >> np.arange(32)) & 1).astype(bool).reshape(N, H, W, Cn)
+            out.append(np.ascontiguousarray(np.transpose(b, (0, 3, 1, 2))))
+        return out
+
+
+def _hip_relu_patterns(kind, net, xt, zt):
+    """the activation patterns of the five ReLU layers as the HIP forward produced them: the net run piece by piece (stem +
+    norm + ReLU, then per block its inner conv (+ CondIN) + ReLU and the block itself), outputs > 0.  Pieces run alone take
+    the same kernels' arithmetic (tools/s16_check.py, tools/pp_check.py: fused and unfused outputs agree bit for bit)."""
+    from dtgan_amd import modules as M
+    from hip_util import n
+    mods = list(net._modules.values())
+    masks = []
+    with torch.no_grad():
+        if kind == "plain":
+            h = M.Sequential(*mods[:3])(xt)
+            blocks = mods[3:]
+        else:
+            h = M.TwoInputSequential(*mods[:2])(xt, zt)
+            blocks = mods[2:]
+        masks.append(n(h) > 0)
+        for blk in blocks:
+            inner = list(blk.conv_block._modules.values())[:3]       # pad, conv (or Merge(conv, CondIN)), ReLU
+            a = M.TwoInputSequential(*inner)(h, zt) if kind == "cin" else M.Sequential(*inner)(h)
+            masks.append(n(a) > 0)
+            h = blk(h, zt) if kind == "cin" else blk(h)
+            masks.append(n(h) > 0)
+    return masks
 
 
 def _hip_trunk(kind, v):
@@ -188,7 +234,9 @@ def test_trunk_at_bench_geometry_matches_the_oracle(kind, prec):
         xt, zt = t(x, grad=True), t(z, grad=True)
         used0 = ops.NORM_SUMS_USED
         with Spy() as spy:
-            y = net(xt, zt) if kind == "cin" else net(xt)
+            with _MaskTap() as tap:
+                y = net(xt, zt) if kind == "cin" else net(xt)
+                fused_masks = tap.patterns((1, C, S, S))   # (cloned to host before the backward frees them)
             y.backward(t(r))
         used = ops.NORM_SUMS_USED - used0
     x3 = prec == "bf16x3"
@@ -212,6 +260,35 @@ def test_trunk_at_bench_geometry_matches_the_oracle(kind, prec):
         assert err < tol, (k, err)
         worst = max(worst, err)
     print("%s/%s: worst parameter gradient %.2e" % (kind, prec, worst))
+    # ---- the same gradients against the oracle differentiated AT THE HIP FORWARD'S ACTIVATION PATTERNS: with no unit on the
+    # other side of its ReLU the comparison is between linear maps again, and the bars are the north-star ones
+    with precision(prec):
+        masks = _hip_relu_patterns(kind, net, xt.detach(), zt.detach())
+    # (piece-by-piece patterns can differ from the fused run's in units within rounding of zero — the pieces take other
+    # kernels for the norms; where the fused forward stored a layer's sign bitmask itself, that is the pattern: each recorded
+    # bitmask replaces the piece-by-piece pattern it agrees with but for such units)
+    taken = []
+    for i, m in enumerate(masks):
+        d = [float(np.mean(f != m)) for f in fused_masks]
+        if d and min(d) < 1e-3:
+            j = int(np.argmin(d))
+            masks[i] = fused_masks[j]
+            taken.append("%d<-%d (%.1e)" % (i, j, d[j]))
+    print("%s/%s: sign bitmasks recorded by the fused forward: %d; used for layers %s" % (kind, prec, len(fused_masks), taken))
+    flipped = ["%.1e" % float(np.mean(m != a)) for m, a in zip(masks, ref["acts"])]   # units on the other side, per ReLU layer
+    refm = _oracle_trunk(kind, masks)
+    tolm = 1e-3 if x3 else 1e-4
+    e_gxm = l2rel(n(xt.grad), refm["gx"])
+    print("%s/%s: with the HIP activation patterns: input gradient norm-wise %.2e (free-running %.2e) %s" % (kind, prec, e_gxm, e_gx, flipped))
+    assert rel(n(y), refm["y"]) < (1e-3 if x3 else 1e-4)
+    assert e_gxm < tolm, e_gxm
+    if kind == "cin":
+        assert l2rel(n(zt.grad), refm["gz"]) < tolm
+    gmaxm = max(float(np.max(np.abs(g))) for g in refm["grads"].values())
+    for k, p in names.items():
+        g, go = n(p.grad), refm["grads"][k]
+        err = np.linalg.norm(g - go) / (np.linalg.norm(go) + 2e-5 * gmaxm * np.sqrt(go.size) / tolm)
+        assert err < tolm, (k, err)
     ents, kerns = spy.entries(), spy.kernels()
     if x3:
         # the pre-split plan: S16 forward (+ sign bitmask in the plain block), un-padded data gradients that emit the norm

@@ -164,6 +164,12 @@ def run(N, H, W, C, time_it, iters):
                 e1.record()
                 torch.cuda.synchronize()
                 line += "  %s %.4f ms" % (nm, e0.elapsed_time(e1) / iters)
+                if os.environ.get("ACG_STAMPS") and hasattr(_lib.load(), "acg_debug_pp_hist"):
+                    import numpy as np
+                    hb = (ctypes.c_ulonglong * (256 * 36))()
+                    assert _lib.load().acg_debug_pp_hist(hb, 256 * 36) == 0
+                    hh = np.frombuffer(hb, dtype=np.uint64).reshape(256, 36).astype(np.float64).mean(0)
+                    print("abl %s %s cycles per stage: %s" % (abl, nm, " ".join("%d" % (v / 16) for v in hh)), flush=True)
             print(line, flush=True)
         os.environ.pop("ACG_PP_ABL", None)
     lib = _lib.load()
@@ -179,6 +185,11 @@ def run(N, H, W, C, time_it, iters):
             wait, work = raw[..., 0], raw[..., 1]
             tot = wait + work
             sh = 100 * wait / np.maximum(tot, 1)
+            if hasattr(lib, "acg_debug_pp_hist"):
+                hb = (ctypes.c_ulonglong * (256 * 36))()
+                assert lib.acg_debug_pp_hist(hb, 256 * 36) == 0
+                hh = np.frombuffer(hb, dtype=np.uint64).reshape(256, 36).astype(np.float64).mean(0)
+                print("%s cycles per stage of a tile (barrier to barrier, mean over tiles x 16): %s" % (nm, " ".join("%d" % (v / 16) for v in hh)), flush=True)
             print("%s stamps: cycles per wave %.0f; share at the barrier: MFMA waves %.1f %% (by wave %s), drain waves %.1f %% (%s), A waves %.1f %%"
                   % (nm, tot[:, :8].mean(), sh[:, :8].mean(), np.round(sh[:, :8].mean(0), 1), sh[:, 8:12].mean(), np.round(sh[:, 8:12].mean(0), 1), sh[:, 12:].mean()), flush=True)
     return ok
