@@ -211,6 +211,55 @@ def test_bench_launches_its_own_ranks():
         assert bad.returncode != 0 and "rank exit codes" in bad.stderr
 
 
+_WORKER8 = """
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as td
+import dtgan_amd
+from dtgan_amd import dist as D
+r, ws = D.init_from_env(backend="gloo")
+assert ws == D.MAX_RANKS == 8
+# a flat gradient buffer with its scalar tail: gradients rank-dependent, 13 reported sums, 4 per-rank monitors
+n = 1000
+buf = torch.full((n + D.SCALAR_TAIL,), float(r + 1))
+tail = buf[n:]
+D.write_scalar_tail(tail, [torch.tensor(float(r * 10 + i)) for i in range(13)], [torch.tensor(float(100 * r + j)) for j in range(4)])
+D.allreduce_mean_([buf])
+assert torch.allclose(buf[:n], torch.full((n,), (ws + 1) / 2.0))
+sums, mm = D.read_scalar_tail(tail, 13, 4)
+want = torch.tensor([sum(q * 10 + i for q in range(ws)) / ws for i in range(13)])
+assert torch.allclose(sums, want), (sums, want)
+assert mm.shape == (8, 4)
+for q in range(ws):                       # every rank's slot arrives intact on every rank (the last one ends the tail exactly)
+    assert torch.allclose(mm[q], torch.tensor([100.0 * q + j for j in range(4)])), (q, mm[q])
+assert D.SUM_SLOTS + 4 * (ws - 1) + 4 == D.SCALAR_TAIL
+print("rank", r, "ok")
+"""
+
+
+def test_eight_rank_scalar_tail_and_bench_dry_run_gloo(tmp_path):
+    """config 4's rank count on the CPU: the scalar tail behind the gradient buffers is sized for MAX_RANKS = 8 — eight gloo
+    ranks fill every per-rank monitor slot and read all of them back after the averaging collective; and `bench.py --gpus 8
+    --dry-run` (the driver's launch shape for the 8-GPU line) brings up eight self-launched ranks and prints ONE line."""
+    script = tmp_path / "worker8.py"
+    script.write_text(_WORKER8 % dict(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="8", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(8)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["dry_run"] is True and line["config"]["parallelism"] == "dp8"
+
+
 def test_phase_exchange_async_handles_complete_out_of_order(monkeypatch):
     """The shape of the RCCL path (dist._allreduce_avg_async with backend "nccl": async handles returned from hooks that
     fire inside backward(), waited for later, per network) with a fake transport whose collectives complete OUT OF ORDER on
