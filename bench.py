@@ -349,7 +349,15 @@ def main():
                    "loss_G_A": round(losses["G_A"], 5)},
         "roofline": {"bound": "mfma", "kernel": "%s (resblock 3x3 reflect 128->128 fwd)" % t_res.kernel,
                      "achieved": None if achieved is None else round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                     "frac": None if achieved is None else round(achieved / peak, 4), "traffic": traffic,
+                     "frac": None if achieved is None else round(achieved / peak, 4),
+                     # beside — never instead of — the spec-peak fraction: what the matrix pipe HOLDS under load.  A register-only
+                     # loop of v_mfma_f32_16x16x32_bf16 on random data sustains 1.88-1.97 PFLOP/s on this chip (DVFS; the
+                     # persistent kernel's bare loop runs 1.97: tools/probes/mfma_rate.hip, DESIGN_LOG.md R5.1), i.e. 633 TFLOP/s
+                     # of algorithmic bf16x3 work
+                     "peak_sustained": (round(1900.0 / 3, 1) if a.precision == "bf16x3" else None),
+                     "frac_of_sustained": (None if achieved is None or a.precision != "bf16x3" else round(achieved / (1900.0 / 3), 4)),
+                     "peak_sustained_source": "tools/probes/mfma_rate.hip (register-only MFMA loop, random data); DESIGN_LOG.md R5.1 (0.235 ms bare loop = 1.97 PFLOP/s)",
+                     "traffic": traffic,
                      "traffic_source": traffic_src, "launches_timed": len(ms), "avg_launch_ms": round(kern_ms, 4),
                      "flops_per_launch": flops, "passes": passes, "three_pass_aggregate": agg, "dominant_by_time": dominant},
         "roofline_hbm": {"bound": "hbm", "kernel": "%s (3x3 stride-2 64->128 downsample fwd)" % t_s2.kernel,

@@ -745,6 +745,30 @@ __global__ __launch_bounds__(512 + 64 * ACG_KROW_NDW) void wgrad_x3_krow_s16(con
         }
         return f;
     };
+#ifdef ACG_ABL_MFMA16   // timing-only ablation (wrong results): every 32x32x16 MFMA as two 16x16x32 on the same fragments — the same
+    // FLOPs, cycles, LDS traffic and registers; what the chip's clock does with the other MFMA shape in THIS kernel
+    auto mma = [&](int t, const AF &a, const BF &bf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 c[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[q] = (f32x4){acc[t][j][4 * q], acc[t][j][4 * q + 1], acc[t][j][4 * q + 2], acc[t][j][4 * q + 3]};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                c[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, bf.h[j], c[q], 0, 0, 0);
+                c[2 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, bf.h[j], c[2 + q], 0, 0, 0);
+                c[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, bf.l[j], c[q], 0, 0, 0);
+                c[2 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, bf.l[j], c[2 + q], 0, 0, 0);
+                c[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, bf.h[j], c[q], 0, 0, 0);
+                c[2 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, bf.h[j], c[2 + q], 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t][j][4 * q + e] = c[q][e];
+        }
+    };
+#else
     auto mma = [&](int t, const AF &a, const BF &bf) {
 #ifndef ACG_ABL_HIONLY   // (timing-only ablation: one MFMA per product, the lo halves still loaded — what plain bf16 MFMAs would take)
 #pragma unroll
@@ -755,6 +779,7 @@ __global__ __launch_bounds__(512 + 64 * ACG_KROW_NDW) void wgrad_x3_krow_s16(con
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, bf.h[j], acc[t][j], 0, 0, 0);
     };
+#endif
 
     __syncthreads();                                     // barrier -1
 #ifdef ACG_STAMP
