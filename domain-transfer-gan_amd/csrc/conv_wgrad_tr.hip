@@ -18,6 +18,7 @@
 #include "common.h"
 #include "conv_internal.h"
 #include <cstdlib>
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -521,327 +522,27 @@ int acg_wgrad_krow_launch(const float *x, const float *dy, float *part, const WG
 // 256 B][64 B pad], 576 bytes = 36 DMA lanes (the four pad lanes are masked): a pixel's 512 bytes are contiguous in
 // memory, rows 576 B apart put the four pixel rows of a transposed-read block on distinct 64-byte bank segments exactly
 // like the 320-byte rows above.
-namespace {
-constexpr int SP = 576;                         // bytes per pixel row
-constexpr int SLANES = SP / 16;                 // DMA lanes per row: 32 data + 4 pad
-constexpr int SXP = (XW * SLANES + 63) / 64;    // DMA pieces of the x window (34 rows): 20
-constexpr int SDP = KP * SLANES / 64;           // ... of the dy run (32 rows): 18
-constexpr int SXB = SXP * 1024, SDB = SDP * 1024;
-constexpr int SBUF = SXB + SDB;                 // one stage buffer
-constexpr int SNB = 4;                          // stage buffers
-static_assert(KP * SLANES % 64 == 0, "piece plan");
-
-__device__ __forceinline__ bf16x8 tr_frag_s(const lds_char *p)
-{
-    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p);
-    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p + 4 * SP));
-    const s16x8 v = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, v);
-}
-}
-
-// 640 threads: waves 0-7 read fragments and issue MFMAs (4 (ci) x 2 (co) waves, 32 x 64 outputs per tap), waves 8-9 issue the
-// DMA pieces (19 each per stage) and wait for them.  FOUR stage buffers: when the MFMA waves pass barrier s, stages s and
-// s+1 are complete and stage s+2 is in flight, so a wave's fragment reads run one tap-step AHEAD of its MFMAs across the
-// stage boundary (the A fragments of the next tap — and the B fragments of the next 16 pixels — are issued before the six
-// MFMAs of the current tap): the LDS latency that used to open every stage behind the barrier is covered by MFMAs.
+//
+// M16 (namespace krow16; opt-in through ACG_KROW_M16, measured slower: DESIGN_LOG.md R5.2): the MFMAs are v_mfma_f32_16x16x32_bf16 — the shape that holds the higher clock under load (1.88-1.97 against
+// 1.73-1.77 PFLOP/s in register-only loops, tools/probes/mfma_rate.hip).  One MFMA spans the whole 32-pixel stage in K; its
+// K group g (lanes 16 g .. 16 g + 15) takes pixels 4 g .. 4 g + 3 and 16 + 4 g .. 16 + 4 g + 3 (two transposed reads, 16 rows
+// apart — the same permutation of K on both operands), a 16-lane group supplies four pixel rows x 16 channels, and rows are
+// 544 bytes: the eight rows the two groups of a 32-lane pass read fall on eight distinct 32-byte bank segments.  The six steps
+// of a stage are (output-channel half) x (tap) instead of (K half) x (tap): the same MFMA cycles and registers per step, the x
+// fragments read once per half.
 #ifndef ACG_KROW_NDW
 #define ACG_KROW_NDW 4
 #endif
-template <bool REFLECT>
-__global__ __launch_bounds__(512 + 64 * ACG_KROW_NDW) void wgrad_x3_krow_s16(const char *__restrict__ x, const char *__restrict__ dy,
-                                                         float *__restrict__ part, WGeom g, unsigned x_bytes, unsigned d_bytes)
-{
-    __shared__ __attribute__((aligned(1024))) char lds[SNB * SBUF];
-    typedef __attribute__((address_space(3))) void lds_void;
-    // DMA waves: issuing a piece costs a wave 100-200 cycles beside a busy CU, 38 pieces per stage; with two such waves the
-    // MFMA waves stood at the barrier 26-50 % of the loop waiting for the ISSUE of the pieces (in-kernel stamps,
-    // -DACG_STAMP), not for their data: four waves share the pieces (10, 10, 9, 9)
-    constexpr int NDW = ACG_KROW_NDW;
-    constexpr int PMIN = SXP / NDW + SDP / NDW;            // pieces per DMA wave and stage: at least this many
-    static_assert(KP == 32 && SNB == 4 && (NDW == 2 || NDW == 4), "piece plan / pipeline depth");
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_ci = g.CiP / BC, tiles_co = g.CoP / BC;
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
-    int b = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-    const int tco = b % tiles_co; b /= tiles_co;
-    const int tci = b % tiles_ci; b /= tiles_ci;
-    const int ky = b % 3;
-    const int split = b / 3;
-    const int ci0 = tci * BC, co0 = tco * BC;
-    const long long mbeg = (long long)split * g.m_per_split;
-    long long mend = mbeg + g.m_per_split;
-    if (mend > g.Mtot) mend = g.Mtot;
-    const int nst = mbeg < mend ? (int)((mend - mbeg) / KP) : 0;
-    const int H = g.Hg, W = g.Wg;
-    const bool do_bias = g.bias_from == 1 && ky == 0 && tci == 0;
-
-    if (wave >= 8) {
-        // ---- DMA waves ----------------------------------------------------------------------------------------------
-        const int dw = wave - 8;
-        const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, x_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rd_ = __builtin_amdgcn_make_buffer_rsrc((void *)dy, 0, d_bytes, 0x00020000);
-        // position of the NEXT stage to load (wave-uniform), advanced by one run of KP pixels per stage
-        int ln, loy, lox;
-        {
-            const long long mm = mbeg < g.Mtot ? mbeg : 0;
-            ln = (int)(mm / ((long long)H * W));
-            const int rr = (int)(mm - (long long)ln * H * W);
-            loy = rr / W;
-            lox = rr - loy * W;
-        }
-        long long lm = mbeg;
-        // Pieces of wave dw: x window pieces dw + NDW j (j < PX) and dy pieces dw + NDW j (j < PD) — which kind a slot is is known
-        // at compile time, and the per-piece address arithmetic is branch-free (the first version decided kind, reflection
-        // and validity per piece with run-time branches: ~30 instructions and five branches per piece, and issuing the
-        // pieces, not their data, paced the loop).  Lane L of a piece holds chunk L % 36 of image row L / 36: chunks 0..15 =
-        // hi of channel groups 0..15, 16..31 = lo, 32..35 = pad (masked).
-        constexpr int PX = (SXP + NDW - 1) / NDW, PD = (SDP + NDW - 1) / NDW;
-        int x_row[PX], x_lds[PX], d_lds[PD];
-        unsigned x_col[PX], d_off[PD];
-        bool x_ok[PX], d_ok[PD];
-#pragma unroll
-        for (int j = 0; j < PX; ++j) {
-            const int pc = dw + NDW * j, L = pc * 64 + lane;
-            const int row = L / SLANES, ch = L - row * SLANES;
-            x_row[j] = row - 1;
-            x_col[j] = (unsigned)(ci0 * 4 + (ch & 15) * 32 + (ch >> 4) * 16);
-            x_ok[j] = pc < SXP && ch < 32 && row < XW;
-            x_lds[j] = __builtin_amdgcn_readfirstlane(pc * 1024);
-        }
-#pragma unroll
-        for (int j = 0; j < PD; ++j) {
-            const int pc = dw + NDW * j, L = pc * 64 + lane;
-            const int row = L / SLANES, ch = L - row * SLANES;
-            d_off[j] = (unsigned)row * (unsigned)(g.Cg * 4) + (unsigned)(co0 * 4 + (ch & 15) * 32 + (ch >> 4) * 16);
-            d_ok[j] = pc < SDP && ch < 32 && row < KP;
-            d_lds[j] = __builtin_amdgcn_readfirstlane(SXB + pc * 1024);
-        }
-        const unsigned xpitch = (unsigned)(g.Cin * 4), dpitch = (unsigned)(g.Cg * 4);
-        auto issue_stage = [&](int buf) {
-            int iy = loy + ky - 1;
-            bool rowok = true;
-            if (REFLECT) {
-                iy = iy < 0 ? -iy : iy;
-                iy = iy >= H ? 2 * (H - 1) - iy : iy;
-            } else {
-                rowok = (unsigned)iy < (unsigned)H;
-            }
-            const int rowbase = (ln * H + iy) * W;
-            char *Bb = lds + buf * SBUF;
-#pragma unroll
-            for (int j = 0; j < PX; ++j) {
-                if (dw + NDW * j < SXP) { // wave-uniform
-                    int ix = lox + x_row[j];
-                    bool ok = x_ok[j] && rowok;
-                    if (REFLECT) {
-                        ix = ix < 0 ? -ix : ix;
-                        ix = ix >= W ? 2 * (W - 1) - ix : ix;
-                    } else {
-                        ok = ok && (unsigned)ix < (unsigned)W;
-                    }
-                    const unsigned off = (unsigned)(rowbase + ix) * xpitch + x_col[j];
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, (lds_void *)(Bb + x_lds[j]), 16, acg_masked_off(off, ok), 0, 0, 0);
-                }
-            }
-            const unsigned dbase = (unsigned)(int)lm * dpitch;
-#pragma unroll
-            for (int j = 0; j < PD; ++j) {
-                if (dw + NDW * j < SDP) // wave-uniform
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rd_, (lds_void *)(Bb + d_lds[j]), 16, acg_masked_off(dbase + d_off[j], d_ok[j]), 0, 0, 0);
-            }
-            lm += KP;
-            lox += KP;
-            if (lox == W) { lox = 0; if (++loy == H) { loy = 0; ++ln; } }
-        };
-        // Bias gradient (column sums of dy) on the side: the DMA waves have the time and the registers.  Lane (pixel group
-        // pg = 4 dw + lane / 16, channel group c8 = lane % 16) adds hi + lo of 8 channels of its KP / (4 NDW) pixels of
-        // every landed dy image; the 4 NDW pixel groups meet in LDS at the end, in fixed order.
-        float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        constexpr int BRW = KP / (4 * NDW);                 // pixel rows per lane group
-        const int bc8 = lane & 15, bpg = 4 * dw + (lane >> 4);
-        auto bias_stage = [&](int buf) {
-            const char *dp = lds + buf * SBUF + SXB + (BRW * bpg) * SP + bc8 * 16;
-#pragma unroll
-            for (int r = 0; r < BRW; ++r) {
-                const u32x4 h = *(const u32x4 *)(dp + r * SP), l = *(const u32x4 *)(dp + r * SP + 256);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    bsum[2 * q] += __builtin_bit_cast(float, h[q] << 16) + __builtin_bit_cast(float, l[q] << 16);
-                    bsum[2 * q + 1] += __builtin_bit_cast(float, h[q] & 0xffff0000u) + __builtin_bit_cast(float, l[q] & 0xffff0000u);
-                }
-            }
-        };
-        // vmcnt counts in issue order: "stage k complete" = at most the PW pieces of each younger stage outstanding
-        if (nst > 0) issue_stage(0);
-        if (nst > 1) issue_stage(1);
-        if (nst > 2) issue_stage(2);
-        if (nst > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PMIN) : "memory");
-        else if (nst > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PMIN) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                    // barrier -1: stage 0 is complete
-        if (do_bias && nst > 0) bias_stage(0);
-        int nxt = 3, bb = 1;
-        for (int s = 0; s < nst; ++s) {
-            if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PMIN) : "memory");  // stage s+1 complete, s+2 in flight
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                // barrier s: every MFMA wave has finished reading stage s-1
-            if (s + 3 < nst) issue_stage(nxt);           // ... whose buffer stage s+3 takes
-            if (do_bias && s + 1 < nst) bias_stage(bb);  // stage s+1 is complete (its buffer is rewritten after barrier s+3)
-            nxt = (nxt + 1) & (SNB - 1);
-            bb = (bb + 1) & (SNB - 1);
-        }
-        __builtin_amdgcn_s_barrier();                    // every MFMA wave is done with the stage buffers
-        if (do_bias) {
-            float *red = (float *)lds;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) red[(bpg * 16 + bc8) * 8 + e] = bsum[e];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                // (the MFMA waves join it)
-            const int c = (tid - 512);                   // the first 128 threads: one per channel
-            if (c < BC) {
-                float sum = 0.f;
-#pragma unroll
-                for (int r = 0; r < 4 * NDW; ++r) sum += red[(r * 16 + (c >> 3)) * 8 + (c & 7)];
-                g.bias_part[(long long)split * g.CoP + co0 + c] = sum;
-            }
-        }
-        return;
-    }
-
-    // ---- MFMA waves -------------------------------------------------------------------------------------------------
-    const int wi = wave >> 1, wj = wave & 1;
-    f32x16 acc[3][2];
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
-    // transposed-read lane map (tools/probes/tr_read.hip): lane 4q+p of 16-lane group gq supplies pixel row 8*(gq>>1) + q,
-    // channels 16*(gq&1) + 4p .. 4p+3
-    const int gq = lane >> 4, li = lane & 15;
-    const int frag_row = 8 * (gq >> 1) + (li >> 2), frag_col = 16 * (gq & 1) + 4 * (li & 3);
-    const int xlane = frag_row * SP + (wi * 32 + frag_col) * 2;
-    const int dlane = SXB + frag_row * SP + (wj * 64 + frag_col) * 2;
-    struct AF { bf16x8 h, l; };
-    struct BF { bf16x8 h[2], l[2]; };
-    auto load_a = [&](int buf, int ks, int t) {
-        const lds_char *xb = (const lds_char *)(lds + buf * SBUF) + xlane + (ks * 16 + t) * SP;
-        AF f;
-        f.h = tr_frag_s(xb);
-        f.l = tr_frag_s(xb + 256);
-        return f;
-    };
-    auto load_b = [&](int buf, int ks) {
-        const lds_char *db = (const lds_char *)(lds + buf * SBUF) + dlane + ks * 16 * SP;
-        BF f;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            f.h[j] = tr_frag_s(db + j * 64);
-            f.l[j] = tr_frag_s(db + 256 + j * 64);
-        }
-        return f;
-    };
-#ifdef ACG_ABL_MFMA16   // timing-only ablation (wrong results): every 32x32x16 MFMA as two 16x16x32 on the same fragments — the same
-    // FLOPs, cycles, LDS traffic and registers; what the chip's clock does with the other MFMA shape in THIS kernel
-    auto mma = [&](int t, const AF &a, const BF &bf) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            f32x4 c[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) c[q] = (f32x4){acc[t][j][4 * q], acc[t][j][4 * q + 1], acc[t][j][4 * q + 2], acc[t][j][4 * q + 3]};
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                c[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, bf.h[j], c[q], 0, 0, 0);
-                c[2 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, bf.h[j], c[2 + q], 0, 0, 0);
-                c[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, bf.l[j], c[q], 0, 0, 0);
-                c[2 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, bf.l[j], c[2 + q], 0, 0, 0);
-                c[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, bf.h[j], c[q], 0, 0, 0);
-                c[2 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, bf.h[j], c[2 + q], 0, 0, 0);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[t][j][4 * q + e] = c[q][e];
-        }
-    };
-#else
-    auto mma = [&](int t, const AF &a, const BF &bf) {
-#ifndef ACG_ABL_HIONLY   // (timing-only ablation: one MFMA per product, the lo halves still loaded — what plain bf16 MFMAs would take)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, bf.h[j], acc[t][j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, bf.l[j], acc[t][j], 0, 0, 0);
-#endif
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, bf.h[j], acc[t][j], 0, 0, 0);
-    };
-#endif
-
-    __syncthreads();                                     // barrier -1
-#ifdef ACG_STAMP
-    unsigned long long st_wait = 0, st_work = 0, st_t = __builtin_amdgcn_s_memtime();
-#endif
-    AF a0, a1;
-    BF b0, b1;
-    if (nst > 0) {
-        b0 = load_b(0, 0);
-        a0 = load_a(0, 0, 0);
-    }
-    int cur = 0;
-    for (int s = 0; s < nst; ++s) {
-        // entering: b0 = B(s, pixels 0..15) and a0 = A(s, 0, tap 0) are loaded or on their way
-        a1 = load_a(cur, 0, 1);
-        mma(0, a0, b0);
-        a0 = load_a(cur, 0, 2);
-        b1 = load_b(cur, 1);
-        mma(1, a1, b0);
-        a1 = load_a(cur, 1, 0);
-        mma(2, a0, b0);
-        a0 = load_a(cur, 1, 1);
-        mma(0, a1, b1);
-        a1 = load_a(cur, 1, 2);
-        mma(1, a0, b1);
-#ifdef ACG_STAMP
-        { const unsigned long long t = __builtin_amdgcn_s_memtime(); st_work += t - st_t; st_t = t; }
-#endif
-        __syncthreads();                                 // barrier s: stage s+1 is complete
-#ifdef ACG_STAMP
-        { const unsigned long long t = __builtin_amdgcn_s_memtime(); st_wait += t - st_t; st_t = t; }
-#endif
-        const int nb = (cur + 1) & (SNB - 1);
-        if (s + 1 < nst) {
-            b0 = load_b(nb, 0);
-            a0 = load_a(nb, 0, 0);
-        }
-        mma(2, a1, b1);
-        cur = nb;
-    }
-#ifdef ACG_STAMP
-    if (lane == 0 && g.bias_part != nullptr) { // diagnostic build only: (barrier wait, the rest) cycles of this wave's main loop
-        unsigned long long *dbg = (unsigned long long *)((char *)g.bias_part + 49152) + ((long long)blockIdx.x * 8 + wave) * 2;
-        dbg[0] = st_wait; dbg[1] = st_work + (__builtin_amdgcn_s_memtime() - st_t);
-    }
-#endif
-    __syncthreads();
-    if (do_bias) __syncthreads();                        // the DMA waves' fold of the bias sums
-
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        float *o = part + ((long long)split * 9 + ky * 3 + t) * g.CiP * g.CoP;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ci = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int co = co0 + wj * 64 + j * 32 + (lane & 31);
-                o[(long long)ci * g.CoP + co] = acc[t][j][r];
-            }
-    }
-}
+#define KS_M16 1
+#define KS_NS krow16
+#include "conv_wgrad_tr_s16.inc"
+#undef KS_M16
+#undef KS_NS
+#define KS_M16 0
+#define KS_NS krow32
+#include "conv_wgrad_tr_s16.inc"
+#undef KS_M16
+#undef KS_NS
 
 int acg_wgrad_krow_s16_launch(const void *x, const void *dy, float *part, const WGeom &g, hipStream_t st)
 {
@@ -849,13 +550,14 @@ int acg_wgrad_krow_s16_launch(const void *x, const void *dy, float *part, const 
     const long long nimg = g.Mtot / ((long long)g.Hg * g.Wg);
     const long long xbytes = nimg * g.Hin * g.Win * g.Cin * 4, dbytes = g.Mtot * g.Cg * 4;
     ACG_REQUIRE(xbytes < (1LL << 32) && dbytes < (1LL << 32), "wgrad_x3_krow_s16: operand exceeds the 4 GiB buffer-addressing limit");
-    if (g.reflect)
-        hipLaunchKernelGGL(wgrad_x3_krow_s16<true>, dim3(blocks), dim3(512 + 64 * ACG_KROW_NDW), 0, st, (const char *)x, (const char *)dy, part, g,
-                           (unsigned)xbytes, (unsigned)dbytes);
-    else
-        hipLaunchKernelGGL(wgrad_x3_krow_s16<false>, dim3(blocks), dim3(512 + 64 * ACG_KROW_NDW), 0, st, (const char *)x, (const char *)dy, part, g,
-                           (unsigned)xbytes, (unsigned)dbytes);
+    // A/B switch (read per call): the v_mfma_f32_16x16x32_bf16 form (krow16) — measured 0.36-0.38 ms against 0.332 ms for the
+    // 32x32x16 form at batch 32 (DESIGN_LOG.md R5.2: its x fragments are read once per output-channel half), so not the default
+    const bool m16 = acg_debug_switch("ACG_KROW_M16");
+#define KROW_S16(R, NS) hipLaunchKernelGGL((NS::wgrad_x3_krow_s16<R>), dim3(blocks), dim3(512 + 64 * ACG_KROW_NDW), 0, st, (const char *)x, (const char *)dy, part, g, (unsigned)xbytes, (unsigned)dbytes)
+    if (g.reflect) { if (m16) KROW_S16(true, krow16); else KROW_S16(true, krow32); }
+    else { if (m16) KROW_S16(false, krow16); else KROW_S16(false, krow32); }
+#undef KROW_S16
     ACG_CHECK_LAUNCH("wgrad_x3_krow_s16");
-    acg_note_kernel("wgrad_x3_krow_s16");
+    acg_note_kernel(m16 ? "wgrad_x3_krow_s16<16x16x32>" : "wgrad_x3_krow_s16");
     return ACG_OK;
 }
