@@ -288,7 +288,7 @@ def main():
     if (N, S, nc) != (32, 256, 3):
         traffic_src = "not measured for this shape (the committed counter runs are batch 32, 256x256x3)"
     for cand in ({"f32": ["r01_c_resblock_conv_traffic_f32.json"],
-                  "bf16x3": ["r04_resblock_conv_traffic_bf16x3.json", "r03_resblock_conv_traffic_bf16x3.json", "r02_z_resblock_conv_traffic_bf16x3.json", "r02_p_resblock_conv_traffic_bf16x3.json", "r02_resblock_conv_traffic_bf16x3.json", "r01_f_resblock_conv_traffic_bf16x3.json"]}.get(a.precision, [])):
+                  "bf16x3": ["r05_resblock_conv_traffic_bf16x3.json", "r04_resblock_conv_traffic_bf16x3.json", "r03_resblock_conv_traffic_bf16x3.json", "r02_z_resblock_conv_traffic_bf16x3.json", "r02_p_resblock_conv_traffic_bf16x3.json", "r02_resblock_conv_traffic_bf16x3.json", "r01_f_resblock_conv_traffic_bf16x3.json"]}.get(a.precision, [])):
         tj = os.path.join(ROOT, "profiles", cand)
         if os.path.exists(tj) and (N, S, nc) == (32, 256, 3):
             traffic, traffic_src = json.load(open(tj)).get("hbm_bytes_per_launch"), "profiles/" + cand
