@@ -51,6 +51,24 @@ template <bool ROWP> struct WsLds {
 };
 }
 
+#ifdef ACG_STAMP
+// diagnostic build only (tools/ws_stamps.py): cycles of set-up, main loop, epilogue (consumer wave 0) and the start time of
+// every workgroup
+__device__ unsigned long long g_ws_tile[8192 * 4];
+extern "C" int acg_debug_ws_tile(unsigned long long *host, size_t n)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ws_tile), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#define WS_TILE_STAMP_END()                                                                                           \
+    if (tid == 0 && blockIdx.x < 8192) {                                                                              \
+        const unsigned long long te_ = __builtin_amdgcn_s_memtime();                                                  \
+        g_ws_tile[blockIdx.x * 4] = tl_loop0 - tl_entry; g_ws_tile[blockIdx.x * 4 + 1] = tl_loop1 - tl_loop0;         \
+        g_ws_tile[blockIdx.x * 4 + 2] = te_ - tl_loop1; g_ws_tile[blockIdx.x * 4 + 3] = tl_real;                      \
+    }
+#else
+#define WS_TILE_STAMP_END()
+#endif
+
 // 4 waves per SIMD = two 8-wave workgroups per CU: the register budget is 128 VGPRs (all four instances allocate 122,
 // no scratch).  STATS: also emit the per-tile (mean, M2) for an InstanceNorm behind the convolution (see the epilogue).
 template <bool REFLECT, bool STATS, bool ROWP>
@@ -70,6 +88,10 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwg = gridDim.x, bid = blockIdx.x;
+#ifdef ACG_STAMP
+    const unsigned long long tl_entry = __builtin_amdgcn_s_memtime(), tl_real = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tl_loop0 = 0, tl_loop1 = 0;
+#endif
     const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
     const int swz = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const int tiles_n = g.ncols_pad / BN;
@@ -282,6 +304,12 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
             static_assert(AL == 2, "the vmcnt immediates below count 2 * AL = 4 A loads per stage");
             // A tiles travel TWO stages ahead in registers (set s & 1): a stage is 768 MFMA cycles per workgroup, shorter than the
             // gather's latency — with one stage ahead the producers stood at the A wait every stage
+            // (Round 5, tools/ws_stamps.py: hipcc puts an s_waitcnt vmcnt(0) of its own in front of the LDS stores below — a
+            // wave's LDS stores are ordered behind its pending LDS-DMA, it cannot tell the A image from the B image — so the
+            // second stage in flight is waited for early.  A two-barrier pipeline without that wait, with the gathers truly
+            // two stages ahead and the weight pieces issued by the consumer waves, measured the same 0.29 ms on the stride-2
+            // 64 -> 128 layer: what paces the stage is the ISSUE of the four gather loads, 1.7 k cycles per stage of
+            // back-pressure from the CU's vector-memory path; DESIGN_LOG.md R5.4.)
             const std::integral_constant<int, 0> c0;
             const std::integral_constant<int, 1> c1;
             load_a_stage(c0);
@@ -369,6 +397,9 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
     };
     const char *pb0 = ldsb + b_base + 2 * L::b_off(0), *pb1 = ldsb + b_base + 2 * L::b_off(1);
     bool done = false;
+#ifdef ACG_STAMP
+    tl_loop0 = __builtin_amdgcn_s_memtime();
+#endif
     if constexpr (ROWP) {
         if (kdim == 3 && S % 6 == 0) {
             // 3 x 3 layers: six stages (two kernel rows) per trip, so buffer, tap column and B buffer of every stage are
@@ -404,6 +435,9 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
         }
     }
     __builtin_amdgcn_s_setprio(0);
+#ifdef ACG_STAMP
+    tl_loop1 = __builtin_amdgcn_s_memtime();
+#endif
     // Epilogue through LDS: the tile (accumulator + bias, activation) is staged in the LDS the main loop no longer needs
     // and leaves in coalesced 512-byte rows — 37 us per launch faster than storing the 16-column MFMA fragments
     // directly (64-byte segments), and the accumulators die early.
@@ -458,6 +492,7 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
             float *dst = out_ptr[row];
             if (dst != nullptr && n0 + c4 * 4 < g.Cout) *(f32x4 *)(dst + n0 + c4 * 4) = *(const f32x4 *)&tile[row * TS + c4 * 4];
         }
+        WS_TILE_STAMP_END()
         return;
     }
     // Data-gradient epilogues with side inputs (ReLU source, skip gradient and its sign bitmask): four rows at a time, every
@@ -504,6 +539,7 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
             if (dst[u] != nullptr && col[u] < g.Cout) *(f32x4 *)(dst[u] + col[u]) = v[u];
         }
     }
+    WS_TILE_STAMP_END()
 }
 
 // same contract as acg_igemm_bf16_launch for bn == 128, Cin % 32 == 0, ACG_PREC_BF16X3
