@@ -102,7 +102,7 @@ igemm_conv_x3_pp(const char *__restrict__ in, const __bf16 *__restrict__ wp, con
     const int Gx = (G >> 3) + (xcd < (G & 7) ? 1 : 0);
     const int nt = jx < cnt ? (cnt - jx + Gx - 1) / Gx : 0;
     auto tile_of = [&](int k) { return start + jx + k * Gx; };
-    const int S = 9 * (g.Cin / KC);                  // stages per tile (a multiple of 36: the launcher checks Cin % 128 == 0)
+    const int S = 9 * (g.Cin / KC);                  // stages per tile (36: the launcher checks Cin == 128)
     const int GHW = g.GH * g.GW;
     auto bar = [&]() {
         asm volatile("" ::: "memory");
@@ -691,7 +691,8 @@ static bool pp_taps(const Taps &t, int *dxmin, int *kstep)
 }
 
 // Geometries of conv_x3_pre.hip that the persistent kernel takes: tiles that are one run of a grid row, 128 output columns,
-// input channels in whole 128s, no frame path
+// exactly 128 input channels (the drain's prefetch of the next tile's side data is scheduled on the S = 36 stages of a
+// 128-channel tile: stages 10 + 12 k and 18 .. 34), no frame path
 bool acg_igemm_x3_pp_ok(const Geom &g, const Taps &t)
 {
     // A/B switches, read per call (tools/pp_check.py flips them inside one process).  Until the persistent kernel beats the
@@ -699,7 +700,7 @@ bool acg_igemm_x3_pp_ok(const Geom &g, const Taps &t)
     const bool off = acg_debug_switch("ACG_NO_PP") || !acg_debug_switch("ACG_PP");
     int a, b;
     if (off || !acg_igemm_x3_pre_ok(g, t) || !pp_taps(t, &a, &b) || a != -1) return false;
-    if (g.GW % BM != 0 || g.Cout != BN || g.ncols_pad != BN || g.Cin % 128 != 0 || g.fold_p != 0) return false;
+    if (g.GW % BM != 0 || g.Cout != BN || g.ncols_pad != BN || g.Cin != 128 || g.fold_p != 0) return false;
     if (g.is != 1 || g.os != 1 || g.Hout != g.GH || g.Wout != g.GW || g.Hin != g.GH || g.Win != g.GW) return false;
     if (g.out_s16 && g.addend != nullptr) return false;
     return true;

@@ -296,8 +296,8 @@ def test_trunk_at_bench_geometry_matches_the_oracle(kind, prec):
         assert "acg_conv2d_fwd_s16" in ents and "acg_conv2d_bwd_weight_s16" in ents and "acg_conv2d_bwd_data_s16_sums" in ents, ents
         if kind == "plain":
             assert "acg_conv2d_fwd_s16_mask" in ents and "acg_conv2d_bwd_data_s16_mask" in ents, ents
-        # (igemm_conv_x3_pre, or its persistent form igemm_conv_x3_pp where that is dispatched: conv_x3_pp.hip)
-        assert any(k.startswith("igemm_conv_x3_pre<REFLECT=1") or k.startswith("igemm_conv_x3_pp<REFLECT=1") for k in kerns), kerns
+        # (igemm_conv_x3_pre; its opt-in persistent form igemm_conv_x3_pp has its own test, tests/test_hip_parked.py)
+        assert any(k.startswith("igemm_conv_x3_pre<REFLECT=1") for k in kerns), kerns
         assert any("SUMS" in k for k in kerns), kerns
         assert "wgrad_x3_krow_s16" in kerns, kerns
         # the norm in front of the first block, the first block's output norm, and in a CINResnetBlock its conditional norm
@@ -366,7 +366,7 @@ def test_presplit_kernels_at_bench_geometry_match_the_oracle():
         y = torch.empty((N, H, W, Cn), device="cuda")
         part = torch.empty((N, H * W // 128, 2, Cn), device="cuda")
         _lib.call("acg_conv2d_fwd_s16", D, P(xs), P(pk.wf), P(pk.bias), P(y), 0, P(part), 0, st)
-        assert _lib.query("acg_last_kernel").decode() in ("igemm_conv_x3_pp<REFLECT=1,STATS>", "igemm_conv_x3_pre<REFLECT=1,STATS=1>")
+        assert _lib.query("acg_last_kernel").decode() == "igemm_conv_x3_pre<REFLECT=1,STATS=1>"
         assert rel(nchw(n(y)), yo.v) < 2e-5, "forward"
         yt = nhwc(yo.v).reshape(N, H * W // 128, 128, Cn)
         assert rel(n(part)[:, :, 0], yt.mean(2)) < 1e-5 and rel(n(part)[:, :, 1], ((yt - yt.mean(2, keepdims=True)) ** 2).sum(2)) < 1e-4, "tile statistics"
@@ -389,7 +389,7 @@ def test_presplit_kernels_at_bench_geometry_match_the_oracle():
         ns.x, ns.mean, ns.rstd, ns.gamma, ns.beta, ns.gstride = P(xn_t), P(mean_t), P(rstd_t), None, None, 0
         ns.sign_mask, ns.act, ns.part = P(nb_t), ops.ACT_RELU, P(psum)
         _lib.call("acg_conv2d_bwd_data_s16_sums", D, P(dys), P(pk.wb), P(dx), P(ws), nbw, P(skip_t), P(sb_t), ctypes.byref(ns), st)
-        assert _lib.query("acg_last_kernel").decode() in ("igemm_conv_x3_pp<REFLECT=0,SUMS>", "igemm_conv_x3_pre<REFLECT=0,STATS=0,SUMS=1>")
+        assert _lib.query("acg_last_kernel").decode() == "igemm_conv_x3_pre<REFLECT=0,STATS=0,SUMS=1>"
         dx_o = X.g + skip * skip_bits
         assert rel(nchw(n(dx)), dx_o) < 2e-5, "data gradient + masked skip addend"
         gy = nhwc(dx_o * norm_bits).reshape(N, H * W // 128, 128, Cn)

@@ -3,6 +3,7 @@ reference, flat-parameter plumbing, loud failure without a GPU, and the 2-rank g
 import json
 import os
 import re
+import socket
 import subprocess
 import sys
 
@@ -243,7 +244,10 @@ def test_eight_rank_scalar_tail_and_bench_dry_run_gloo(tmp_path):
     --dry-run` (the driver's launch shape for the 8-GPU line) brings up eight self-launched ranks and prints ONE line."""
     script = tmp_path / "worker8.py"
     script.write_text(_WORKER8 % dict(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="8", OMP_NUM_THREADS="1")
+    with socket.socket() as sk:   # a free port of this host (a fixed one collides when two test runs share it)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="8", OMP_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(8)]
     outs = [p.communicate(timeout=300)[0] for p in procs]

@@ -195,6 +195,36 @@ def run(N, H, W, C, time_it, iters):
     return ok
 
 
+def wide_stays_on_pre():
+    """a 256 -> 128 channel layer (S = 72 stages per tile): the persistent kernel's drain is scheduled on the 36 stages of a
+    128-channel tile, so acg_igemm_x3_pp_ok must leave this layer to igemm_conv_x3_pre whatever ACG_PP says"""
+    dev = torch.device("cuda")
+    st = ops._stream()
+    N, H, W, Ci, Co = 1, 64, 128, 256, 128
+    d = ops.conv_desc(N, H, W, Ci, Co, 3, 1, 1, 1, Ci, Co)
+    D = ctypes.byref(d)
+    if not _lib.query("acg_conv2d_s16_supported", D):
+        print("256 input channels: not a pre-split layer (nothing to check)")
+        return True
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn((N, H, W, Ci), device=dev, generator=g).clamp_min(0)
+    w = torch.randn((Co, Ci, 3, 3), device=dev, generator=g) * 0.05
+    b = torch.randn(Co, device=dev, generator=g)
+    pk = ops.PackedConv(w, b, Ci, Co)
+    xs = enc(x)
+    ys, names = [], []
+    for on in (False, True):
+        use_pp(on)
+        y = torch.full((N, H, W, Co), float("nan"), device=dev)
+        _lib.call("acg_conv2d_fwd_s16", D, P(xs), P(pk.wf), P(pk.bias), P(y), 1, None, 0, st)
+        names.append(_lib.query("acg_last_kernel").decode())
+        torch.cuda.synchronize()
+        ys.append(y)
+    ok = all("x3_pre" in n for n in names) and same("256 -> 128 forward, ACG_PP on vs off", ys[1], ys[0])
+    print("256 input channels: %s %s" % ("stays on igemm_conv_x3_pre" if ok else "WRONG KERNEL", names), flush=True)
+    return ok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--time", action="store_true")
@@ -205,6 +235,7 @@ def main():
     ok = run(1, 64, 128, 128, False, 0)     # the smallest map of the un-padded data gradient: 64 tiles, one per workgroup
     ok &= run(3, 64, 256, 128, False, 0)    # two tiles per grid row; 384 tiles over 256 workgroups (uneven)
     ok &= run(5, 128, 128, 128, False, 0)   # 640 tiles: 2-3 per workgroup
+    ok &= wide_stays_on_pre()
     if a.time:
         ok &= run(a.batch, 128, 128, 128, True, a.iters)
     print("ALL OK" if ok else "FAILED")
