@@ -104,6 +104,7 @@ SIGNATURES = {
     "acg_conv2d_bwd_data_add_supported": (c_int, [_P]),
     "acg_conv2d_bwd_data_add": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "acg_mask_apply": (c_int, [_P, _P, _P, c_size_t, _P]),
+    "acg_dropout_apply": (c_int, [_P, _P, c_float, _P, c_size_t, _P]),
     "acg_conv2d_bwd_data_relu": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "acg_conv2d_fwd_stats": (c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "acg_norm_stats_from_partials": (c_int, [_P, c_int, c_size_t, c_int, c_int, c_float, c_int, _P, _P, _P]),
@@ -144,7 +145,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 114   # include/acgan_hip.h ACG_VERSION this binding was written against
+ABI_VERSION = 115   # include/acgan_hip.h ACG_VERSION this binding was written against
 
 
 class AcgError(RuntimeError):

@@ -474,13 +474,13 @@ __global__ __launch_bounds__(256) void norm_bwd_apply(const float *__restrict__ 
 }
 
 __global__ __launch_bounds__(256) void mask_apply_kernel(const float *__restrict__ x, const unsigned *__restrict__ mask,
-                                                         float *__restrict__ out, long long n4)
+                                                         float *__restrict__ out, long long n4, float scale)
 {
     for (long long f = blockIdx.x * (long long)blockDim.x + threadIdx.x; f < n4; f += (long long)gridDim.x * blockDim.x) {
         f32x4 v = *(const f32x4 *)(x + f * 4);
         const unsigned nb = norm_mask_nibble(mask, f);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (nb >> k) & 1u ? v[k] : 0.f;
+        for (int k = 0; k < 4; ++k) v[k] = (nb >> k) & 1u ? v[k] * scale : 0.f;   // scale 1: exact
         *(f32x4 *)(out + f * 4) = v;
     }
 }
@@ -489,8 +489,19 @@ extern "C" int acg_mask_apply(const float *x, const unsigned *sign_mask, float *
     ACG_REQUIRE(x != nullptr && sign_mask != nullptr && out != nullptr && n % 4 == 0, "acg_mask_apply: bad arguments");
     const long long n4 = (long long)(n / 4);
     const int blocks = acg_cdiv(n4, 256) > 8192 ? 8192 : acg_cdiv(n4, 256);
-    hipLaunchKernelGGL(mask_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, sign_mask, out, n4);
+    hipLaunchKernelGGL(mask_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, sign_mask, out, n4, 1.f);
     ACG_CHECK_LAUNCH("mask_apply_kernel");
+    return ACG_OK;
+}
+// nn.Dropout(p) in training mode with the keep draw GIVEN as a bitmask (bit e % 32 of word e / 32 for the float at index e):
+// out = keep ? x * scale : 0 with scale = 1 / (1 - p); the backward is the same map on the gradient
+extern "C" int acg_dropout_apply(const float *x, const unsigned *keep_bits, float scale, float *out, size_t n, void *stream)
+{
+    ACG_REQUIRE(x != nullptr && keep_bits != nullptr && out != nullptr && n % 4 == 0 && scale > 0.f, "acg_dropout_apply: bad arguments");
+    const long long n4 = (long long)(n / 4);
+    const int blocks = acg_cdiv(n4, 256) > 8192 ? 8192 : acg_cdiv(n4, 256);
+    hipLaunchKernelGGL(mask_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, keep_bits, out, n4, scale);
+    ACG_CHECK_LAUNCH("mask_apply_kernel(dropout)");
     return ACG_OK;
 }
 

@@ -136,37 +136,47 @@ class _BatchNormMixin(_Cached):
         C = cpad(self.num_features) if self._pad16 else self.num_features
         return self._cached(lambda: (_padded_vec(self.weight, C), _padded_vec(self.bias, C)))
 
-    def forward_act(self, x, act=ACT_NONE):
+    def forward_act(self, x, act=ACT_NONE, res=None):
+        """res: a residual added before the activation (ResnetBlock with --norm batch: ReLU(x + BN(conv(...))),
+        networks.py:23-31 -> modules.py:227-235) — folded into the apply pass like InstanceNorm's"""
         if self._pad16:
             x = restore_width(x, cpad(self.num_features))
         C = x.shape[-1]
         g, b = self._gb()
         if not self.training:  # eval mode: normalise with the running buffers (model.eval(), train.py:258)
-            return ops.NormAct.apply(x, self.weight, self.bias, None, "bn_eval", act, self.eps, g, b,
+            return ops.NormAct.apply(x, self.weight, self.bias, res, "bn_eval", act, self.eps, g, b,
                                      self.running_mean.contiguous(), self.running_var.contiguous(), 0.0)
         if sync_bn_active():  # statistics over every rank's shard (SURVEY §8e)
-            y = ops.SyncBatchNormAct.apply(x, self.weight, self.bias, act, self.eps, g, b, self.running_mean,
-                                           self.running_var, self.momentum)
+            y = ops.SyncBatchNormAct.apply(x, self.weight, self.bias, ACT_NONE if res is not None else act, self.eps, g, b,
+                                           self.running_mean, self.running_var, self.momentum)
             with torch.no_grad():
                 self.num_batches_tracked += 1
-            return y
+            return y if res is None else add_act(y, res, act)
         if C == self.num_features and self.running_mean.is_contiguous() and self.running_var.is_contiguous():
             # no channel padding (every BatchNorm of the reference's networks: widths are multiples of 16): the statistics
             # kernel updates the running buffers in place
-            y = ops.NormAct.apply(x, self.weight, self.bias, None, "bn", act, self.eps, g, b, self.running_mean,
+            y = ops.NormAct.apply(x, self.weight, self.bias, res, "bn", act, self.eps, g, b, self.running_mean,
                                   self.running_var, self.momentum)
         else:
             rm = torch.zeros(C, device=x.device, dtype=torch.float32)
             rv = torch.ones(C, device=x.device, dtype=torch.float32)
             rm[:self.num_features].copy_(self.running_mean)
             rv[:self.num_features].copy_(self.running_var)
-            y = ops.NormAct.apply(x, self.weight, self.bias, None, "bn", act, self.eps, g, b, rm, rv, self.momentum)
+            y = ops.NormAct.apply(x, self.weight, self.bias, res, "bn", act, self.eps, g, b, rm, rv, self.momentum)
             with torch.no_grad():
                 self.running_mean.copy_(rm[:self.num_features])
                 self.running_var.copy_(rv[:self.num_features])
         with torch.no_grad():
             self.num_batches_tracked += 1
         return y
+
+
+def add_act(y, res, act):
+    """act(y + res) through the norm kernels with constant statistics (mean 0, rstd 1, gamma 1, beta 0: the 'bn_eval' form of
+    ops.NormAct, whose backward is dx = gy, dres = gy) — the residual behind a SyncBatchNorm, which has no fused form"""
+    C = y.shape[-1]
+    one, zero = torch.ones(C, device=y.device), torch.zeros(C, device=y.device)
+    return ops.NormAct.apply(y, one, zero, res, "bn_eval", act, 0.0, one, zero, zero, one, 0.0)
 
 
 class BatchNorm2d(nn.BatchNorm2d, _BatchNormMixin):
@@ -375,6 +385,13 @@ def run_sequence(mods, x, C, z=None, res=None, last_block=False):
             reflect = m.padding[0]
             i += 1
             continue
+        if isinstance(m, nn.Dropout):   # --use_dropout: behind the first ReLU of a residual block (modules.py:167-168, 214-215)
+            if m.training and m.p > 0.0:
+                if ops.is_s16(x):
+                    raise NotImplementedError("dropout on a pre-split tensor")
+                x = ops.DropoutFn.apply(x, C, m.p)
+            i += 1
+            continue
         if isinstance(m, (ResnetBlock, CINResnetBlock)):
             x = m.forward_nhwc(x, z, last=not (i + 1 < n and isinstance(mods[i + 1], (ResnetBlock, CINResnetBlock))))
             ns_prev = None   # (the slot of the norm in front of the trunk belongs to the first block's first convolution)
@@ -392,8 +409,6 @@ def run_sequence(mods, x, C, z=None, res=None, last_block=False):
             if i < n and isinstance(mods[i], (InstanceNorm, CondInstanceNorm, BatchNorm2d)):
                 norm = mods[i]
                 i += 1
-        elif isinstance(m, nn.Dropout):
-            raise NotImplementedError("use_dropout: Dropout is not implemented by the HIP path (reference default is off)")
         elif isinstance(m, nn.Sigmoid):
             raise NotImplementedError("use_sigmoid / --no_lsgan: the reference's BCE branch is broken (model.py:59-63); "
                                       "only LSGAN is implemented")
@@ -479,10 +494,8 @@ def run_sequence(mods, x, C, z=None, res=None, last_block=False):
                                      emit, s16, ns_prev)
                 if ns_prev is not None:
                     x._acg_ns = ns_prev
-            else:
-                if fuse_res:
-                    raise NotImplementedError("residual after BatchNorm")
-                x = norm.forward_act(x, act)
+            else:   # BatchNorm2d (--norm batch; E_B always): a block-output norm takes the residual + ReLU in its apply pass
+                x = norm.forward_act(x, ACT_RELU if fuse_res else act, res if fuse_res else None)
     if res is None and ops.is_s16(x):   # the list ended with a block
         x = ops.S16Decode.apply(x)
     return x, C

@@ -864,6 +864,61 @@ class NormAct(torch.autograd.Function):
         return dx, dg, db, dres, None, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
+# nn.Dropout inside the residual blocks (--use_dropout, options.py:65 -> modules.py:167-168, 214-215).  DROPOUT_SOURCE: None =
+# draw the keep bits on the device (torch's Philox generator: 32 Bernoulli(1/2) bits per random word); a callable
+# (nhwc_shape, real_channels, p) -> int32 bit words injects the draw (parity tests feed the fixture's masks to both sides)
+DROPOUT_SOURCE = None
+
+
+def dropout_keep_bits(shape, C, p):
+    if DROPOUT_SOURCE is not None:
+        return DROPOUT_SOURCE(tuple(shape), C, p)
+    if p != 0.5:
+        raise NotImplementedError("Dropout(p=%g): the device draw implements the reference's p = 0.5 (one random bit per element)" % p)
+    n = 1
+    for d in shape:
+        n *= d
+    dev = torch.device("cuda", torch.cuda.current_device())
+    return torch.randint(-2 ** 31, 2 ** 31, ((n + 31) // 32,), device=dev, dtype=torch.int64).to(torch.int32)
+
+
+def pack_keep_bits(keep_nchw, Cp, device):
+    """a boolean NCHW keep mask (the reference's layout) -> bit words over the NHWC C16 tensor (pad channels: dropped)"""
+    k = torch.as_tensor(keep_nchw, device=device).to(torch.bool)
+    N, C, H, W = k.shape
+    full = torch.zeros((N, H, W, Cp), device=device, dtype=torch.int64)
+    full[..., :C] = k.permute(0, 2, 3, 1).to(torch.int64)
+    words = (full.reshape(-1, 32) << torch.arange(32, device=device, dtype=torch.int64)).sum(1)
+    return torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32)
+
+
+class DropoutFn(torch.autograd.Function):
+    """y = keep ? x / (1 - p) : 0 on an NHWC C16 tensor (acg_dropout_apply); backward: the same map on dy"""
+
+    @staticmethod
+    def forward(ctx, x, C, p):
+        x = x.contiguous()
+        _check(x)
+        if x.numel() % 32:
+            raise _lib.AcgError("dropout: tensor size must be a multiple of 32 elements")
+        bits = dropout_keep_bits(x.shape, C, p)
+        if bits.numel() * 32 != x.numel() or bits.dtype != torch.int32 or not bits.is_cuda:
+            raise _lib.AcgError("dropout: keep bits must be %d int32 words on the device" % (x.numel() // 32))
+        y = torch.empty_like(x)
+        ctx.scale = 1.0 / (1.0 - p)
+        _lib.call("acg_dropout_apply", _ptr(x), _ptr(bits), ctx.scale, _ptr(y), x.numel(), _stream())
+        ctx.save_for_backward(bits)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (bits,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        _lib.call("acg_dropout_apply", _ptr(dy), _ptr(bits), ctx.scale, _ptr(dx), dy.numel(), _stream())
+        return dx, None, None
+
+
 class SyncBatchNormAct(torch.autograd.Function):
     """BatchNorm (train mode) with statistics over ALL ranks' batches: per-rank (count, mean, M2) from the stats
     kernel, one all-reduce of [C x 3] floats, Chan-style combination; backward all-reduces the two per-channel sums

@@ -52,7 +52,7 @@ _T = [
     ("which_model_netD", str, "basic", "(accepted, unused — as in the reference)"),
     ("which_model_netG", str, "resnet", "(accepted, unused — as in the reference)"),
     ("norm", str, "instance", "instance or batch normalization"),
-    ("use_dropout", "flag", False, "not implemented by the HIP path"),
+    ("use_dropout", "flag", False, "use dropout for the generator"),
     ("max_gnorm", float, 500., "max grad norm to which it will be clipped"),
     ("stoch_enc", "flag", False, "use a stochastic encoder"),
     ("z_gan", ("choice", int, [0, 1]), 1, "use a GAN on z_B"),

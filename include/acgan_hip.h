@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ACG_VERSION 114
+#define ACG_VERSION 115
 
 typedef enum {
     ACG_OK = 0,
@@ -263,6 +263,11 @@ int acg_norm_bwd_apply(const float *dy, const float *y, const float *x, const fl
 /* out = x where the sign-bitmask bit (acg_norm_apply layout) is set, else 0 — the materialised form of a masked skip
  * gradient, for the paths that cannot fuse it (n % 4 == 0) */
 int acg_mask_apply(const float *x, const unsigned *sign_mask, float *out, size_t n, void *stream);
+/* nn.Dropout(p), training mode (replaces modules.py:167-168, 214-215 `nn.Dropout(0.5)` behind the first ReLU of a residual
+ * block): out = keep ? x * scale : 0, scale = 1 / (1 - p); the Bernoulli(1 - p) draw is GIVEN, one bit per element in the
+ * sign-bitmask layout (bit e % 32 of word e / 32), so forward and backward (the same call on the gradient) share it and a
+ * test can inject it.  n % 4 == 0. */
+int acg_dropout_apply(const float *x, const unsigned *keep_bits, float scale, float *out, size_t n, void *stream);
 
 /* ---- elementwise ---- */
 int acg_act_bwd(const float *dy, const float *y, float *dx, size_t n, int act, void *stream); /* dx = dy*act'(y) */

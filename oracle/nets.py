@@ -53,6 +53,17 @@ class Net(object):
     def P(self, key):
         return self.params[key]
 
+    # `--use_dropout` (options.py:65): the Dropout(0.5) behind the first ReLU of every residual block.  The keep masks are
+    # GIVEN (self.drop = callable(shape) -> NCHW keep mask, one call per Dropout forward, in call order); eval mode: identity
+    drop = None
+
+    def _drop(self, x):
+        if not getattr(self, "use_dropout", False) or not self.training:
+            return x
+        if self.drop is None:
+            raise RuntimeError("oracle: use_dropout needs an injected mask source (net.drop)")
+        return ops.dropout(x, self.drop(x.v.shape))
+
     def _bn(self, x, prefix):
         stats = {k: self.buffers[prefix + "." + k] for k in ("running_mean", "running_var", "num_batches_tracked")}
         y = ops.batch_norm(x, self.P(prefix + ".weight"), self.P(prefix + ".bias"), stats, self.training)
@@ -65,17 +76,20 @@ class Net(object):
 class ResnetGenerator(Net):
     """networks.py:203-252 (+ modules.py:193-235 ResnetBlock)."""
 
-    def __init__(self, input_nc, output_nc, ngf, n_blocks=3, dtype=np.float32):
+    def __init__(self, input_nc, output_nc, ngf, n_blocks=3, dtype=np.float32, norm="instance", use_dropout=False):
         Net.__init__(self, dtype)
         self.nb = n_blocks
+        self.norm, self.use_dropout = norm, use_dropout   # networks.py:23-31 get_norm_layer; modules.py:214-215
+        self.j = 1 if use_dropout else 0
         self._conv("model.1", ngf, input_nc, 7); self._in("model.2", ngf)
         self._conv("model.4", 2 * ngf, ngf, 3); self._in("model.5", 2 * ngf)
         self._conv("model.7", 4 * ngf, 2 * ngf, 3); self._in("model.8", 4 * ngf)
         for i in range(n_blocks):
             b = "model.%d.conv_block" % (10 + i)
+            # the Dropout module sits at index 3 and shifts the second stage's state_dict keys (modules.py:214-228)
             self._conv(b + ".1", 4 * ngf, 4 * ngf, 3)
-            self._conv(b + ".4", 4 * ngf, 4 * ngf, 3)
-            self._in(b + ".5", 4 * ngf)
+            self._conv(b + ".%d" % (4 + self.j), 4 * ngf, 4 * ngf, 3)
+            self._in(b + ".%d" % (5 + self.j), 4 * ngf)
         t = 10 + n_blocks
         self.t = t
         self._add("model.%d.weight" % t, (4 * ngf, 2 * ngf, 3, 3)); self._add("model.%d.bias" % t, (2 * ngf,))
@@ -87,12 +101,16 @@ class ResnetGenerator(Net):
         self._add(p + ".weight", (co, ci, k, k)); self._add(p + ".bias", (co,))
 
     def _in(self, p, c):
+        if self.norm == "batch":
+            return self._add_bn(p, c)
         self._add(p + ".scale", (c,)); self._add(p + ".shift", (c,))
 
     def _c(self, x, p, **kw):
         return ops.conv2d(x, self.P(p + ".weight"), self.P(p + ".bias"), **kw)
 
     def _n(self, x, p):
+        if self.norm == "batch":
+            return self._bn(x, p)
         return ops.instance_norm(x, self.P(p + ".scale"), self.P(p + ".shift"))
 
     def forward(self, x):
@@ -103,7 +121,8 @@ class ResnetGenerator(Net):
         for i in range(self.nb):
             b = "model.%d.conv_block" % (10 + i)
             o = ops.relu(self._c(h, b + ".1", pad=1, pad_mode="reflect"))       # modules.py:211-212: no norm
-            o = self._n(self._c(o, b + ".4", pad=1, pad_mode="reflect"), b + ".5")
+            o = self._drop(o)                                                    # modules.py:214-215
+            o = self._n(self._c(o, b + ".%d" % (4 + self.j), pad=1, pad_mode="reflect"), b + ".%d" % (5 + self.j))
             h = ops.relu(ops.add(h, o))                                          # modules.py:232-235
         h = ops.conv_transpose2d(h, self.P("model.%d.weight" % t), self.P("model.%d.bias" % t))
         h = ops.relu(self._n(h, "model.%d" % (t + 1)))
@@ -114,9 +133,11 @@ class ResnetGenerator(Net):
 class CINResnetGenerator(Net):
     """networks.py:149-197 (+ modules.py:104-188 CondInstanceNorm / CINResnetBlock)."""
 
-    def __init__(self, nlatent, input_nc, output_nc, ngf, n_blocks=3, dtype=np.float32):
+    def __init__(self, nlatent, input_nc, output_nc, ngf, n_blocks=3, dtype=np.float32, use_dropout=False):
         Net.__init__(self, dtype)
         self.nb, self.nl = n_blocks, nlatent
+        self.use_dropout = use_dropout
+        self.j = 1 if use_dropout else 0   # Dropout at conv_block index 3 shifts the later keys (modules.py:167-181)
         self._conv("model.1", ngf, input_nc, 7); self._cin("model.2", ngf)
         self._conv("model.4", 2 * ngf, ngf, 3); self._cin("model.5", 2 * ngf)
         self._conv("model.7", 4 * ngf, 2 * ngf, 3); self._cin("model.8", 4 * ngf)
@@ -124,8 +145,8 @@ class CINResnetGenerator(Net):
             b = "model.%d.conv_block" % (10 + i)
             self._conv(b + ".1.module1", 4 * ngf, 4 * ngf, 3)
             self._cin(b + ".1.module2", 4 * ngf)
-            self._conv(b + ".4", 4 * ngf, 4 * ngf, 3)
-            self._add(b + ".5.scale", (4 * ngf,)); self._add(b + ".5.shift", (4 * ngf,))
+            self._conv(b + ".%d" % (4 + self.j), 4 * ngf, 4 * ngf, 3)
+            self._add(b + ".%d.scale" % (5 + self.j), (4 * ngf,)); self._add(b + ".%d.shift" % (5 + self.j), (4 * ngf,))
         t = 10 + n_blocks
         self.t = t
         self._add("model.%d.weight" % t, (4 * ngf, 2 * ngf, 3, 3)); self._add("model.%d.bias" % t, (2 * ngf,))
@@ -158,8 +179,9 @@ class CINResnetGenerator(Net):
         for i in range(self.nb):
             b = "model.%d.conv_block" % (10 + i)
             o = ops.relu(self._n(self._c(h, b + ".1.module1", pad=1, pad_mode="reflect"), z, b + ".1.module2"))
-            o = self._c(o, b + ".4", pad=1, pad_mode="reflect")
-            o = ops.instance_norm(o, self.P(b + ".5.scale"), self.P(b + ".5.shift"))   # modules.py:180-181
+            o = self._drop(o)                                                    # modules.py:167-168
+            o = self._c(o, b + ".%d" % (4 + self.j), pad=1, pad_mode="reflect")
+            o = ops.instance_norm(o, self.P(b + ".%d.scale" % (5 + self.j)), self.P(b + ".%d.shift" % (5 + self.j)))   # modules.py:180-181
             h = ops.relu(ops.add(h, o))
         h = ops.conv_transpose2d(h, self.P("model.%d.weight" % t), self.P("model.%d.bias" % t))
         h = ops.relu(self._n(h, z, "model.%d" % (t + 1)))
@@ -169,24 +191,31 @@ class CINResnetGenerator(Net):
 
 # -------------------------------------------------------------- discriminators
 class _ConvD(Net):
+    norm = "instance"   # `--norm batch` (options.py:64, networks.py:23-31): BatchNorm2d in place of InstanceNorm
+
     def _conv(self, p, co, ci, k):
         self._add(p + ".weight", (co, ci, k, k)); self._add(p + ".bias", (co,))
 
     def _in(self, p, c):
+        if self.norm == "batch":
+            return self._add_bn(p, c)
         self._add(p + ".scale", (c,)); self._add(p + ".shift", (c,))
 
     def _c(self, x, p, **kw):
         return ops.conv2d(x, self.P(p + ".weight"), self.P(p + ".bias"), **kw)
 
     def _n(self, x, p):
+        if self.norm == "batch":
+            return self._bn(x, p)
         return ops.instance_norm(x, self.P(p + ".scale"), self.P(p + ".shift"))
 
 
 class Discriminator(_ConvD):
     """D_B — networks.py:308-349: k4, strides 2,2,1,1,1, pad 1."""
 
-    def __init__(self, input_nc, ndf, dtype=np.float32):
+    def __init__(self, input_nc, ndf, dtype=np.float32, norm="instance"):
         Net.__init__(self, dtype)
+        self.norm = norm
         self._conv("model.0", ndf, input_nc, 4)
         self._conv("model.2", 2 * ndf, ndf, 4); self._in("model.3", 2 * ndf)
         self._conv("model.5", 4 * ndf, 2 * ndf, 4); self._in("model.6", 4 * ndf)
@@ -204,8 +233,9 @@ class Discriminator(_ConvD):
 class Discriminator_edges(_ConvD):
     """D_A — networks.py:352-393: four k3 s2 p1 convs then a k4 p0 head."""
 
-    def __init__(self, input_nc, ndf, dtype=np.float32):
+    def __init__(self, input_nc, ndf, dtype=np.float32, norm="instance"):
         Net.__init__(self, dtype)
+        self.norm = norm
         self._conv("model.0", ndf, input_nc, 3)
         self._conv("model.2", 2 * ndf, ndf, 3); self._in("model.3", 2 * ndf)
         self._conv("model.5", 4 * ndf, 2 * ndf, 3); self._in("model.6", 4 * ndf)

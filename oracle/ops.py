@@ -267,6 +267,20 @@ def tanh(x):
 # ----------------------------------------------------------------------------
 # plumbing
 # ----------------------------------------------------------------------------
+def dropout(x, keep, p=0.5):
+    """torch.nn.Dropout(p) in training mode (modules.py:167-168, 214-215: `nn.Dropout(0.5)` behind the first ReLU of both
+    block types): y = x * keep / (1 - p) with `keep` the Bernoulli(1 - p) draw — GIVEN here (the fixtures inject the same
+    draw into the reference, tools/make_goldens.py), so the op is a pure function of its inputs."""
+    m = (np.asarray(keep) != 0).astype(x.v.dtype) * x.v.dtype.type(1.0 / (1.0 - p))
+    return T(x.v * m, (x,), lambda g: (g * m,))
+
+
+def dropout_keep(seed, k, shape, p=0.5):
+    """the keep mask of the k-th Dropout call of a fixture (NCHW, the reference's layout): regenerated from the seed on
+    every box, like the parameters (oracle/recipe.py)"""
+    return np.random.RandomState((seed * 1000003 + k) & 0x7FFFFFFF).rand(*shape) >= p
+
+
 def add(a, b):
     return T(a.v + b.v, (a, b), lambda g: (g, g))
 

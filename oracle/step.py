@@ -20,7 +20,7 @@ class Opt(object):
         d = dict(input_nc=3, output_nc=3, ngf=32, nef=32, ndf=64, nlatent=16, n_blocks=3,
                  lr=2e-4, beta1=0.5, max_gnorm=500.0, lambda_A=1.0, lambda_B=1.0, lambda_z_B=0.025,
                  lambda_sup_A=0.1, lambda_sup_B=0.1,
-                 stoch_enc=False, z_gan=1, enc_A_B=1, niter_decay=25)
+                 stoch_enc=False, z_gan=1, enc_A_B=1, niter_decay=25, norm="instance", use_dropout=False)
         d.update(kw)
         self.__dict__.update(d)
 
@@ -95,12 +95,16 @@ class AugStep(object):
     def __init__(self, opt, dtype=np.float32):
         self.opt, self.dtype = opt, np.dtype(dtype)
         o = opt
-        self.netG_A_B = nets.CINResnetGenerator(o.nlatent, o.input_nc, o.output_nc, o.ngf, o.n_blocks, dtype)
-        self.netG_B_A = nets.ResnetGenerator(o.output_nc, o.input_nc, o.ngf, o.n_blocks, dtype)
+        # model.py:343-371: opt.norm reaches G_B_A and both image discriminators (G_A_B is always CondInstanceNorm,
+        # E_B always 'batch'); opt.use_dropout both generators
+        self.netG_A_B = nets.CINResnetGenerator(o.nlatent, o.input_nc, o.output_nc, o.ngf, o.n_blocks, dtype,
+                                                use_dropout=o.use_dropout)
+        self.netG_B_A = nets.ResnetGenerator(o.output_nc, o.input_nc, o.ngf, o.n_blocks, dtype, norm=o.norm,
+                                             use_dropout=o.use_dropout)
         enc_nc = o.output_nc + (o.input_nc if o.enc_A_B else 0)                       # model.py:360-362
         self.netE_B = nets.LatentEncoder(o.nlatent, enc_nc, o.nef, dtype)
-        self.netD_A = nets.Discriminator_edges(o.input_nc, 32, dtype)                 # model.py:366-367: ndf=32
-        self.netD_B = nets.Discriminator(o.output_nc, o.ndf, dtype)
+        self.netD_A = nets.Discriminator_edges(o.input_nc, 32, dtype, norm=o.norm)    # model.py:366-367: ndf=32
+        self.netD_B = nets.Discriminator(o.output_nc, o.ndf, dtype, norm=o.norm)
         self.netD_z_B = nets.DiscriminatorLatent(o.nlatent, o.ndf, dtype)
         self._make_optimizers()
 
@@ -110,6 +114,17 @@ class AugStep(object):
         self.optimizer_G_B = Adam(self.netG_A_B.parameters() + self.netE_B.parameters(), o.lr, o.beta1)
         self.optimizer_D_A = Adam(self.netD_A.parameters(), o.lr / 5.0, o.beta1)
         self.optimizer_D_B = Adam(self.netD_B.parameters() + self.netD_z_B.parameters(), o.lr / 5.0, o.beta1)
+
+    def set_dropout_seed(self, seed):
+        """--use_dropout fixtures: the k-th Dropout forward of the step sequence (both generators share the counter, in
+        the reference's call order model.py:404, 407, 467, 493) takes ops.dropout_keep(seed, k, shape)"""
+        k = [0]
+
+        def src(shape):
+            m = ops.dropout_keep(seed, k[0], shape)
+            k[0] += 1
+            return m
+        self.netG_A_B.drop = self.netG_B_A.drop = src
 
     def nets(self):
         return OrderedDict([("netG_A_B", self.netG_A_B), ("netG_B_A", self.netG_B_A), ("netE_B", self.netE_B),

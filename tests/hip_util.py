@@ -89,3 +89,30 @@ class Spy(object):
     def kernels(self, entry=None):
         """kernels of the launches whose entry point starts with `entry` (all convolution launches if None)"""
         return [k for n, k in self.seen if k and (entry is None or n.startswith(entry))]
+
+
+def injected_dropout(seed):
+    """--use_dropout fixtures: the k-th Dropout forward takes the seeded keep mask the fixture's generator gave the reference
+    (oracle.ops.dropout_keep, NCHW) — packed into the bit words acg_dropout_apply reads (ops.DROPOUT_SOURCE)"""
+    import contextlib
+    from dtgan_amd import ops
+    from oracle import ops as oops
+
+    @contextlib.contextmanager
+    def cm():
+        if seed is None:
+            yield
+            return
+        k = [0]
+
+        def src(shape, C, p):
+            N, H, W, Cp = shape
+            keep = oops.dropout_keep(seed, k[0], (N, C, H, W), p)
+            k[0] += 1
+            return ops.pack_keep_bits(keep, Cp, torch.device("cuda", 0))
+        ops.DROPOUT_SOURCE = src
+        try:
+            yield
+        finally:
+            ops.DROPOUT_SOURCE = None
+    return cm()

@@ -22,10 +22,12 @@ def build(meta):
     from dtgan_amd import networks as N
     c, n = meta["cfg"], meta["net"]
     g = [0]
-    if n == "netG_B_A":
-        return N.define_G(c["input_nc"], c["output_nc"], c["ngf"], gpu_ids=g, n_blocks=c["n_blocks"])
+    if n == "netG_B_A":   # --norm batch / --use_dropout fixtures carry the option in their cfg (options.py:64-65)
+        return N.define_G(c["input_nc"], c["output_nc"], c["ngf"], norm=c.get("norm", "instance"),
+                          use_dropout=c.get("use_dropout", False), gpu_ids=g, n_blocks=c["n_blocks"])
     if n == "netG_A_B":
-        return N.define_stochastic_G(c["nlatent"], c["input_nc"], c["output_nc"], c["ngf"], gpu_ids=g, n_blocks=c["n_blocks"])
+        return N.define_stochastic_G(c["nlatent"], c["input_nc"], c["output_nc"], c["ngf"],
+                                     use_dropout=c.get("use_dropout", False), gpu_ids=g, n_blocks=c["n_blocks"])
     if n == "netD_B":
         return N.define_D_B(c["input_nc"], c["ndf"], "basic", "instance", gpu_ids=g)
     if n == "netD_A":
@@ -40,7 +42,7 @@ def build(meta):
 @pytest.mark.parametrize("impl", ["mfma", "direct", "mfma-bf16x3"])
 @pytest.mark.parametrize("name", names("net"))
 def test_net_matches_reference_golden(name, impl):
-    from hip_util import precision
+    from hip_util import precision, injected_dropout
     from dtgan_amd import ops
     arr, meta = load(name)
     if impl == "direct" and name not in ("G_A_B_s16_nb3", "D_B_s40", "E_B_s64"):
@@ -49,7 +51,7 @@ def test_net_matches_reference_golden(name, impl):
     impl = impl.split("-")[0]
     ops.set_conv_impl(impl)
     try:
-        with precision("bf16x3" if x3 else "f32"):
+        with precision("bf16x3" if x3 else "f32"), injected_dropout(meta.get("drop_seed")):
             _check_net(arr, meta, x3, name)
     finally:
         ops.set_conv_impl("mfma")

@@ -47,8 +47,8 @@ STEP_TOL = {  # precision -> ((loss, gnorm, image) at step 0, the same after Ada
 @pytest.mark.parametrize("prec", ["f32", "bf16x3"])
 @pytest.mark.parametrize("name", names("step"))
 def test_train_instance_matches_reference_golden(name, prec):
-    from hip_util import precision
-    with precision(prec):
+    from hip_util import precision, injected_dropout
+    with precision(prec), injected_dropout(load(name)[1].get("drop_seed")):   # one mask counter over all steps of the fixture
         _check_steps(name, prec)
 
 
@@ -81,15 +81,24 @@ DIGEST_TOL = {"f32": (3e-3, 5e-3), "bf16x3": (2e-2, 2e-2)}
 # a sum over ReLU-gated per-sample shifts) of the two full-resolution CondInstanceNorms of G_A_B whose planes are largest —
 # the only tensors of the 'rich' fixtures outside the bf16x3 tolerance (measured 3e-2 .. 0.16; all others <= 2e-2)
 RICH_X3_SKIP = (("netG_A_B", "model.2.shift_conv"), ("netG_A_B", "model.14.shift_conv"))
+# The --norm batch --use_dropout fixture: BatchNorm gains are ~N(1, 0.02) at initialisation (networks.py:19-21) where the
+# InstanceNorm gains are ~N(0, 0.02), so G_B_A is a high-gain network there although the flavour is 'init', and D_A ends in
+# BatchNorms over 4 samples x (2x2 | 1x1) maps.  tools/step_grad_conditioning.py: the EXACT-fp32 path moves G_B_A's gradients
+# by 2e-4 .. 8e-3 (discretely: one LeakyReLU / ReLU unit on the other side) when its inputs are perturbed by 4e-6, G_A_B's by
+# 2e-5; bf16x3 lands 8e-2 off on the head bias (a sum over all pixels of the image gradient), 2-4e-2 on two more tensors
+# whose digests stay inside the tolerance.  That one tensor is skipped by name in bf16x3; f32 pins it on the same fixture.
+BN_DROPOUT_X3_SKIP = (("netG_B_A", "model.19.bias"),)
 # Networks whose .grad after the step is comparable: the reference lets loss_G.backward() pile the (unused) G-phase
 # gradients on top of the discriminators' D-phase .grad (model.py:509, no zero_grad for them); the HIP path skips those
 # weight gradients, so the discriminators are pinned by their UPDATE digests (which only see the D-phase gradient).
 GRAD_NETS = ("netG_A_B", "netG_B_A", "netE_B")
 
 
-def _check_digests(m, arr, pre, prec, flavour="init"):
+def _check_digests(m, arr, pre, prec, flavour="init", bn_dropout=False):
     gt, ut = DIGEST_TOL[prec]
     skip = RICH_X3_SKIP if (prec == "bf16x3" and flavour == "rich") else ()
+    if prec == "bf16x3" and bn_dropout:
+        skip = skip + BN_DROPOUT_X3_SKIP
     bad, seen, skipped = [], 0, []
     for nname, net in m._net_dict().items():
         params = dict(net.named_parameters())
@@ -155,7 +164,7 @@ def _check_steps(name, prec):
         for k in ("real_A", "real_B"):
             assert np.array_equal(n(visuals[k]), arr["s%d/%s" % (st, k)])
         if st == 0:
-            _check_digests(m, arr, pre, prec, meta["flavour"])
+            _check_digests(m, arr, pre, prec, meta["flavour"], bn_dropout=meta["opt"].get("norm") == "batch")
     if meta["aug"]:   # BatchNorm running buffers after the last step (networks.py:407-415, 450-462)
         for nname in ("netE_B", "netD_z_B"):
             for k, b in m._net_dict()[nname].named_buffers():

@@ -16,12 +16,32 @@ from golden_util import load, names, rel_err, digest
 NET_TOL = 2e-5
 
 
+def seeded_dropout(seed):
+    """mask source of a --use_dropout fixture: the k-th Dropout forward takes oracle.ops.dropout_keep(seed, k, shape)"""
+    from oracle import ops
+    k = [0]
+
+    def src(shape):
+        m = ops.dropout_keep(seed, k[0], shape)
+        k[0] += 1
+        return m
+    return src
+
+
 def build_net(meta, dtype):
     c, n = meta["cfg"], meta["net"]
     if n == "netG_B_A":
-        return nets.ResnetGenerator(c["input_nc"], c["output_nc"], c["ngf"], c["n_blocks"], dtype)
-    if n == "netG_A_B":
-        return nets.CINResnetGenerator(c["nlatent"], c["input_nc"], c["output_nc"], c["ngf"], c["n_blocks"], dtype)
+        net = nets.ResnetGenerator(c["input_nc"], c["output_nc"], c["ngf"], c["n_blocks"], dtype, norm=c.get("norm", "instance"),
+                                   use_dropout=c.get("use_dropout", False))
+    elif n == "netG_A_B":
+        net = nets.CINResnetGenerator(c["nlatent"], c["input_nc"], c["output_nc"], c["ngf"], c["n_blocks"], dtype,
+                                      use_dropout=c.get("use_dropout", False))
+    else:
+        net = None
+    if net is not None:
+        if "drop_seed" in meta:
+            net.drop = seeded_dropout(meta["drop_seed"])
+        return net
     if n == "netD_B":
         return nets.Discriminator(c["input_nc"], c["ndf"], dtype)
     if n == "netD_A":
@@ -77,6 +97,8 @@ def _run_step(name, dtype):
     m = (step.AugStep if meta["aug"] else step.StochStep)(opt, dtype=dtype)
     vals = {n: recipe.values_for(net.shapes, n, meta["seed"], meta["flavour"]) for n, net in m.nets().items()}
     m.load(vals)
+    if "drop_seed" in meta:
+        m.set_dropout_seed(meta["drop_seed"])
     return arr, meta, m
 
 

@@ -62,7 +62,7 @@ def main():
     ops.set_precision("bf16x3")
     ok = run(1, 128, 128, 128, True)       # the N = 1 trunk geometry
     ok &= run(2, 64, 64, 128, True)        # two segments per grid row
-    ok &= run(1, 64, 128, 128, False)      # zero padding
+    ok &= run(3, 32, 64, 128, True)        # odd image count, 32-pixel-row map
     print("ALL OK" if ok else "FAILED")
     sys.exit(0 if ok else 1)
 

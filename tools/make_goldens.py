@@ -4,7 +4,7 @@ from /root/reference/augmented_cyclegan) on CPU with torch.  Test infrastructure
 runs only in the build container (the reference does not travel to the GPU box);
 the fixtures it writes are data (inputs + expected outputs), never reference source.
 
-    PYTHONDONTWRITEBYTECODE=1 python tools/make_goldens.py
+    PYTHONDONTWRITEBYTECODE=1 python tools/make_goldens.py [fixture names ...]     (no names: all of them)
 
 Parameters come from oracle/recipe.py (regenerated from seeds on every box), so the
 fixtures hold only inputs, outputs, gradients and digests.
@@ -32,8 +32,10 @@ import modules as rmod  # noqa: E402  (reference)
 import model as rmodel  # noqa: E402  (reference)
 
 from oracle import recipe  # noqa: E402
+from oracle import ops as oracle_ops  # noqa: E402  (dropout_keep: the seeded keep masks both sides regenerate)
 
 torch.set_num_threads(8)
+ONLY = set(a for a in sys.argv[1:] if not a.startswith("-"))   # regenerate just these fixtures
 OUT = os.path.join(ROOT, "tests", "golden")
 os.makedirs(OUT, exist_ok=True)
 META = dict(torch=torch.__version__, numpy=np.__version__, generator="tools/make_goldens.py",
@@ -89,12 +91,44 @@ def rnd(seed, shape):
     return np.random.RandomState(seed).normal(0, 1, shape).astype(np.float32)
 
 
+class InjectedDropout(object):
+    """--use_dropout fixtures: while active, torch.nn.Dropout.forward (the reference's blocks call nn.Dropout(0.5),
+    modules.py:167-168, 214-215) multiplies by the SEEDED keep mask oracle.ops.dropout_keep(seed, k, shape) of its k-th
+    call instead of drawing from torch's RNG stream — torch's own module is patched, never the reference's source — so
+    the branch is a pure function of the fixture's inputs on every side."""
+
+    def __init__(self, seed):
+        self.seed, self.k = seed, 0
+
+    def __enter__(self):
+        self.orig = nn.Dropout.forward
+        me = self
+
+        def forward(mod, x):
+            if not mod.training:
+                return x
+            keep = oracle_ops.dropout_keep(me.seed, me.k, tuple(x.shape), mod.p)
+            me.k += 1
+            return x * torch.from_numpy(keep.astype(np.float32) / (1.0 - mod.p)).to(x.dtype)
+        nn.Dropout.forward = forward
+        return self
+
+    def __exit__(self, *a):
+        nn.Dropout.forward = self.orig
+
+
 # ---------------------------------------------------------------- network-level goldens
-def net_case(name, build, net_name, inputs, seed=0, flavour="rich", buffers=False, cfg=None):
+def net_case(name, build, net_name, inputs, seed=0, flavour="rich", buffers=False, cfg=None, drop_seed=None):
+    if ONLY and name not in ONLY:
+        return
     net = load_recipe(build(), net_name, seed, flavour)
     net.train()
     tin = [torch.from_numpy(a.copy()).requires_grad_(True) for a in inputs]
-    out = net.forward(*tin)
+    if drop_seed is not None:
+        with InjectedDropout(drop_seed):
+            out = net.forward(*tin)
+    else:
+        out = net.forward(*tin)
     outs = list(out) if isinstance(out, tuple) else [out]
     Rs = [rnd(seed + 900 + i, tuple(o.shape)) for i, o in enumerate(outs)]
     loss = sum((o * torch.from_numpy(R)).sum() for o, R in zip(outs, Rs))
@@ -110,7 +144,8 @@ def net_case(name, build, net_name, inputs, seed=0, flavour="rich", buffers=Fals
     if buffers:
         for k, b in net.named_buffers():
             arr["buf/" + k] = b.detach().numpy().copy()
-    save(name, arr, kind="net", net=net_name, seed=seed, flavour=flavour, cfg=cfg or {})
+    extra = {} if drop_seed is None else {"drop_seed": drop_seed}
+    save(name, arr, kind="net", net=net_name, seed=seed, flavour=flavour, cfg=cfg or {}, **extra)
 
 
 def make_net_goldens():
@@ -130,6 +165,15 @@ def make_net_goldens():
              cfg=dict(nlatent=nl, input_nc=1, output_nc=1, ngf=ngf, n_blocks=3))
     net_case("G_A_B_s16_nb9", lambda: with_blocks(rnet.define_stochastic_G(nl, nc, nc, ngf), 9, True, ngf, nl),
              "netG_A_B", [x16, z2], cfg=dict(nlatent=nl, input_nc=nc, output_nc=nc, ngf=ngf, n_blocks=9))
+    # --norm batch (options.py:64 -> networks.py:23-31: BatchNorm2d in the stem, the tail AND inside ResnetBlock) and
+    # --use_dropout (options.py:65 -> modules.py:167-168, 214-215: Dropout(0.5) behind the first ReLU of both block types)
+    x16b = np.random.RandomState(18).uniform(-1, 1, (3, nc, 16, 16)).astype(np.float32)
+    net_case("G_B_A_s16_nb3_batchnorm", lambda: rnet.define_G(nc, nc, ngf, norm="batch"), "netG_B_A", [x16b], buffers=True,
+             cfg=dict(input_nc=nc, output_nc=nc, ngf=ngf, n_blocks=3, norm="batch"))
+    net_case("G_B_A_s16_nb3_dropout", lambda: rnet.define_G(nc, nc, ngf, use_dropout=True), "netG_B_A", [x16], drop_seed=31,
+             cfg=dict(input_nc=nc, output_nc=nc, ngf=ngf, n_blocks=3, use_dropout=True))
+    net_case("G_A_B_s16_nb3_dropout", lambda: rnet.define_stochastic_G(nl, nc, nc, ngf, use_dropout=True), "netG_A_B",
+             [x16, z2], drop_seed=32, cfg=dict(nlatent=nl, input_nc=nc, output_nc=nc, ngf=ngf, n_blocks=3, use_dropout=True))
     x64 = np.random.RandomState(14).uniform(-1, 1, (2, nc, 64, 64)).astype(np.float32)
     x40 = np.random.RandomState(15).uniform(-1, 1, (2, nc, 40, 40)).astype(np.float32)
     net_case("D_B_s40", lambda: rnet.define_D_B(nc, 8, "basic", "instance"), "netD_B", [x40],
@@ -182,10 +226,12 @@ def run_ref_step(m, rec, A, B, z, aug):
         pass
 
 
-def step_case(name, aug, opt_kw, N, S, steps=2, seed=0, flavour="rich", eps_seed=None):
+def step_case(name, aug, opt_kw, N, S, steps=2, seed=0, flavour="rich", eps_seed=None, drop_seed=None):
     """eps_seed: for --stoch_enc cases — the N(0,1) draw inside the reference's gauss_reparametrize
     (`std.data.new(N, 1, nl).normal_()`, model.py:19) is replaced by a fixed, recorded eps (torch.Tensor.normal_ is
     patched for tensors of exactly that shape while the step runs), so the branch becomes a pure function of the inputs."""
+    if ONLY and name not in ONLY:
+        return
     opt = ref_opt(**opt_kw)
     rec = Recorder()
     # recorders around the reference's own loss / clip functions
@@ -235,6 +281,9 @@ def step_case(name, aug, opt_kw, N, S, steps=2, seed=0, flavour="rich", eps_seed
         wrap_forward(m.netE_B, rec.enc, lambda o: (o[0].detach().numpy().copy(), o[1].detach().numpy().copy()))
 
     arr = {}
+    drop = InjectedDropout(drop_seed) if drop_seed is not None else None   # one mask counter over all steps
+    if drop is not None:
+        drop.__enter__()
     try:
         for st in range(steps):
             A, B, z = recipe.inputs(seed + st, N, opt.input_nc, opt.output_nc, S, opt.nlatent)
@@ -305,8 +354,11 @@ def step_case(name, aug, opt_kw, N, S, steps=2, seed=0, flavour="rich", eps_seed
     finally:
         rmodel.F.l1_loss, rmodel.criterion_GAN, torch.nn.utils.clip_grad_norm = orig_l1, orig_crit, orig_clip
         rmodel.log_prob_gaussian = orig_lpg
+        if drop is not None:
+            drop.__exit__()
+    extra = {} if drop_seed is None else {"drop_seed": drop_seed}
     save(name, arr, kind="step", aug=bool(aug), seed=seed, flavour=flavour, N=N, S=S, steps=steps,
-         opt={k: v for k, v in opt_kw.items()}, loss_keys=loss_keys, gnorm_keys=gn_keys)
+         opt={k: v for k, v in opt_kw.items()}, loss_keys=loss_keys, gnorm_keys=gn_keys, **extra)
 
 
 def make_step_goldens():
@@ -319,6 +371,9 @@ def make_step_goldens():
     # --stoch_enc branch (model.py:15-22, 414-419, 478-484, 501-502) with the reparametrisation noise injected
     step_case("step_aug_small_s64_stoch_enc", True, dict(small, stoch_enc=True), N=4, S=64, steps=2, flavour="init",
               eps_seed=77)
+    # --norm batch --use_dropout: BatchNorm2d in G_B_A / D_A / D_B, Dropout(0.5) in every residual block of both generators
+    step_case("step_aug_small_s64_bn_dropout", True, dict(small, norm="batch", use_dropout=True), N=4, S=64, steps=2,
+              flavour="init", drop_seed=55)
 
 
 if __name__ == "__main__":
@@ -509,7 +564,7 @@ def data_case(name="data_pipeline"):
     save(name, arr, kind="data")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not ONLY:
     make_key_fixture()
     make_init_fixture()
     eval_case("eval_aug_small_s64", dict(input_nc=3, output_nc=3, ngf=8, nef=8, ndf=8, nlatent=4), N=4, S=64)
