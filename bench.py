@@ -206,7 +206,9 @@ def dry_run(a):
                           "dtype": a.precision, "data": "synthetic",
                           "config": {"workload": "%s: %dx%dx%d, %d resblocks, batch=%d per GPU (global %d)"
                                                  % (a.config_name, a.size, a.size, a.nc, a.blocks, a.batch, a.batch * ws),
-                                     "parallelism": "dp%d" % ws}}), flush=True)
+                                     "parallelism": "dp%d" % ws,
+                                     "backend": td.get_backend() if ws > 1 else "none (single process)",
+                                     "world_size_seen": td.get_world_size() if ws > 1 else 1}}), flush=True)
 
 
 def main():
@@ -264,6 +266,25 @@ def main():
     barrier()
     dt = time.time() - t0
     ops.CONV_TIMERS[:] = []
+    # what the matrix pipe holds on THIS device in its present clock / power state: the library's register-only MFMA loop
+    # (acg_probe_mfma_rate), timed here, right BEHIND the timed region — printed beside the spec peak, never instead of it.
+    # (In front of the timed region its 150 ms at full matrix power cost the step 3 %: 145.8 against 141.6 ms, every trunk
+    # kernel 3-4 % slower — the chip starts the timed steps at a lower clock.)
+    sustained = None
+    if a.precision == "bf16x3" and rank == 0:
+        import ctypes
+        from dtgan_amd import _lib
+        scratch = torch.empty(512 * 1024, device=dev)
+        fl = ctypes.c_double(0.0)
+        best = 0.0
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.call("acg_probe_mfma_rate", ops._ptr(scratch), scratch.numel(), 120000, ctypes.byref(fl), ops._stream())
+            e1.record()
+            torch.cuda.synchronize()
+            best = max(best, fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+        sustained = best
     fused_paths = {k: round(v / float(a.steps), 2) for k, v in sorted(ops.FUSED.items())}
     if ws > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -288,21 +309,25 @@ def main():
     if (N, S, nc) != (32, 256, 3):
         traffic_src = "not measured for this shape (the committed counter runs are batch 32, 256x256x3)"
     for cand in ({"f32": ["r01_c_resblock_conv_traffic_f32.json"],
-                  "bf16x3": ["r05_resblock_conv_traffic_bf16x3.json", "r04_resblock_conv_traffic_bf16x3.json", "r03_resblock_conv_traffic_bf16x3.json", "r02_z_resblock_conv_traffic_bf16x3.json", "r02_p_resblock_conv_traffic_bf16x3.json", "r02_resblock_conv_traffic_bf16x3.json", "r01_f_resblock_conv_traffic_bf16x3.json"]}.get(a.precision, [])):
+                  "bf16x3": ["r06_resblock_conv_traffic_bf16x3.json", "r05_resblock_conv_traffic_bf16x3.json", "r04_resblock_conv_traffic_bf16x3.json", "r03_resblock_conv_traffic_bf16x3.json", "r02_z_resblock_conv_traffic_bf16x3.json", "r02_p_resblock_conv_traffic_bf16x3.json", "r02_resblock_conv_traffic_bf16x3.json", "r01_f_resblock_conv_traffic_bf16x3.json"]}.get(a.precision, [])):
         tj = os.path.join(ROOT, "profiles", cand)
         if os.path.exists(tj) and (N, S, nc) == (32, 256, 3):
             traffic, traffic_src = json.load(open(tj)).get("hbm_bytes_per_launch"), "profiles/" + cand
             break
     # the other two passes of the same layer (the data gradient is the largest line of the profile): per-pass launch time
     # and the three-pass aggregate = 3 x the forward's FLOPs over the sum of the three mean launch times.  The weight
-    # gradient's bracket includes its split-K reduction launch (~10 us).
+    # gradient's main kernel and its split-K reduction launch (~10 us) are timed apart; the aggregate charges both.
     passes = {}
     for nm, tm in (("fwd", t_res), ("dgrad", t_res_d), ("wgrad", t_res_w)):
-        v = tm.ms()
+        v = tm.ms_main()   # the kernel alone: the weight gradient's split-K reduction launch is timed apart (acg_debug_mid_event)
         if v:
             m_ = sum(v) / len(v)
             passes[nm] = {"kernel": tm.kernel, "launches_timed": len(v), "avg_launch_ms": round(m_, 4),
                           "achieved": round(flops / (m_ * 1e-3) / 1e12, 2), "frac": round(flops / (m_ * 1e-3) / 1e12 / peak, 4)}
+            if nm == "wgrad":
+                full = tm.ms()
+                passes[nm]["with_split_k_reduce_ms"] = round(sum(full) / len(full), 4)
+                passes[nm]["split_k_reduce_ms"] = round(sum(full) / len(full) - m_, 4)
     # data-gradient launches that also carry the first pass of the backward of the norm in front of the layer (its input read
     # as one more side stream, per-tile sums written: acg_conv2d_bwd_data_s16_sums) are timed apart; the aggregate below takes
     # the launch-weighted mean over BOTH kinds, i.e. it charges that norm work to the convolution
@@ -316,7 +341,7 @@ def main():
     agg = None
     if "fwd" in passes and "wgrad" in passes and dgrad_all:
         dmean = sum(dgrad_all) / len(dgrad_all)
-        tot = passes["fwd"]["avg_launch_ms"] + dmean + passes["wgrad"]["avg_launch_ms"]
+        tot = passes["fwd"]["avg_launch_ms"] + dmean + passes["wgrad"]["with_split_k_reduce_ms"]
         agg = {"ms_fwd_dgrad_wgrad": round(tot, 4), "dgrad_mean_all_launches_ms": round(dmean, 4),
                "achieved": round(3 * flops / (tot * 1e-3) / 1e12, 2), "frac": round(3 * flops / (tot * 1e-3) / 1e12 / peak, 4)}
     # the kernel instance of the resblock layer that costs the step most (launches per step x mean launch time) — what a
@@ -325,7 +350,7 @@ def main():
     dominant = None
     inst = {}
     for nm, tm in (("fwd", t_res), ("dgrad", t_res_d), ("dgrad_sums", t_res_ds), ("wgrad", t_res_w)):
-        for k, v in tm.by_kernel().items():
+        for k, v in tm.by_kernel(main=True).items():   # kernels alone, as a rocprofv3 kernel table lists them
             inst.setdefault((nm, k), []).extend(v)
     if inst:
         (nm, k), v = max(inst.items(), key=lambda kv: sum(kv[1]))
@@ -346,17 +371,20 @@ def main():
                                "Augmented CycleGAN train_instance), batch=%d per GPU (global %d)"
                                % (a.config_name, S, S, nc, a.blocks, N, N * ws),
                    "parallelism": "dp%d" % ws, "batchnorm": "sync" if a.sync_bn else "per-rank",
+                   # what torch.distributed itself reports (a SCALE record shows RCCL saw N ranks)
+                   "backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else "none (single process)"),
+                   "world_size_seen": (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1),
                    "loss_G_A": round(losses["G_A"], 5)},
         "roofline": {"bound": "mfma", "kernel": "%s (resblock 3x3 reflect 128->128 fwd)" % t_res.kernel,
                      "achieved": None if achieved is None else round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": None if achieved is None else round(achieved / peak, 4),
-                     # beside — never instead of — the spec-peak fraction: what the matrix pipe HOLDS under load.  A register-only
-                     # loop of v_mfma_f32_16x16x32_bf16 on random data sustains 1.88-1.97 PFLOP/s on this chip (DVFS; the
-                     # persistent kernel's bare loop runs 1.97: tools/probes/mfma_rate.hip, DESIGN_LOG.md R5.1), i.e. 633 TFLOP/s
-                     # of algorithmic bf16x3 work
-                     "peak_sustained": (round(1900.0 / 3, 1) if a.precision == "bf16x3" else None),
-                     "frac_of_sustained": (None if achieved is None or a.precision != "bf16x3" else round(achieved / (1900.0 / 3), 4)),
-                     "peak_sustained_source": "tools/probes/mfma_rate.hip (register-only MFMA loop, random data); DESIGN_LOG.md R5.1 (0.235 ms bare loop = 1.97 PFLOP/s)",
+                     # beside — never instead of — the spec-peak fraction: what the matrix pipe HOLDS under load on this device,
+                     # measured in this process right behind the timed region (best of three ~50 ms runs of the library's
+                     # register-only v_mfma_f32_16x16x32_bf16 loop on random data); / 3 = algorithmic bf16x3 work
+                     "peak_sustained": (None if sustained is None else round(sustained / 3, 1)),
+                     "frac_of_sustained": (None if achieved is None or sustained is None else round(achieved / (sustained / 3), 4)),
+                     "peak_sustained_source": (None if sustained is None else "measured live: acg_probe_mfma_rate (register-only bf16 MFMA loop, random "
+                                               "operands, 8 waves per CU) ran at %.0f TFLOP/s executed on this device right behind the timed region" % sustained),
                      "traffic": traffic,
                      "traffic_source": traffic_src, "launches_timed": len(ms), "avg_launch_ms": round(kern_ms, 4),
                      "flops_per_launch": flops, "passes": passes, "three_pass_aggregate": agg, "dominant_by_time": dominant},
@@ -366,7 +394,7 @@ def main():
                          "launches_timed": len(ms2), "avg_launch_ms": round(k2, 4), "bytes_per_launch": bytes2},
     }
     out["fused_paths"] = {"per_step": fused_paths, "note": "launches per training step that took each fused path (ops.FUSED); "
-                          "config 3 expects 58 norm_bwd_sums_from_dgrad (54 trunk + 4 row pipeline), 72 wgrad_s16, 18 relu bitmask links"}
+                          "config 3 expects 70 norm_bwd_sums_from_dgrad (54 trunk + 16 full-resolution layers), 72 wgrad_s16, 18 relu bitmask links"}
     if ws == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a, [x for x in argv if x != "--no-cpu-baseline"])
     print(json.dumps(out), flush=True)

@@ -103,6 +103,8 @@ SIGNATURES = {
     "acg_conv2d_fwd_stats_supported": (c_int, [_P]),
     "acg_conv2d_bwd_data_add_supported": (c_int, [_P]),
     "acg_conv2d_bwd_data_add": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "acg_debug_mid_event": (c_int, [_P]),
+    "acg_probe_mfma_rate": (c_int, [_P, c_size_t, c_int, ctypes.POINTER(ctypes.c_double), _P]),
     "acg_mask_apply": (c_int, [_P, _P, _P, c_size_t, _P]),
     "acg_dropout_apply": (c_int, [_P, _P, c_float, _P, c_size_t, _P]),
     "acg_conv2d_bwd_data_relu": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, _P]),
@@ -145,7 +147,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 115   # include/acgan_hip.h ACG_VERSION this binding was written against
+ABI_VERSION = 116   # include/acgan_hip.h ACG_VERSION this binding was written against
 
 
 class AcgError(RuntimeError):

@@ -15,6 +15,7 @@ extern int g_acg_conv_impl;
 // timings on one GPU box).  Development aids, not configuration: they are honoured only when ACG_DEBUG_SWITCHES is set, so a
 // stray variable in a production environment cannot change which kernels run.
 bool acg_debug_switch(const char *name);
+void acg_record_mid_event(hipStream_t st);   // acg_debug_mid_event: bench.py times a main kernel and its reduction apart
 
 #define ACG_REQUIRE(cond, ...)                 \
     do {                                       \

@@ -948,8 +948,10 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
             if (ns != nullptr) {   // fp32 operands: only the persistent row pipeline (conv_rows.hip) emits the norm-backward sums
                 g.ns_x = ns->x; g.ns_mean = ns->mean; g.ns_rstd = ns->rstd; g.ns_gamma = ns->gamma; g.ns_beta = ns->beta;
                 g.ns_gstride = ns->gstride; g.ns_mask = ns->sign_mask; g.ns_act = ns->act; g.ns_part = ns->part;
-                ACG_REQUIRE(ns->part != nullptr && !thin_in_valu_dgrad(d) && acg_conv_rows_ok(g, t),
-                            "dgrad: norm sums on fp32 operands need the row-pipeline geometry (query acg_conv2d_bwd_data_sums_supported)");
+                // (which kernel takes them is checked where the launch is dispatched: conv_bf16.hip / conv_igemm.hip refuse a
+                // geometry that would land on a kernel without the sums epilogue)
+                ACG_REQUIRE(ns->part != nullptr && !thin_in_valu_dgrad(d) && !frame && acg_conv2d_bwd_data_sums_supported(d),
+                            "dgrad: norm sums on fp32 operands: unsupported geometry (query acg_conv2d_bwd_data_sums_supported)");
             }
             rc = thin_in_valu_dgrad(d) ? thin_out_launch(src, wb, bias, out, g, t, st) : acg_igemm_launch(src, wb, bias, out, g, t, st);
         }
@@ -972,6 +974,7 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
     ACG_REQUIRE(!thin_out(d), "dgrad: stride 2 with <= 4 output channels is not supported by the thin packing");
     // stride 2: four sub-pixel phases, each a dense small-tap convolution (no zero insertion)
     ACG_REQUIRE(d->pad_mode == ACG_PAD_ZERO, "dgrad: stride 2 needs zero padding");
+    ACG_REQUIRE(addend == nullptr && relu_src == nullptr && relu_mask == nullptr && !in_s16 && !out_s16, "dgrad: stride 2 takes no fused side inputs");
     g.Hout = d->Hi; g.Wout = d->Wi; g.os = 2;
     auto phase_taps = [&](int py, int px, Taps &tt, int base) {
         int n = 0;
@@ -1014,9 +1017,17 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
         Geom g4 = g;
         g4.nphase = 0; g4.ph_ntaps = 0;
         Taps plan;
+        if (ns != nullptr) {   // the first backward pass of the norm in front of the stride-2 convolution rides on the four-phase tile
+            g4.ns_x = ns->x; g4.ns_mean = ns->mean; g4.ns_rstd = ns->rstd; g4.ns_gamma = ns->gamma; g4.ns_beta = ns->beta;
+            g4.ns_gstride = ns->gstride; g4.ns_mask = ns->sign_mask; g4.ns_act = ns->act; g4.ns_part = ns->part;
+            ACG_REQUIRE(ns->part != nullptr && stats == nullptr && acg_igemm_ph4_ok(g4) && acg_ph4_plan(t, ntp, &plan),
+                        "dgrad: norm sums on a stride-2 data gradient need the four-phase tile (query acg_conv2d_bwd_data_sums_supported)");
+            return acg_igemm_ph4_launch(src, wb, bias, dst, g4, plan, g.w_elems, st);
+        }
         if (acg_igemm_ph4_ok(g4) && acg_ph4_plan(t, ntp, &plan)) return acg_igemm_ph4_launch(src, wb, bias, dst, g4, plan, g.w_elems, st);
         return acg_igemm_launch(src, wb, bias, dst, g, t, st);
     }
+    ACG_REQUIRE(ns == nullptr, "dgrad: norm sums on a stride-2 data gradient need the four-phase tile (query acg_conv2d_bwd_data_sums_supported)");
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
             g.oy0 = py; g.ox0 = px;
@@ -1258,12 +1269,30 @@ extern "C" int acg_conv2d_bwd_data_s16_sums(const acg_conv_desc *d, const void *
 }
 
 // The same on fp32 operands, where the data gradient runs on the persistent row pipeline (conv_rows_x3: zero-padded 3x3 stride 1,
-// 32 output and 64 input channels of the convolution, width a multiple of 128): part[N][Hi*Wi/128][2][Ci], summed over the
-// chunks by acg_norm_bwd_partials like the pre-split kernel's (the sums of a workgroup's rows sit in its first chunk)
+// 32 output and 64 input channels of the convolution, width a multiple of 128), on the four-phase tile of the stride-2 3x3
+// layer (igemm_conv_ph4<SUMS>: 64 input channels, Wo a multiple of 128), on the generic tile (the 32 -> 64 layer's data gradient)
+// or on conv_thinrow_x3 (the head's): part[N][Hi*Wi/128][2][Ci], summed over the chunks by acg_norm_bwd_partials like the
+// pre-split kernel's (where a workgroup owns several chunks its sums sit in the first, zeros in the others)
 extern "C" int acg_conv2d_bwd_data_sums_supported(const acg_conv_desc *d)
 {
     if (d == nullptr || g_acg_precision != ACG_PREC_BF16X3 || g_acg_conv_impl != ACG_IMPL_MFMA || acg_debug_switch("ACG_NO_ROWS")) return 0;
     if (check_desc(d, "acg_conv2d_bwd_data_sums_supported") != ACG_OK) return 0;
+    // the four-phase tile of the stride-2 3x3 data gradient (igemm_conv_ph4<SUMS>): 64 input channels of the convolution, phase
+    // grid rows that are whole 128-pixel tiles
+    static const bool no_tile_sums = acg_debug_switch("ACG_NO_TILE_SUMS");   // A/B switch: the three producers of round 6
+    if (!no_tile_sums && d->K == 3 && d->stride == 2 && d->pad == 1 && d->pad_mode != ACG_PAD_REFLECT && d->Ci == 64 && d->Co % 32 == 0 &&
+        d->Hi == 2 * d->Ho && d->Wi == 2 * d->Wo && d->Wo % 128 == 0 && !acg_debug_switch("ACG_NO_PH4"))
+        return 1;
+    // the 7x7 (K <= 7) stride-1 zero-padded layer with a C4 image on its output side (the head, networks.py:187-188):
+    // conv_thinrow_x3's whole 8 x 16 tiles
+    if (!no_tile_sums && d->stride == 1 && d->pad_mode != ACG_PAD_REFLECT && thin_out(d) && d->Co == 4 && d->Ci == 32 && d->K >= 2 && d->K <= 7 &&
+        d->Hi == d->Ho && d->Wi == d->Wo && d->Hi % 8 == 0 && d->Wi % 16 == 0 && !thin_in_valu_dgrad(d) && !acg_debug_switch("ACG_NO_THINROW"))
+        return 1;
+    // the generic 128-pixel tile on the data gradient of the zero-padded 3x3 stride-1 32 -> 64 layer (networks.py:164: 64 gathered,
+    // 32 written channels — the mirror shape the row pipeline does not take): whole tiles inside one image
+    if (!no_tile_sums && d->K == 3 && d->stride == 1 && d->pad == 1 && d->pad_mode != ACG_PAD_REFLECT && d->Ci == 32 && d->Co == 64 &&
+        d->Hi == d->Ho && d->Wi == d->Wo && ((long long)d->Hi * d->Wi) % 128 == 0)
+        return 1;
     return d->K == 3 && d->stride == 1 && d->pad == 1 && d->pad_mode != ACG_PAD_REFLECT && d->Co == 32 && d->Ci == 64 && d->Hi == d->Ho &&
            d->Wi == d->Wo && d->Wi % 128 == 0 ? 1 : 0;
 }
@@ -1423,6 +1452,7 @@ static int wgrad_common(const acg_conv_desc *d, const float *x_side, const float
         rc = acg_wgrad_launch(x_side, g_side, (float *)ws, g, t, st);
     }
     if (rc) return rc;
+    acg_record_mid_event(st);
     const int Cp = bias_from == 1 ? g.CoP : g.CiP, Cr = g.bias_from ? (bias_from == 1 ? Or : Ir) : 0;
     const bool quad = g.thin != 2 && Or % 4 == 0 && g.CoP % 4 == 0;   // the kernel's four-channels-per-element path
     const long long total = (long long)t.n * Ir * (quad ? Or / 4 : Or);
@@ -1469,6 +1499,7 @@ static int wgrad_thin_out(const acg_conv_desc *d, const float *x, const float *d
     }
     int rc = acg_wgrad_launch(dy, x, (float *)ws, g, t, st);
     if (rc) return rc;
+    acg_record_mid_event(st);
     const long long total = (long long)t.n * Ir * Or;
     const int el_log2 = (total < 8192 && g.nsplit >= 64) ? 4 : 6;
     const int wblocks = acg_cdiv(total, 1 << el_log2);

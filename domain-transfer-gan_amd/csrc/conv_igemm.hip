@@ -306,9 +306,9 @@ int acg_igemm_launch(const float *in, const float *wp, const float *bias, float 
     const Taps t = acg_taps_pack(t0);
     const int bn = bn_for(g.Cout);
     if (g_acg_precision != ACG_PREC_F32 && g_acg_conv_impl == ACG_IMPL_MFMA && !g0.thin) return acg_igemm_bf16_launch(in, wp, bias, out, g0, t, bn, g0.w_elems, st);
-    ACG_REQUIRE(g0.ns_part == nullptr, "igemm_conv: norm-backward sums requested on a kernel that does not emit them");
     if (g0.thin && acg_conv_thinrow_ok(g0, t))   // C4 image -> 32 channels: the row-packed weights sit behind the regular region
         return acg_conv_thinrow_launch(in, wp + g0.w_elems, bias, out, g0, t, st);
+    ACG_REQUIRE(g0.ns_part == nullptr, "igemm_conv: norm-backward sums requested on a kernel that does not emit them");
     const long long nimg = g.Mtot / ((long long)g.GH * g.GW);
     const long long in_bytes = nimg * g.Hin * g.Win * g.Cin * 4;
     ACG_REQUIRE(in_bytes < (1LL << 32), "igemm_conv: gathered tensor of %lld bytes exceeds the 4 GiB buffer-addressing limit", in_bytes);

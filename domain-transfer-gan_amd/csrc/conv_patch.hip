@@ -466,12 +466,53 @@ __global__ __launch_bounds__(256) void conv_thinrow_x3(const float *__restrict__
                 tile[((wave * 2 + r) * PT_TW + 4 * kg + k) * 32 + co] = acg_apply_act(acc[r][ct][k] + bv, g.stats != nullptr ? (int)ACG_ACT_NONE : g.act);
     }
     __syncthreads();
+    // Norm-backward sums (acg_conv2d_bwd_data_sums, round 6: the data gradient of the 7x7 head is the gradient w.r.t. the output of
+    // the norm + ReLU in front of it, networks.py:184-188): the norm's input ns_x is read at the pixels the tile stores and
+    // sum gy, sum gy * xhat (gy = dx * [norm output > 0], recomputed from x) leave per tile — whole tiles, no bias / activation
+    const bool nsum = g.ns_part != nullptr;   // (uniform)
+    const int nc4 = tid & 7;                  // a thread's channel quad is the same for its four pixels
+    f32x4 ns1 = {0.f, 0.f, 0.f, 0.f}, ns2 = ns1, nmu = ns1, nrs = ns1, nga = {1.f, 1.f, 1.f, 1.f}, nbe = nga;
+    const bool ns_relu = nsum && g.ns_act == ACG_ACT_RELU;
+    if (nsum) {
+        nmu = *(const f32x4 *)(g.ns_mean + n * 32 + nc4 * 4);
+        nrs = *(const f32x4 *)(g.ns_rstd + n * 32 + nc4 * 4);
+        if (ns_relu) {
+            nga = *(const f32x4 *)(g.ns_gamma + g.ns_gstride * n + nc4 * 4);
+            nbe = *(const f32x4 *)(g.ns_beta + g.ns_gstride * n + nc4 * 4);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < PT_TH * PT_TW * 8 / 256; ++k) {   // 4 float4 per thread: 8 lanes per pixel
         const int idx = tid + 256 * k, pix = idx >> 3, c4 = idx & 7;
         const int gy = gy0 + pix / PT_TW, gx = gx0 + pix % PT_TW;
-        if (gy < g.GH && gx < g.GW && c4 * 4 < g.Cout)
-            *(f32x4 *)(out + (((long long)n * g.Hout + gy) * g.Wout + gx) * g.Cout + c4 * 4) = *(const f32x4 *)&tile[pix * 32 + c4 * 4];
+        if (gy < g.GH && gx < g.GW && c4 * 4 < g.Cout) {
+            const long long o = (((long long)n * g.Hout + gy) * g.Wout + gx) * g.Cout + c4 * 4;
+            const f32x4 v = *(const f32x4 *)&tile[pix * 32 + c4 * 4];
+            *(f32x4 *)(out + o) = v;
+            if (nsum) {
+                const f32x4 xh = (*(const f32x4 *)(g.ns_x + o) - nmu) * nrs;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float gyv = (ns_relu && !(xh[q] * nga[q] + nbe[q] > 0.f)) ? 0.f : v[q];   // same expression as norm_apply_kernel
+                    ns1[q] += gyv;
+                    ns2[q] += gyv * xh[q];
+                }
+            }
+        }
+    }
+    if (nsum) {   // 32 threads share a channel quad: fold through the tile buffer in fixed order
+        __syncthreads();
+        *(f32x4 *)&tile[(tid >> 3) * 64 + nc4 * 8] = ns1;
+        *(f32x4 *)&tile[(tid >> 3) * 64 + nc4 * 8 + 4] = ns2;
+        __syncthreads();
+        if (tid < 64) {
+            const int c = tid & 31, which = tid >> 5;
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) a += tile[r * 64 + (c >> 2) * 8 + which * 4 + (c & 3)];
+            g.ns_part[((long long)(n * tiles_y * tiles_x + ty * tiles_x + tx) * 2 + which) * 32 + c] = a;
+        }
+        return;
     }
     if (g.stats != nullptr) {   // (uniform; whole tiles only: the launcher checks)
         const int c = tid & 31, h = tid >> 5;   // channel c, pixels 16 h .. 16 h + 15
@@ -510,6 +551,11 @@ bool acg_conv_thinrow_ok(const Geom &g, const Taps &t)
     if (off || g_acg_precision != ACG_PREC_BF16X3 || g_acg_conv_impl != ACG_IMPL_MFMA || !g.thin || g.fold_p) return false;
     if (g.Cin != 4 || g.Cout != 32 || g.ncols_pad != 32 || g.os != 1 || g.is != 1 || g.oy0 != 0 || g.ox0 != 0 || t.n < 4) return false;
     if (g.stats != nullptr && (g.GH % PT_TH != 0 || g.GW % PT_TW != 0 || g.act != ACG_ACT_NONE)) return false;   // whole 128-pixel tiles
+    if (g.ns_part != nullptr && (g.stats != nullptr || g.GH % PT_TH != 0 || g.GW % PT_TW != 0 || g.act != ACG_ACT_NONE || g.ns_x == nullptr ||
+                                 g.ns_mean == nullptr || g.ns_rstd == nullptr || g.ns_mask != nullptr ||
+                                 (g.ns_act != ACG_ACT_NONE && (g.ns_act != ACG_ACT_RELU || g.ns_gamma == nullptr || g.ns_beta == nullptr)) ||
+                                 (g.ns_gstride != 0 && (g.ns_gstride < 32 || g.ns_gstride % 4 != 0))))
+        return false;
     int a, b, kh, kw;
     return patchn_window(t, &a, &b, &kh, &kw) && g.Hin >= 2 && g.Win >= 2;
 }
@@ -519,6 +565,7 @@ int acg_conv_thinrow_launch(const float *in, const void *wr, const float *bias, 
 {
     int ymin, xmin, KH, KW;
     ACG_REQUIRE(acg_conv_thinrow_ok(g, t) && patchn_window(t, &ymin, &xmin, &KH, &KW), "conv_thinrow_x3: unsupported geometry");
+    ACG_REQUIRE(g.ns_part == nullptr || bias == nullptr, "conv_thinrow_x3: the norm sums ride on a plain data gradient (no bias)");
     const long long nimg = g.Mtot / ((long long)g.GH * g.GW);
     const long long in_bytes = nimg * g.Hin * g.Win * g.Cin * 4;
     ACG_REQUIRE(in_bytes < (1LL << 32), "conv_thinrow_x3: gathered tensor exceeds the 4 GiB buffer-addressing limit");
@@ -528,7 +575,7 @@ int acg_conv_thinrow_launch(const float *in, const void *wr, const float *bias, 
     else
         hipLaunchKernelGGL((conv_thinrow_x3<false>), dim3((unsigned)blocks), dim3(256), 0, st, in, (const __bf16 *)wr, bias, out, g, ymin, xmin, KH, (unsigned)in_bytes);
     ACG_CHECK_LAUNCH("conv_thinrow_x3");
-    acg_note_kernel("conv_thinrow_x3<REFLECT=%d> (%dx%d window)", g.reflect ? 1 : 0, KH, KW);
+    acg_note_kernel("conv_thinrow_x3<REFLECT=%d%s> (%dx%d window)", g.reflect ? 1 : 0, g.ns_part != nullptr ? ",SUMS=1" : "", KH, KW);
     return ACG_OK;
 }
 

@@ -39,6 +39,70 @@ bool acg_debug_switch(const char *name)
 }
 extern "C" int acg_version(void) { return ACG_VERSION; }
 
+// bench.py's timing hook: an event the NEXT weight-gradient entry point of this thread records on its stream between its
+// main kernel and its split-K reduction, so that the two are timed apart (then cleared)
+static thread_local void *g_mid_event = nullptr;
+extern "C" int acg_debug_mid_event(void *event) { g_mid_event = event; return ACG_OK; }
+void acg_record_mid_event(hipStream_t st)
+{
+    if (g_mid_event != nullptr) {
+        (void)hipEventRecord((hipEvent_t)g_mid_event, st);
+        g_mid_event = nullptr;
+    }
+}
+
+// What the matrix pipe HOLDS under load on this device, now: a register-only loop of v_mfma_f32_16x16x32_bf16 on random bf16
+// operands (no LDS, no memory), two waves per SIMD on every CU — tools/probes/mfma_rate.hip inside the library, so that
+// bench.py can print the sustained ceiling it measured itself next to the spec peak.  The caller times the launch;
+// *flops_out = the FLOPs it executes.
+typedef __bf16 probe_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned probe_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void mfma_rate_probe_kernel(float *__restrict__ out, int iters)
+{
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+    probe_bf16x8 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {   // two bf16 per word: hashed sign / mantissa, exponents near 1.0
+        probe_u32x4 w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned h = (tid * 8u + i) * 2654435761u + k * 40503u;
+            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            const unsigned lo = (h & 0x807fu) | ((120u + (h >> 20) % 8u) << 7), hi = ((h >> 8) & 0x807fu) | ((120u + (h >> 24) % 8u) << 7);
+            w[k] = lo | (hi << 16);
+        }
+        if (i < 4) a[i] = __builtin_bit_cast(probe_bf16x8, w); else b[i - 4] = __builtin_bit_cast(probe_bf16x8, w);
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    float keep = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) keep += acc[i][j][0] + acc[i][j][3];
+    if (keep == 12345.678f) out[tid] = keep;
+}
+extern "C" int acg_probe_mfma_rate(float *scratch, size_t scratch_floats, int iters, double *flops_out, void *stream)
+{
+    int dev = 0, cus = 0;
+    ACG_REQUIRE(hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0,
+                "acg_probe_mfma_rate: no device");
+    ACG_REQUIRE(scratch != nullptr && scratch_floats >= (size_t)cus * 512 && iters > 0 && flops_out != nullptr, "acg_probe_mfma_rate: scratch of >= 512 floats per CU");
+    hipLaunchKernelGGL(mfma_rate_probe_kernel, dim3(cus), dim3(512), 0, (hipStream_t)stream, scratch, iters);
+    ACG_CHECK_LAUNCH("mfma_rate_probe_kernel");
+    *flops_out = (double)cus * 8 * iters * 16 * 2.0 * 16 * 16 * 32;
+    return ACG_OK;
+}
+
 // ---------------------------------------------------------------- activation backward
 __global__ void act_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, float *__restrict__ dx,
                                long long n4, int act)

@@ -223,33 +223,48 @@ class ConvTimer(object):
         self.match, self.kind, self.events, self.kernel = match, kind, [], None
 
     class _Span(object):
-        def __init__(self, timers):
-            self.timers = timers
+        def __init__(self, timers, mid=False):
+            self.timers, self.em = timers, None
             if timers:
                 self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                if mid:   # weight gradient: the library records this event between its main kernel and the split-K reduction
+                    self.em = torch.cuda.Event(enable_timing=True)
+                    self.em.record()   # (creates the hipEvent_t; the library's record replaces this timestamp)
+                    _lib.call("acg_debug_mid_event", ctypes.c_void_p(self.em.cuda_event))
                 self.e0.record()
 
         def done(self):
             if self.timers:
                 self.e1.record()
+                if self.em is not None:
+                    _lib.call("acg_debug_mid_event", None)   # (an entry point without a reduction must not leave it armed)
                 k = _lib.query("acg_last_kernel").decode()   # what the dispatcher actually launched
                 for t in self.timers:
-                    t.events.append((self.e0, self.e1, k))
+                    t.events.append((self.e0, self.e1, k, self.em))
                     t.kernel = k
 
     @staticmethod
     def span(kind, d):
         """-> object whose done() closes the bracket (a no-op unless a timer of this kind matches descriptor d)"""
-        return ConvTimer._Span([t for t in CONV_TIMERS if t.kind == kind and t.match(d)])
+        return ConvTimer._Span([t for t in CONV_TIMERS if t.kind == kind and t.match(d)], mid=(kind == "wgrad"))
 
     def ms(self):
-        return [a.elapsed_time(b) for a, b, _ in self.events]
+        return [a.elapsed_time(b) for a, b, _, _ in self.events]
 
-    def by_kernel(self):
+    def ms_main(self):
+        """the main kernel alone where the pass has a second launch behind it (weight gradient: its split-K reduction)"""
+        return [self._main(a, b, m) for a, b, _, m in self.events]
+
+    @staticmethod
+    def _main(a, b, m):
+        v = a.elapsed_time(m) if m is not None else -1.0
+        return v if v > 0.0 else a.elapsed_time(b)   # (not recorded by the library: the place-holder stamp lies before `a`)
+
+    def by_kernel(self, main=False):
         """-> {kernel label: [ms per launch]} (one pass of one layer can be served by several template instances)"""
         out = {}
-        for a, b, k in self.events:
-            out.setdefault(k, []).append(a.elapsed_time(b))
+        for a, b, k, m in self.events:
+            out.setdefault(k, []).append(self._main(a, b, m) if main else a.elapsed_time(b))
         return out
 
 
@@ -546,11 +561,12 @@ class Conv2dFn(torch.autograd.Function):
                 ctx.link_in.done = True
             elif (dskip is None and ctx.norm_sums is not None and ctx.norm_sums.x is not None and ctx.norm_sums.mask is None and
                   tuple(ctx.norm_sums.x.shape) == tuple(dx.shape) and _lib.query("acg_conv2d_bwd_data_sums_supported", ctypes.byref(d))):
-                # dx is the gradient w.r.t. the output of the norm in front: the row pipeline leaves that norm's backward sums
+                # dx is the gradient w.r.t. the output of the norm in front: the data-gradient kernel (row pipeline, four-phase
+                # stride-2 tile, generic tile, thin-row kernel of the head) leaves that norm's backward sums
                 ns = ctx.norm_sums
                 part = torch.empty((d.N, (d.Hi * d.Wi) // STATS_ROWS, 2, d.Ci), device=dx.device, dtype=torch.float32)
                 desc = ns.desc(part)
-                _fused("dgrad_rows_norm_sums")
+                _fused("dgrad_f32_norm_sums")
                 _lib.call("acg_conv2d_bwd_data_sums", ctypes.byref(d), _ptr(g), _ptr(pk.wb), _ptr(dx), _ptr(ws), nb, ctypes.byref(desc), st)
                 ns.part, ns.dx = part, dx
             else:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ACG_VERSION 115
+#define ACG_VERSION 116
 
 typedef enum {
     ACG_OK = 0,
@@ -63,6 +63,14 @@ const char *acg_last_error(void);
  * "igemm_conv_x3_ws<REFLECT=1,STATS=1,ROWP=1>").  Diagnostic: the reference delegates algorithm choice to
  * torch.nn.Conv2d / cuDNN (networks.py:158-189) and cannot say what ran; bench.py labels its roofline with this. */
 const char *acg_last_kernel(void);
+/* Measurement hooks (bench.py; the reference has no counterpart — its timing is train.py:243's wall clock per image).
+ * acg_debug_mid_event: `event` (a hipEvent_t) is recorded by the NEXT weight-gradient entry point of the calling thread
+ * between its main kernel and its split-K reduction launch, then forgotten: the two are timed apart.
+ * acg_probe_mfma_rate: enqueues a register-only v_mfma_f32_16x16x32_bf16 loop (`iters` x 16 MFMAs per wave, 8 waves per
+ * CU, random operands, no LDS / memory traffic) and returns the FLOPs it executes in *flops_out; timed by the caller it
+ * gives the matrix rate the device sustains in its present clock / power state (scratch: >= 512 floats per CU, never written). */
+int acg_debug_mid_event(void *event);
+int acg_probe_mfma_rate(float *scratch, size_t scratch_floats, int iters, double *flops_out, void *stream);
 /* selects the convolution implementation for subsequent calls on this process
  * (MFMA implicit GEMM = product path; DIRECT = naive one-thread-per-output kernels kept
  * as an on-device cross-check).  Both are HIP kernels; there is no CPU path. */
@@ -166,8 +174,11 @@ int acg_conv2d_bwd_data_s16_sums_supported(const acg_conv_desc *d);
 int acg_conv2d_bwd_data_s16_sums(const acg_conv_desc *d, const void *dy_s16, const float *wb, float *dx, void *ws,
                                  size_t ws_bytes, const float *addend, const unsigned *addend_sign_mask,
                                  const acg_norm_sums *ns, void *stream);
-/* ... and on fp32 operands where the data gradient runs on the persistent row pipeline (zero-padded 3x3 stride 1, Co == 32,
- * Ci == 64, Wi % 128 == 0): ns->sign_mask must be NULL (the activation mask is recomputed from ns->x) */
+/* ... and on fp32 operands (round 6: every norm of a generator whose consumer is a convolution): the persistent row pipeline
+ * (zero-padded 3x3 stride 1, Co == 32, Ci == 64, Wi % 128 == 0), the four-phase tile of the stride-2 3x3 layer (Ci == 64,
+ * Wo % 128 == 0), the generic tile (3x3 stride 1, Ci == 32, Co == 64, Hi * Wi % 128 == 0) and the thin-row kernel of the 7x7
+ * head (Ci == 32, a C4 image on the output side, Hi % 8 == 0, Wi % 16 == 0).  ns->sign_mask must be NULL (the activation
+ * mask is recomputed from ns->x); part[N][Hi * Wi / 128][2][Ci], every entry written. */
 int acg_conv2d_bwd_data_sums_supported(const acg_conv_desc *d);
 int acg_conv2d_bwd_data_sums(const acg_conv_desc *d, const float *dy, const float *wb, float *dx, void *ws, size_t ws_bytes,
                              const acg_norm_sums *ns, void *stream);
