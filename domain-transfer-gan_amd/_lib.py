@@ -40,6 +40,11 @@ class AdamGroup(ctypes.Structure):
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_size_t), ("sumsq", c_void_p)]
 
 
+class PackItem(ctypes.Structure):
+    """acg_pack_item (include/acgan_hip.h)."""
+    _fields_ = [("w", c_void_p), ("wf", c_void_p), ("wb", c_void_p), ("Or", c_int), ("Ir", c_int), ("K", c_int), ("Ci", c_int), ("Co", c_int)]
+
+
 MAX_SEGMENTS = 96
 
 
@@ -103,6 +108,8 @@ SIGNATURES = {
     "acg_conv2d_fwd_stats_supported": (c_int, [_P]),
     "acg_conv2d_bwd_data_add_supported": (c_int, [_P]),
     "acg_conv2d_bwd_data_add": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "acg_pack_conv_weights_multi_supported": (c_int, [c_int, c_int, c_int]),
+    "acg_pack_conv_weights_multi": (c_int, [_P, c_int, _P]),
     "acg_debug_mid_event": (c_int, [_P]),
     "acg_probe_mfma_rate": (c_int, [_P, c_size_t, c_int, ctypes.POINTER(ctypes.c_double), _P]),
     "acg_mask_apply": (c_int, [_P, _P, _P, c_size_t, _P]),
@@ -147,7 +154,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 116   # include/acgan_hip.h ACG_VERSION this binding was written against
+ABI_VERSION = 117   # include/acgan_hip.h ACG_VERSION this binding was written against
 
 
 class AcgError(RuntimeError):

@@ -70,14 +70,14 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, int Or, int Ir, 
 
 // bf16 packing: wf16 [tap][Ci/16][CoP][16], wb16 [tap][Co/16][CiP][16] (same element counts, half the bytes)
 // split != 0: also write lo = bf16(w - float(hi)) at [n_elems ...) of each buffer (the buffers are sized in floats)
-__global__ void pack_weight_bf16_kernel(const float *__restrict__ w, int Or, int Ir, int K, int Ci, int Co, int CoP,
-                                        int CiP, __bf16 *__restrict__ wf, __bf16 *__restrict__ wb, int split)
+// i0 / stride: the calling thread's first element and step over the layer's nf + nb elements
+__device__ __forceinline__ void pack_bf16_body(const float *__restrict__ w, int Or, int Ir, int K, int Ci, int Co, int CoP, int CiP,
+                                               __bf16 *__restrict__ wf, __bf16 *__restrict__ wb, int split, long long i0, long long stride)
 {
     const int KK = K * K;
     const long long nf = (long long)KK * (Ci / 16) * CoP * 16;
     const long long nb = (long long)(KK + (K == 3 ? 3 : 0)) * (Co / 16) * CiP * 16; // wb_slabs(K)
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nf + nb;
-         i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = i0; i < nf + nb; i += stride) {
         if (i < nf) {
             if (wf == nullptr) continue;
             long long r = i;
@@ -108,6 +108,29 @@ __global__ void pack_weight_bf16_kernel(const float *__restrict__ w, int Or, int
             if (split) wb[nb + i - nf] = (__bf16)(v - (float)hi);
         }
     }
+}
+__global__ void pack_weight_bf16_kernel(const float *__restrict__ w, int Or, int Ir, int K, int Ci, int Co, int CoP,
+                                        int CiP, __bf16 *__restrict__ wf, __bf16 *__restrict__ wb, int split)
+{
+    pack_bf16_body(w, Or, Ir, K, Ci, Co, CoP, CiP, wf, wb, split, blockIdx.x * (long long)blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
+}
+// every regular (non-thin) layer of a network in ONE launch (acg_pack_conv_weights_multi): the packed copies are refreshed once
+// per optimiser step, and one launch per layer was 68 five-microsecond kernels per training step
+#define PACK_MAX_ITEMS 48
+struct PackTable {
+    acg_pack_item it[PACK_MAX_ITEMS];
+    int first[PACK_MAX_ITEMS + 1];   // first workgroup of item i
+    short cop[PACK_MAX_ITEMS], cip[PACK_MAX_ITEMS];   // acg_ncols_pad of the item's Co / Ci
+    int n, split;
+};
+__global__ __launch_bounds__(256) void pack_weight_bf16_multi_kernel(PackTable T)
+{
+    int k = 0;
+    while (k + 1 < T.n && (int)blockIdx.x >= T.first[k + 1]) ++k;   // (uniform)
+    const acg_pack_item q = T.it[k];
+    const int nblk = T.first[k + 1] - T.first[k];
+    pack_bf16_body(q.w, q.Or, q.Ir, q.K, q.Ci, q.Co, T.cop[k], T.cip[k], (__bf16 *)q.wf, (__bf16 *)q.wb, T.split,
+                   ((long long)blockIdx.x - T.first[k]) * 256 + threadIdx.x, (long long)nblk * 256);
 }
 
 // thin packing: rows are k = tap*4 + c (c < 4), grouped in 8-chunks: out[kc][col][8].
@@ -376,6 +399,37 @@ extern "C" int acg_pack_conv_weight(const float *w, int Or, int Ir, int K, int C
         hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Or, Ir, K, Ci, Co,
                            acg_ncols_pad(Co), acg_ncols_pad(Ci), wf, wb);
     ACG_CHECK_LAUNCH("pack_weight_kernel");
+    return ACG_OK;
+}
+
+// the same for the regular layers of a whole network at once (bf16 / bf16x3 arithmetic; thin layers keep acg_pack_conv_weight)
+extern "C" int acg_pack_conv_weights_multi_supported(int Or, int Ir, int K)
+{
+    const bool thin_i = thin_ok(Ir, K), thin_o = thin_ok(Or, K);
+    return use_bf16() && !((thin_i || thin_o) && !(thin_i && thin_o)) ? 1 : 0;
+}
+extern "C" int acg_pack_conv_weights_multi(const acg_pack_item *items, int n, void *stream)
+{
+    ACG_REQUIRE(items != nullptr && n >= 1 && use_bf16(), "acg_pack_conv_weights_multi: bf16 / bf16x3 arithmetic only (see acg_pack_conv_weights_multi_supported)");
+    for (int base = 0; base < n; base += PACK_MAX_ITEMS) {
+        PackTable T;
+        T.n = n - base < PACK_MAX_ITEMS ? n - base : PACK_MAX_ITEMS;
+        T.split = (int)(g_acg_precision == ACG_PREC_BF16X3);
+        T.first[0] = 0;
+        for (int i = 0; i < T.n; ++i) {
+            const acg_pack_item &q = items[base + i];
+            ACG_REQUIRE(q.w != nullptr && q.wf != nullptr && q.wb != nullptr && q.Ci % 16 == 0 && q.Co % 16 == 0 && q.Or <= q.Co && q.Ir <= q.Ci && q.K >= 1 && q.K <= 7 &&
+                        acg_pack_conv_weights_multi_supported(q.Or, q.Ir, q.K),
+                        "acg_pack_conv_weights_multi: item %d: bad dims or a thin layer (Or=%d Ir=%d K=%d Ci=%d Co=%d)", base + i, q.Or, q.Ir, q.K, q.Ci, q.Co);
+            T.it[i] = q;
+            T.cop[i] = (short)acg_ncols_pad(q.Co); T.cip[i] = (short)acg_ncols_pad(q.Ci);
+            const long long ne = (long long)acg_packed_wf_elems(q.K, q.Ci, q.Co) + (long long)acg_packed_wb_elems(q.K, q.Ci, q.Co);
+            const int nb = acg_cdiv(ne, 256 * 8) > 256 ? 256 : acg_cdiv(ne, 256 * 8);   // ~8 elements per thread
+            T.first[i + 1] = T.first[i] + (nb < 1 ? 1 : nb);
+        }
+        hipLaunchKernelGGL(pack_weight_bf16_multi_kernel, dim3(T.first[T.n]), dim3(256), 0, (hipStream_t)stream, T);
+        ACG_CHECK_LAUNCH("pack_weight_bf16_multi_kernel");
+    }
     return ACG_OK;
 }
 
@@ -974,7 +1028,8 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
     ACG_REQUIRE(!thin_out(d), "dgrad: stride 2 with <= 4 output channels is not supported by the thin packing");
     // stride 2: four sub-pixel phases, each a dense small-tap convolution (no zero insertion)
     ACG_REQUIRE(d->pad_mode == ACG_PAD_ZERO, "dgrad: stride 2 needs zero padding");
-    ACG_REQUIRE(addend == nullptr && relu_src == nullptr && relu_mask == nullptr && !in_s16 && !out_s16, "dgrad: stride 2 takes no fused side inputs");
+    ACG_REQUIRE(addend == nullptr && relu_src == nullptr && relu_mask == nullptr && !in_s16 && !out_s16 && ns == nullptr,
+                "dgrad: stride 2 takes no fused side inputs / norm sums (query acg_conv2d_bwd_data_sums_supported)");
     g.Hout = d->Hi; g.Wout = d->Wi; g.os = 2;
     auto phase_taps = [&](int py, int px, Taps &tt, int base) {
         int n = 0;
@@ -1017,17 +1072,10 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
         Geom g4 = g;
         g4.nphase = 0; g4.ph_ntaps = 0;
         Taps plan;
-        if (ns != nullptr) {   // the first backward pass of the norm in front of the stride-2 convolution rides on the four-phase tile
-            g4.ns_x = ns->x; g4.ns_mean = ns->mean; g4.ns_rstd = ns->rstd; g4.ns_gamma = ns->gamma; g4.ns_beta = ns->beta;
-            g4.ns_gstride = ns->gstride; g4.ns_mask = ns->sign_mask; g4.ns_act = ns->act; g4.ns_part = ns->part;
-            ACG_REQUIRE(ns->part != nullptr && stats == nullptr && acg_igemm_ph4_ok(g4) && acg_ph4_plan(t, ntp, &plan),
-                        "dgrad: norm sums on a stride-2 data gradient need the four-phase tile (query acg_conv2d_bwd_data_sums_supported)");
-            return acg_igemm_ph4_launch(src, wb, bias, dst, g4, plan, g.w_elems, st);
-        }
         if (acg_igemm_ph4_ok(g4) && acg_ph4_plan(t, ntp, &plan)) return acg_igemm_ph4_launch(src, wb, bias, dst, g4, plan, g.w_elems, st);
         return acg_igemm_launch(src, wb, bias, dst, g, t, st);
     }
-    ACG_REQUIRE(ns == nullptr, "dgrad: norm sums on a stride-2 data gradient need the four-phase tile (query acg_conv2d_bwd_data_sums_supported)");
+
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
             g.oy0 = py; g.ox0 = px;
@@ -1269,29 +1317,23 @@ extern "C" int acg_conv2d_bwd_data_s16_sums(const acg_conv_desc *d, const void *
 }
 
 // The same on fp32 operands, where the data gradient runs on the persistent row pipeline (conv_rows_x3: zero-padded 3x3 stride 1,
-// 32 output and 64 input channels of the convolution, width a multiple of 128), on the four-phase tile of the stride-2 3x3
-// layer (igemm_conv_ph4<SUMS>: 64 input channels, Wo a multiple of 128), on the generic tile (the 32 -> 64 layer's data gradient)
-// or on conv_thinrow_x3 (the head's): part[N][Hi*Wi/128][2][Ci], summed over the chunks by acg_norm_bwd_partials like the
+// 32 output and 64 input channels of the convolution, width a multiple of 128), on the generic tile (the 32 -> 64 layer's data
+// gradient) or on conv_thinrow_x3 (the head's): part[N][Hi*Wi/128][2][Ci], summed over the chunks by acg_norm_bwd_partials like the
 // pre-split kernel's (where a workgroup owns several chunks its sums sit in the first, zeros in the others)
 extern "C" int acg_conv2d_bwd_data_sums_supported(const acg_conv_desc *d)
 {
     if (d == nullptr || g_acg_precision != ACG_PREC_BF16X3 || g_acg_conv_impl != ACG_IMPL_MFMA || acg_debug_switch("ACG_NO_ROWS")) return 0;
     if (check_desc(d, "acg_conv2d_bwd_data_sums_supported") != ACG_OK) return 0;
-    // the four-phase tile of the stride-2 3x3 data gradient (igemm_conv_ph4<SUMS>): 64 input channels of the convolution, phase
-    // grid rows that are whole 128-pixel tiles
-    static const bool no_tile_sums = acg_debug_switch("ACG_NO_TILE_SUMS");   // A/B switch: the three producers of round 6
-    if (!no_tile_sums && d->K == 3 && d->stride == 2 && d->pad == 1 && d->pad_mode != ACG_PAD_REFLECT && d->Ci == 64 && d->Co % 32 == 0 &&
-        d->Hi == 2 * d->Ho && d->Wi == 2 * d->Wo && d->Wo % 128 == 0 && !acg_debug_switch("ACG_NO_PH4"))
-        return 1;
+    static const bool no_tile_sums = acg_debug_switch("ACG_NO_TILE_SUMS");   // A/B switch: the two producers of round 6
     // the 7x7 (K <= 7) stride-1 zero-padded layer with a C4 image on its output side (the head, networks.py:187-188):
     // conv_thinrow_x3's whole 8 x 16 tiles
     if (!no_tile_sums && d->stride == 1 && d->pad_mode != ACG_PAD_REFLECT && thin_out(d) && d->Co == 4 && d->Ci == 32 && d->K >= 2 && d->K <= 7 &&
         d->Hi == d->Ho && d->Wi == d->Wo && d->Hi % 8 == 0 && d->Wi % 16 == 0 && !thin_in_valu_dgrad(d) && !acg_debug_switch("ACG_NO_THINROW"))
         return 1;
     // the generic 128-pixel tile on the data gradient of the zero-padded 3x3 stride-1 32 -> 64 layer (networks.py:164: 64 gathered,
-    // 32 written channels — the mirror shape the row pipeline does not take): whole tiles inside one image
+    // 32 written channels — the mirror shape the row pipeline does not take): row-patch tiles, i.e. rows of whole 128-pixel tiles
     if (!no_tile_sums && d->K == 3 && d->stride == 1 && d->pad == 1 && d->pad_mode != ACG_PAD_REFLECT && d->Ci == 32 && d->Co == 64 &&
-        d->Hi == d->Ho && d->Wi == d->Wo && ((long long)d->Hi * d->Wi) % 128 == 0)
+        d->Hi == d->Ho && d->Wi == d->Wo && d->Wi % 128 == 0 && !acg_debug_switch("ACG_NO_RP"))
         return 1;
     return d->K == 3 && d->stride == 1 && d->pad == 1 && d->pad_mode != ACG_PAD_REFLECT && d->Co == 32 && d->Ci == 64 && d->Hi == d->Ho &&
            d->Wi == d->Wo && d->Wi % 128 == 0 ? 1 : 0;

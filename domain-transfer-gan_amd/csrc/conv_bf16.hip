@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
     __shared__ __attribute__((aligned(16))) __bf16 As[NIMG * A_IMG];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[NTX * NIMG * B_IMG];
     __shared__ __attribute__((aligned(16))) unsigned out_rel[BM];  // byte offset of a tile row's output pixel from the tile's first, ~0u: no such pixel
-    __shared__ float sred[2 * WM * BN];   // cross-wave fold of the per-tile statistics (Geom.stats) / norm-backward sums (Geom.ns_part)
+    __shared__ float sred[(RP && SPLIT && BM / WM == 32 && BN / WN == 32 ? 2 : 1) * WM * BN];   // cross-wave fold of the per-tile statistics (Geom.stats) / norm-backward sums (Geom.ns_part)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -208,6 +208,23 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
             }
     };
 
+    // Norm-backward sums (Geom.ns_part, below): only the one-column-block row-patch instance carries the code (the data gradient of
+    // the 3x3 32 -> 64 layer); the norm input x at the tile's output positions is requested during the LAST stage's MFMAs
+    constexpr bool NS = RP && SPLIT && MB == 1 && NB == 1;
+    float ns_xv[NS ? 16 : 1];
+    auto ns_load = [&]() {
+        if constexpr (NS) {
+            const __amdgpu_buffer_rsrc_t rnx = __builtin_amdgcn_make_buffer_rsrc((void *)(g.ns_x + off0), 0, 0xFFFFFFF0u, 0x00020000);
+            const int co = n0 + wn * TN + (lane & 31);
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const u32x4 rel = *(const u32x4 *)&out_rel[wm * TM + 8 * r4 + 4 * (lane >> 5)];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    ns_xv[4 * r4 + q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rnx, acg_masked_off(rel[q] + (unsigned)co * 4u, co < g.Cout && rel[q] != ~0u), 0, 0));
+            }
+        }
+    };
     load_stage(0);
     for (int s = 0; s < S; ++s) {
         int gfirst = 0, gnt = 1, gtx0 = 0;   // this stage's tap group (row patch)
@@ -242,6 +259,7 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
             }
         __syncthreads();
         if (s + 1 < S) load_stage(s + 1);
+        else if (NS && g.ns_part != nullptr) ns_load();
         // (a run-time trip count on purpose: with `if (q < gnt)` bodies the accumulators are merged through VGPRs and every
         // tap pays 2 x 32 v_accvgpr moves)
 #pragma unroll 1
@@ -321,17 +339,14 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
             __syncthreads();
         }
     }
-    if (g.ns_part != nullptr) {
-        // Norm-backward sums (acg_conv2d_bwd_data_sums, round 6): this launch is a data gradient whose output is the gradient w.r.t.
-        // the OUTPUT of a norm (+ ReLU) with input ns_x — the first pass of that norm's backward, sum gy and sum gy * xhat per
-        // channel over the tile's 128 pixels (gy = dx * act'(y), the mask recomputed from x like norm_bwd_partial<.., 1>), leaves
-        // from here: x is read at the positions the tile stores.  Whole tiles inside one image, no bias / activation (launcher).
-        const __amdgpu_buffer_rsrc_t rnx = __builtin_amdgcn_make_buffer_rsrc((void *)(g.ns_x + off0), 0, 0xFFFFFFF0u, 0x00020000);
-        const int img = (int)(m0 / GHW);
-        const bool ns_relu = g.ns_act == ACG_ACT_RELU;
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int co = n0 + wn * TN + j * 32 + (lane & 31);
+    if constexpr (NS) {
+        if (g.ns_part != nullptr) {
+            // Norm-backward sums (acg_conv2d_bwd_data_sums, round 6): this launch is a data gradient whose output is the gradient
+            // w.r.t. the OUTPUT of a norm (+ ReLU) with input ns_x — the first pass of that norm's backward, sum gy and sum gy * xhat
+            // per channel over the tile's 128 pixels (gy = dx * act'(y), the mask recomputed from x like norm_bwd_partial<.., 1>),
+            // leaves from here.  Whole tiles inside one image, no bias / activation (launcher).
+            const bool ns_relu = g.ns_act == ACG_ACT_RELU;
+            const int co = n0 + wn * TN + (lane & 31);
             const bool cok = co < g.Cout;
             float mu = 0.f, rs = 0.f, ga = 1.f, be = 1.f;
             if (cok) {
@@ -341,40 +356,28 @@ __global__ __launch_bounds__(256) void igemm_conv_bf16(const float *__restrict__
             }
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int i = 0; i < MB; ++i) {
-                float xv[16];
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const u32x4 rel = *(const u32x4 *)&out_rel[wm * TM + i * 32 + 8 * r4 + 4 * (lane >> 5)];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        xv[4 * r4 + q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rnx, acg_masked_off(rel[q] + (unsigned)co * 4u, cok && rel[q] != ~0u), 0, 0));
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float xh = (xv[r] - mu) * rs;
-                    const float gy = (ns_relu && !(xh * ga + be > 0.f)) ? 0.f : acc[i][j][r];   // same expression as norm_apply_kernel
-                    s1 += gy;
-                    s2 += gy * xh;
-                }
+            for (int r = 0; r < 16; ++r) {
+                const float xh = (ns_xv[r] - mu) * rs;
+                const float gy = (ns_relu && !(xh * ga + be > 0.f)) ? 0.f : acc[0][0][r];   // same expression as norm_apply_kernel
+                s1 += gy;
+                s2 += gy * xh;
             }
             s1 += __shfl_xor(s1, 32);
             s2 += __shfl_xor(s2, 32);
             if (lane < 32) {
-                sred[wm * BN + wn * TN + j * 32 + lane] = s1;
-                sred[WM * BN + wm * BN + wn * TN + j * 32 + lane] = s2;
+                sred[wm * BN + wn * TN + lane] = s1;
+                sred[WM * BN + wm * BN + wn * TN + lane] = s2;
+            }
+            __syncthreads();
+            if (tid < BN && n0 + tid < g.Cout) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) { a += sred[w * BN + tid]; b += sred[WM * BN + w * BN + tid]; }
+                float *o = g.ns_part + ((m0 / BM) * 2) * g.Cout + n0 + tid;   // part[N][GHW / BM][2][Cout], tile-major like m0
+                o[0] = a;
+                o[g.Cout] = b;
             }
         }
-        __syncthreads();
-        if (tid < BN && n0 + tid < g.Cout) {
-            float a = 0.f, b = 0.f;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) { a += sred[w * BN + tid]; b += sred[WM * BN + w * BN + tid]; }
-            float *o = g.ns_part + ((m0 / BM) * 2) * g.Cout + n0 + tid;   // part[N][GHW / BM][2][Cout], tile-major like m0
-            o[0] = a;
-            o[g.Cout] = b;
-        }
-        __syncthreads();
     }
     // Stores: 32 lanes x 4 B = one 128-byte line of an output pixel per half wave.  Branch-free: bias and activation in a
     // pass over the accumulators, then buffer stores relative to the tile's first pixel whose masked lanes (no such row /
@@ -508,7 +511,8 @@ int acg_igemm_bf16_launch(const float *in, const void *wp, const float *bias, fl
     const bool ns_tile = split && !acg_igemm_uses_ws(g0) && g0.nphase == 0 && g0.stats == nullptr && bias == nullptr && g0.act == ACG_ACT_NONE &&
                          g0.os == 1 && ((long long)g0.GH * g0.GW) % 128 == 0 && g0.ns_x != nullptr && g0.ns_mean != nullptr && g0.ns_rstd != nullptr &&
                          g0.ns_mask == nullptr && (g0.ns_act == ACG_ACT_NONE || (g0.ns_act == ACG_ACT_RELU && g0.ns_gamma != nullptr && g0.ns_beta != nullptr)) &&
-                         (g0.ns_gstride == 0 || g0.ns_gstride >= g0.Cout) && !acg_conv_patchn_ok(g0, t) && !acg_conv_patch16_ok(g0, t);
+                         (g0.ns_gstride == 0 || g0.ns_gstride >= g0.Cout) && !acg_conv_patchn_ok(g0, t) && !acg_conv_patch16_ok(g0, t) &&
+                         bn == 32 && g0.Cin % 32 == 0 && !g0.reflect && !acg_debug_switch("ACG_NO_RP") && [&]() { Taps tq = t; return rp_groups(g, tq); }();
     ACG_REQUIRE(g0.ns_part == nullptr || (split && !acg_igemm_uses_ws(g0) && (acg_conv_rows_ok(g0, t) || ns_tile)),
                 "igemm_conv_bf16: norm-backward sums requested on a geometry neither the row pipeline nor the generic tile takes");
     if (acg_igemm_uses_ws(g0)) {

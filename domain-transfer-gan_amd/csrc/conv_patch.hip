@@ -420,6 +420,16 @@ __global__ __launch_bounds__(256) void conv_thinrow_x3(const float *__restrict__
     }
     __syncthreads();
 
+    // norm-backward sums (the epilogue below): the norm input x at the four pixels this thread stores, requested now — in flight
+    // under the kernel rows (whole tiles: the launcher checks)
+    f32x4 nsx[PT_TH * PT_TW * 8 / 256];
+    if (g.ns_part != nullptr) {   // (uniform)
+#pragma unroll
+        for (int k = 0; k < PT_TH * PT_TW * 8 / 256; ++k) {
+            const int idx = tid + 256 * k, pix = idx >> 3, c4 = idx & 7;
+            nsx[k] = *(const f32x4 *)(g.ns_x + (((long long)n * g.Hout + gy0 + pix / PT_TW) * g.Wout + gx0 + pix % PT_TW) * g.Cout + c4 * 4);
+        }
+    }
     // ---- kernel rows: wave w owns tile rows 2w, 2w+1; lane l: pixel l & 15 of the row, window columns 2 (l >> 4), + 1
     f32x4 acc[2][2];
 #pragma unroll
@@ -490,7 +500,7 @@ __global__ __launch_bounds__(256) void conv_thinrow_x3(const float *__restrict__
             const f32x4 v = *(const f32x4 *)&tile[pix * 32 + c4 * 4];
             *(f32x4 *)(out + o) = v;
             if (nsum) {
-                const f32x4 xh = (*(const f32x4 *)(g.ns_x + o) - nmu) * nrs;
+                const f32x4 xh = (nsx[k] - nmu) * nrs;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float gyv = (ns_relu && !(xh[q] * nga[q] + nbe[q] > 0.f)) ? 0.f : v[q];   // same expression as norm_apply_kernel

@@ -22,7 +22,7 @@ import torch
 
 from . import dist as acg_dist
 from . import networks, ops
-from .modules import as_latent, mark_dirty
+from .modules import as_latent, mark_dirty, repack
 from .ops import cpad
 
 
@@ -150,8 +150,8 @@ class FusedAdam(object):
         self.t += 1
         ops.clip_adam_multi([(f.p, f.gv, f.m, f.v, f.sumsq) for f in self.flats], max_norm, g['lr'], g['betas'][0],
                             g['betas'][1], g['eps'], self.t, self.t_dev if self.dev_step else None)
-        for f in self.flats:
-            mark_dirty(f.net)
+        for f in self.flats:   # the packed copies follow the parameters: one launch per network (modules.repack)
+            repack(f.net)
         return [f.sumsq for f in self.flats]
 
     def state_dict(self):

@@ -42,6 +42,23 @@ def mark_dirty(net):
             m._acg_cache = None
 
 
+def repack(net):
+    """after the fused Adam kernel changed `net`'s parameters: refresh the packed weights of its convolution layers in place, all
+    regular layers in ONE launch (ops.repack_many; one launch per layer was 68 small kernels per training step), and drop
+    every other cached derived form (padded norm vectors).  A layer that has not run yet has nothing to refresh."""
+    entries = []
+    for m in net.modules():
+        c = getattr(m, "_acg_cache", None)
+        if c is None:
+            continue
+        if isinstance(m, (Conv2d, ConvTranspose2d)) and isinstance(c[1], ops.PackedConv) and c[0] == m._cache_key():
+            entries.append((c[1], m.weight, m.bias))
+        else:
+            m._acg_cache = None
+    if entries:
+        ops.repack_many(entries)
+
+
 class _Cached(object):
     """Mixin: per-layer cache of device-side derived forms, keyed on the parameters' versions."""
     _acg_cache = None

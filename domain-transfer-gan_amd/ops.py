@@ -203,6 +203,10 @@ class PackedConv(object):
         _check(w)
         _lib.call("acg_pack_conv_weight", _ptr(w), self.Or, self.Ir, self.K, self.Ci, self.Co, _ptr(self.wf), _ptr(self.wb),
                   _stream())
+        self.refresh_bias(bias)
+
+    def refresh_bias(self, bias):
+        w = self.wf
         if bias is not None:
             n = bias.numel()
             npad = cpad(n)
@@ -212,6 +216,32 @@ class PackedConv(object):
                 if self.bias is None or self.bias.data_ptr() == bias.data_ptr():
                     self.bias = torch.empty(npad, device=w.device, dtype=torch.float32)
                 _lib.call("acg_pad_vector", _ptr(bias.detach()), n, _ptr(self.bias), npad, _stream())
+
+
+def repack_many(entries):
+    """entries: [(PackedConv, weight, bias)] whose parameters the optimiser just changed: refresh the packed copies IN PLACE —
+    the regular layers of the list in one launch (acg_pack_conv_weights_multi), thin layers and the exact-fp32 mode layer by
+    layer.  (In place: nothing of a step reads a network's old weights after its Adam update.)"""
+    multi = []
+    for pk, w, b in entries:
+        if _lib.query("acg_pack_conv_weights_multi_supported", pk.Or, pk.Ir, pk.K):
+            multi.append((pk, w, b))
+        else:
+            pk.refresh(w, b)
+    if not multi:
+        return
+    arr = (_lib.PackItem * len(multi))()
+    keep = []
+    for i, (pk, w, b) in enumerate(multi):
+        wd = w.detach().contiguous()
+        _check(wd)
+        keep.append(wd)
+        arr[i].w, arr[i].wf, arr[i].wb = wd.data_ptr(), pk.wf.data_ptr(), pk.wb.data_ptr()
+        arr[i].Or, arr[i].Ir, arr[i].K, arr[i].Ci, arr[i].Co = pk.Or, pk.Ir, pk.K, pk.Ci, pk.Co
+    _lib.call("acg_pack_conv_weights_multi", arr, len(multi), _stream())
+    _fused("packed_weights_multi", len(multi))
+    for pk, w, b in multi:
+        pk.refresh_bias(b)
 
 
 class ConvTimer(object):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ACG_VERSION 116
+#define ACG_VERSION 117
 
 typedef enum {
     ACG_OK = 0,
@@ -107,6 +107,17 @@ int acg_ncols_pad(int c);
 size_t acg_packed_wf_elems(int K, int Ci, int Co);
 size_t acg_packed_wb_elems(int K, int Ci, int Co);
 int acg_pack_conv_weight(const float *w_oihw, int Or, int Ir, int K, int Ci, int Co, float *wf, float *wb, void *stream);
+/* The regular (non-thin) layers of a whole network in ONE launch — the packed copies are refreshed once per optimiser step
+ * (model.py:447-452, 510-515 `optimizer.step()` changes every weight), and one launch per layer was 68 five-microsecond
+ * kernels per training step.  bf16 / bf16x3 arithmetic; a layer qualifies where acg_pack_conv_weights_multi_supported
+ * (thin layers and the exact-fp32 mode keep acg_pack_conv_weight).  Same bytes as acg_pack_conv_weight writes. */
+typedef struct {
+    const float *w;      /* OIHW, real Or x Ir */
+    float *wf, *wb;      /* acg_packed_w{f,b}_elems floats each */
+    int Or, Ir, K, Ci, Co;
+} acg_pack_item;
+int acg_pack_conv_weights_multi_supported(int Or, int Ir, int K);
+int acg_pack_conv_weights_multi(const acg_pack_item *items, int n, void *stream);
 int acg_pad_vector(const float *src, int n, float *dst, int np, void *stream); /* bias -> C16 */
 
 /* ---- nn.Conv2d forward (+bias, + fused activation) — networks.py:159-188, 211-243, 321-338,
@@ -174,9 +185,8 @@ int acg_conv2d_bwd_data_s16_sums_supported(const acg_conv_desc *d);
 int acg_conv2d_bwd_data_s16_sums(const acg_conv_desc *d, const void *dy_s16, const float *wb, float *dx, void *ws,
                                  size_t ws_bytes, const float *addend, const unsigned *addend_sign_mask,
                                  const acg_norm_sums *ns, void *stream);
-/* ... and on fp32 operands (round 6: every norm of a generator whose consumer is a convolution): the persistent row pipeline
- * (zero-padded 3x3 stride 1, Co == 32, Ci == 64, Wi % 128 == 0), the four-phase tile of the stride-2 3x3 layer (Ci == 64,
- * Wo % 128 == 0), the generic tile (3x3 stride 1, Ci == 32, Co == 64, Hi * Wi % 128 == 0) and the thin-row kernel of the 7x7
+/* ... and on fp32 operands: the persistent row pipeline (zero-padded 3x3 stride 1, Co == 32, Ci == 64, Wi % 128 == 0), and
+ * from round 6 the generic row-patch tile (3x3 stride 1, Ci == 32, Co == 64, Wi % 128 == 0) and the thin-row kernel of the 7x7
  * head (Ci == 32, a C4 image on the output side, Hi % 8 == 0, Wi % 16 == 0).  ns->sign_mask must be NULL (the activation
  * mask is recomputed from ns->x); part[N][Hi * Wi / 128][2][Ci], every entry written. */
 int acg_conv2d_bwd_data_sums_supported(const acg_conv_desc *d);
