@@ -169,9 +169,27 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
         const int tap_v = taps.pk[lane < taps.n ? lane : 0];
         auto tap_pk = [&](int t) { return __builtin_amdgcn_readlane(tap_v, t); };
         int bt = 0, bc0 = 0; // tap and first input channel of the next B stage
+        // Timing-only gates (wrong results; tools/build_variant.sh <name> -DWS_ABL_...; DESIGN_LOG.md R6.3): what would a tile cost
+        // that streamed half / none of its weight pieces (two accumulator sets sharing one weight stage), or half / none of its
+        // gathered pixels (a de-interleaved stride-2 row patch)?  Skipped loads are not issued (weights) or masked off (gathers).
+#if defined(WS_ABL_HALFW)
+        const bool ws_skip_w = (tile_m & 1) != 0;
+#elif defined(WS_ABL_NOW)
+        const bool ws_skip_w = true;
+#else
+        const bool ws_skip_w = false;
+#endif
+#if defined(WS_ABL_HALFA)
+        const bool ws_skip_a = (tile_m & 1) != 0;
+#elif defined(WS_ABL_NOA)
+        const bool ws_skip_a = true;
+#else
+        const bool ws_skip_a = false;
+#endif
         auto dma_b = [&](int buf) { // 2 * BL pieces per thread: hi and lo image of stage (bt, bc0) into B buffer `buf`
             char *Bb = (char *)(lds + L::b_off(buf));
             const unsigned soff = (unsigned)((((tap_pk(bt) >> 16) * (g.Cin >> 4) + (bc0 >> 4)) * g.ncols_pad) * 16) * 2u;
+            if (!ws_skip_w)
 #pragma unroll
             for (int i = 0; i < BL; ++i) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(Bb + b_lds[i]), 16, b_voff[i], soff, 0, 0);
@@ -189,6 +207,7 @@ igemm_conv_x3_ws(const float *__restrict__ in, const __bf16 *__restrict__ wp,
             *(acg_u32x4 *)&As[AIMG + a_at] = lo;
         };
         auto load_a = [&](int j, unsigned off, bool ok) {
+            ok = ok && !ws_skip_a;
             const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off, ok), 0, 0);
             const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rin, acg_masked_off(off + 16u, ok), 0, 0);
             const f32x4 flo = __builtin_bit_cast(f32x4, lo), fhi = __builtin_bit_cast(f32x4, hi);
