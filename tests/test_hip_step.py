@@ -56,12 +56,15 @@ def test_train_instance_matches_reference_golden(name, prec):
 # fixture flavour.  'init' = the reference's own initialisation statistics (what training starts from): the north-star
 # 1e-3 bar holds in bf16x3.  'rich' = O(1) InstanceNorm gains everywhere, deliberately ill-conditioned
 # (tools/conditioning_probe.py: the EXACT-fp32 path itself moves rec_* by 4e-4..9e-4 under a 4e-6 input perturbation):
-# bf16x3 lands at 0.8-1.4e-3 there, allowed 3e-3.  After an Adam update the fp32 oracle itself is 1.9e-2 from the
+# bf16x3 lands at 1.8-7.9e-4 on the reference goldens (0.8-1.4e-3 in the 6-block oracle case, allowed 3e-3 there).  After an Adam update the fp32 oracle itself is 1.9e-2 from the
 # reference on 'rich' (tests/test_oracle_golden.py).
 # (after the first Adam update the exact-fp32 HIP path sits 8e-3 and bf16x3 2.5e-2 from the reference on the 'init' stoch_enc fixture: Adam turns
 # summation-order noise on ~zero gradients into +-lr moves, and rec_* passes them through two generators)
+# Round 6: the measured step-0 errors are recorded every run (ACG_REC_ERR_LOG; profiles/r06_rec_errors.txt) — 'rich' in bf16x3
+# lands at 1.8e-4 .. 7.9e-4, so the reference goldens are all held to the north-star 1e-3 at step 0 now (the 3e-3 allowance
+# of rounds 2-5 remains only in the build's own 6-block oracle case below, which measures 0.8 / 1.4e-3).
 REC_TOL = {("f32", "init"): (2e-4, 2e-2), ("f32", "rich"): (3e-4, 4e-2),
-           ("bf16x3", "init"): (1e-3, 4e-2), ("bf16x3", "rich"): (3e-3, 6e-2)}
+           ("bf16x3", "init"): (1e-3, 4e-2), ("bf16x3", "rich"): (1e-3, 6e-2)}
 
 
 # What the fixtures hold beyond losses and images (tools/make_goldens.py:292-304, taken from the reference after
