@@ -135,7 +135,9 @@ def test_norm_backward_sums_from_the_data_gradient_epilogue(kind):
         # sums over 16 k pixels, allowed for against the weight gradient of the same layer)
         noise = 0.0
         if k.endswith(".bias") and k.replace(".bias", ".weight") in pb:
-            noise = 5e-4 * pb[k.replace(".bias", ".weight")].abs().max().item()
+            # (measured up to 5.1e-4 of the layer's largest weight gradient: 1.22e-3 absolute on model.10.conv_block.4.bias,
+            # a sum over 16 k pixels whose exact value is 0 — round 6, three more norms take their sums from a data gradient)
+            noise = 7e-4 * pb[k.replace(".bias", ".weight")].abs().max().item()
         # (the scale / shift layers of a CondInstanceNorm sum ReLU-gated per-sample terms over a whole plane: the two runs'
         # differently ordered sums reach them with 2e-5 .. 3e-5; measured 2.0003e-5 on model.2.shift_conv)
         tol = 4e-5 if ("shift_conv" in k or "scale_conv" in k) else 2e-5
