@@ -55,6 +55,11 @@ def parse_args(argv=None):
     ap.add_argument("--blocks", type=int, default=None)
     ap.add_argument("--nc", type=int, default=None, help="image channels of both domains")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-step-graph", action="store_true",
+                    help="enqueue every step kernel by kernel.  Default on ONE GPU: the step is replayed as one captured HIP graph "
+                         "(model.enable_step_graph, train.py --step_graph: the same launches without ~1 400 launch boundaries, "
+                         "138.8-139.1 against 140.9-141.7 ms), except on the sampled steps that carry the HIP-event brackets of "
+                         "the roofline block, which run eagerly.  With several ranks the data-parallel exchange keeps the eager path.")
     ap.add_argument("--timer-every", type=int, default=5, metavar="N",
                     help="bracket the roofline kernels with HIP events on every N-th timed step only (0: never; the events are "
                          "barrier packets between back-to-back launches and cost the step time)")
@@ -237,14 +242,25 @@ def main():
     ops.set_precision(a.precision)
     torch.manual_seed(0)  # identical replicas by construction (and broadcast from rank 0 anyway)
     model = M.AugmentedCycleGAN(make_opt(a, local_rank), testing=True)
+    use_graph = ws == 1 and not a.no_step_graph
+    if use_graph:
+        model.enable_step_graph()
+    graph_obj = model._step_graph
 
     g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
     N, S, nc = a.batch, a.size, a.nc
     real_A = torch.rand((N, nc, S, S), device=dev, generator=g) * 2 - 1
     real_B = torch.rand((N, nc, S, S), device=dev, generator=g) * 2 - 1
 
-    def step():
+    def step(eager=False):
+        nonlocal_graph = graph_obj
         z = torch.randn((N, 16, 1, 1), device=dev, generator=g)       # train.py:193: fresh prior every step
+        if eager and nonlocal_graph is not None:     # a sampled step: the same train_instance, enqueued kernel by kernel
+            model._step_graph = None
+            try:
+                return model.train_instance(real_A, real_B, z)
+            finally:
+                model._step_graph = nonlocal_graph
         return model.train_instance(real_A, real_B, z)
 
     def barrier():
@@ -254,6 +270,20 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    # the graph is captured on its third call (two eager calls settle the lazily built state): never inside the timed region
+    try:
+        while graph_obj is not None and graph_obj.graph is None:
+            step()
+        if graph_obj is not None:
+            # torch.cuda.graph() empties the caching allocator before it captures: the first eagerly enqueued step behind the
+            # capture allocates its ~50 GB of activations afresh (measured: 1.1 s instead of 0.14 s, in 2 of 18 runs inside the
+            # timed region) — it happens here, untimed, and one replay behind it
+            step(eager=True)
+            step()
+    except Exception as e:   # a capture that fails leaves no graph behind (model.StepGraph): the run goes on eagerly, and says so
+        print("bench.py: step-graph capture failed (%s: %s); continuing with eager launches" % (type(e).__name__, e), file=sys.stderr)
+        model.enable_step_graph(False)
+        graph_obj = None
     # dominant kernel: resblock 3x3 reflect conv 128->128 at S/2; HBM-bound companion: the stride-2 64->128 downsample
     # (networks.py:168, 220) at full resolution — forward launches only, HIP events on the launch stream
     is_res = lambda d: d.K == 3 and d.Ci == 128 and d.Co == 128 and d.stride == 1 and d.pad_mode == 1
@@ -264,12 +294,22 @@ def main():
     ops.FUSED.clear()
     barrier()
     t0 = time.time()
+    eager_steps = 0
+    step_marks = [] if os.environ.get("ACG_BENCH_STEP_TIMES") else None   # diagnostic: one event behind every timed step
     for i in range(a.steps):
-        ops.CONV_TIMERS[:] = timers if (a.timer_every > 0 and i % a.timer_every == 0) else []
-        losses, _, _ = step()
+        sampled = a.timer_every > 0 and i % a.timer_every == 0
+        ops.CONV_TIMERS[:] = timers if sampled else []
+        eager_steps += 1 if (sampled or graph_obj is None) else 0
+        losses, _, _ = step(eager=sampled)
+        if step_marks is not None:
+            ev = torch.cuda.Event(enable_timing=True); ev.record(); step_marks.append((ev, time.time()))
     barrier()
     dt = time.time() - t0
     ops.CONV_TIMERS[:] = []
+    if step_marks:
+        print("per-step: GPU ms between step ends %s | host s at step ends %s" % (
+            " ".join("%.1f" % step_marks[k][0].elapsed_time(step_marks[k + 1][0]) for k in range(len(step_marks) - 1)),
+            " ".join("%.3f" % (tm - t0) for _, tm in step_marks)), file=sys.stderr)
     # what the matrix pipe holds on THIS device in its present clock / power state: the library's register-only MFMA loop
     # (acg_probe_mfma_rate), timed here, right BEHIND the timed region — printed beside the spec peak, never instead of it.
     # (In front of the timed region its 150 ms at full matrix power cost the step 3 %: 145.8 against 141.6 ms, every trunk
@@ -289,7 +329,8 @@ def main():
             torch.cuda.synchronize()
             best = max(best, fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
         sustained = best
-    fused_paths = {k: round(v / float(a.steps), 2) for k, v in sorted(ops.FUSED.items())}
+    # (ops.FUSED counts in Python: a graph replay does not pass there — the counts are those of the eagerly enqueued steps)
+    fused_paths = {k: round(v / float(max(eager_steps, 1)), 2) for k, v in sorted(ops.FUSED.items())}
     if ws > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -376,6 +417,8 @@ def main():
                                "Augmented CycleGAN train_instance), batch=%d per GPU (global %d)"
                                % (a.config_name, S, S, nc, a.blocks, N, N * ws),
                    "parallelism": "dp%d" % ws, "batchnorm": "sync" if a.sync_bn else "per-rank",
+                   "launch": ("one captured HIP graph per step (model.enable_step_graph); %d of the %d timed steps — the ones carrying the "
+                              "HIP-event brackets — enqueued kernel by kernel" % (eager_steps, a.steps)) if graph_obj is not None else "eager",
                    # what torch.distributed itself reports (a SCALE record shows RCCL saw N ranks)
                    "backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else "none (single process)"),
                    "world_size_seen": (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1),

@@ -8,6 +8,6 @@ R=$GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
   d=$R/gpurun_out/pmc_$(echo $c | tr A-Z a-z | sed 's/_size//')
   rm -rf $d
-  timeout -k 10 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/pmc_$c.log 2>&1
+  timeout -k 10 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-step-graph > $R/gpurun_out/pmc_$c.log 2>&1
   echo "$c done: $(ls $d/*/ | tr '\n' ' ')"
 done
