@@ -22,7 +22,7 @@ import torch
 
 from . import dist as acg_dist
 from . import networks, ops
-from .modules import as_latent, mark_dirty, repack
+from .modules import as_latent, mark_dirty, packed_of, repack
 from .ops import cpad
 
 
@@ -200,7 +200,7 @@ class StepGraph(object):
     WARMUP = 2
 
     def __init__(self, model):
-        self.model, self.graph, self.key, self.calls, self.ws = model, None, None, 0, None
+        self.model, self.graph, self.key, self.calls, self.ws, self.packed = model, None, None, 0, None, None
 
     def _key(self, a, b, z):
         m = self.model
@@ -219,11 +219,13 @@ class StepGraph(object):
             if opt.t_dev is None:
                 opt.t_dev = torch.zeros(1, dtype=torch.int32, device=real_A.device)
         graph = torch.cuda.CUDAGraph()
-        # every derived tensor the step uses (packed weights, padded vectors) must be rebuilt INSIDE the graph: a cache
-        # that is still valid here — the discriminators', packed in the previous step's G phase — would be baked in as a
-        # pointer to eager memory and as the weights of one particular step
+        # every derived tensor the step uses must be current at every replay.  The packed convolution weights are: each
+        # optimiser step refreshes them IN PLACE (modules.repack) — eagerly and inside the graph alike — so the objects the
+        # layers hold now are baked in as they are (round 6: rebuilding them inside the graph cost every replay 68 pack
+        # launches), kept alive by this object and checked before every replay.  The other derived forms (padded norm
+        # vectors) are copies a kernel made once: those are rebuilt INSIDE the graph.
         for net in m._nets():
-            mark_dirty(net)
+            mark_dirty(net, keep_packed=True)
         # ... and so must the scratch buffers: the captured kernels keep the workspace POINTERS, and ops.workspace() replaces
         # an eager buffer as soon as a later eager op (a larger evaluation batch) needs more.  The capture therefore starts
         # from an empty workspace table, so its buffers come from the graph's private pool, and this object keeps them alive;
@@ -245,6 +247,7 @@ class StepGraph(object):
                 opt.dev_step = False
         # only a capture that completed is kept: a failed one leaves no half-built graph behind for the next call to replay
         self.graph, self.key, self.inputs, self.pending, self.ws = graph, key, inputs, pending, graph_ws
+        self.packed = [packed_of(net) for net in m._nets()]     # (strong references: the graph holds their device pointers)
 
     def __call__(self, real_A, real_B, prior_z_B):
         m = self.model
@@ -254,6 +257,12 @@ class StepGraph(object):
             with _in_train_step():
                 return m._train_instance(real_A, real_B, prior_z_B)
         opts = list(m._optimizers().values())
+        if self.graph is not None and key == self.key:
+            # the layers must still hold the packed weights the graph was captured with (a checkpoint load, a precision switch or
+            # mark_dirty() in between replaces them): otherwise capture again
+            now = [packed_of(net) for net in m._nets()]
+            if any(a is not b for pa, pb in zip(now, self.packed) for a, b in zip(pa, pb)):
+                self.graph = None
         if self.graph is None or key != self.key:
             self.graph = self.key = None
             self._capture(key, real_A, real_B, prior_z_B)
@@ -264,8 +273,8 @@ class StepGraph(object):
         self.graph.replay()
         for opt in opts:
             opt.t += 1
-        for net in m._nets():                         # the replay repacked and then updated the weights behind Python's caches
-            mark_dirty(net)
+        for net in m._nets():    # the replay updated the weights behind Python's caches (and repacked the convolutions' in place)
+            mark_dirty(net, keep_packed=True)
         return self.pending.resolve()
 
 

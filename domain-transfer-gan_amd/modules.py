@@ -34,12 +34,27 @@ def sync_bn_active():
     return SYNC_BN and IN_TRAIN_STEP and ops_dist_on()
 
 
-def mark_dirty(net):
+def mark_dirty(net, keep_packed=False):
     """Parameters of `net` changed outside torch's version counter (fused Adam kernel):
-    drop the cached packed weights / padded vectors of all its layers."""
+    drop the cached packed weights / padded vectors of all its layers.  keep_packed: the packed convolution weights are
+    known to be current (`repack` refreshed them in place behind the optimiser step) and stay; only the other derived forms go."""
     for m in net.modules():
         if hasattr(m, "_acg_cache"):
+            c = m._acg_cache
+            if keep_packed and c is not None and isinstance(c[1], ops.PackedConv) and c[0] == m._cache_key():
+                continue
             m._acg_cache = None
+
+
+def packed_of(net):
+    """the PackedConv objects the convolution layers of `net` currently hold (None where a layer has none): what a captured
+    graph bakes in as pointers"""
+    out = []
+    for m in net.modules():
+        if isinstance(m, (Conv2d, ConvTranspose2d)):
+            c = getattr(m, "_acg_cache", None)
+            out.append(c[1] if (c is not None and isinstance(c[1], ops.PackedConv) and c[0] == m._cache_key()) else None)
+    return out
 
 
 def repack(net):
