@@ -60,6 +60,9 @@ def parse_args(argv=None):
                          "(model.enable_step_graph, train.py --step_graph: the same launches without ~1 400 launch boundaries, "
                          "138.8-139.1 against 140.9-141.7 ms), except on the sampled steps that carry the HIP-event brackets of "
                          "the roofline block, which run eagerly.  With several ranks the data-parallel exchange keeps the eager path.")
+    ap.add_argument("--sync-scalars", action="store_true",
+                    help="wait for every replayed step's losses on the host (the reference's loop does, train.py:198-243) instead of "
+                         "reading them one step late")
     ap.add_argument("--timer-every", type=int, default=5, metavar="N",
                     help="bracket the roofline kernels with HIP events on every N-th timed step only (0: never; the events are "
                          "barrier packets between back-to-back launches and cost the step time)")
@@ -244,7 +247,9 @@ def main():
     model = M.AugmentedCycleGAN(make_opt(a, local_rank), testing=True)
     use_graph = ws == 1 and not a.no_step_graph
     if use_graph:
-        model.enable_step_graph()
+        # (defer_scalars: a replayed step hands back a DeferredStep instead of waiting for its 23 scalars; the host enqueues the
+        # next replay meanwhile and the line's loss is read from the last step behind the timed region)
+        model.enable_step_graph(defer_scalars=not a.sync_scalars)
     graph_obj = model._step_graph
 
     g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
@@ -300,11 +305,12 @@ def main():
         sampled = a.timer_every > 0 and i % a.timer_every == 0
         ops.CONV_TIMERS[:] = timers if sampled else []
         eager_steps += 1 if (sampled or graph_obj is None) else 0
-        losses, _, _ = step(eager=sampled)
+        last = step(eager=sampled)
         if step_marks is not None:
             ev = torch.cuda.Event(enable_timing=True); ev.record(); step_marks.append((ev, time.time()))
     barrier()
     dt = time.time() - t0
+    losses = (last.result() if hasattr(last, "result") else last)[0]
     ops.CONV_TIMERS[:] = []
     if step_marks:
         print("per-step: GPU ms between step ends %s | host s at step ends %s" % (
@@ -418,7 +424,10 @@ def main():
                                % (a.config_name, S, S, nc, a.blocks, N, N * ws),
                    "parallelism": "dp%d" % ws, "batchnorm": "sync" if a.sync_bn else "per-rank",
                    "launch": ("one captured HIP graph per step (model.enable_step_graph); %d of the %d timed steps — the ones carrying the "
-                              "HIP-event brackets — enqueued kernel by kernel" % (eager_steps, a.steps)) if graph_obj is not None else "eager",
+                              "HIP-event brackets — enqueued kernel by kernel; %s" % (eager_steps, a.steps,
+                              "every step's scalars awaited on the host" if a.sync_scalars else
+                              "a replayed step's 23 scalars travel to pinned memory asynchronously (read behind the timed region)"))
+                             if graph_obj is not None else "eager",
                    # what torch.distributed itself reports (a SCALE record shows RCCL saw N ranks)
                    "backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else "none (single process)"),
                    "world_size_seen": (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1),

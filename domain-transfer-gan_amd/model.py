@@ -191,6 +191,23 @@ class _PendingVals(object):
         return self.finish(OrderedDict(zip(self.names, self.dev.tolist())))
 
 
+class DeferredStep(object):
+    """What `train_instance` returns under `enable_step_graph(defer_scalars=True)`: the step's reported scalars are on their way
+    to pinned host memory (an asynchronous copy enqueued behind the replay); `result()` waits for that copy and builds the
+    usual (losses, visuals[, gnorms]) — so the host can enqueue step k + 1 while step k runs and read step k's losses later
+    (the reference's loop reads them every step, train.py:198-243; a loop that logs every n-th step need not wait every step).
+    The tensors in `visuals` are the graph's static buffers: overwritten by the next step."""
+
+    def __init__(self, pending, host, event):
+        self._pending, self._host, self._event, self._out = pending, host, event, None
+
+    def result(self):
+        if self._out is None:
+            self._event.synchronize()
+            self._out = self._pending.finish(OrderedDict(zip(self._pending.names, self._host.tolist())))
+        return self._out
+
+
 class StepGraph(object):
     """train_instance captured into a HIP graph (torch.cuda.CUDAGraph drives hipStreamBeginCapture / hipGraphLaunch; the
     library's ctypes launches go to the capturing stream like torch's own kernels).  What a replay cannot take from the
@@ -201,6 +218,7 @@ class StepGraph(object):
 
     def __init__(self, model):
         self.model, self.graph, self.key, self.calls, self.ws, self.packed = model, None, None, 0, None, None
+        self.defer_scalars = False
 
     def _key(self, a, b, z):
         m = self.model
@@ -273,9 +291,16 @@ class StepGraph(object):
         self.graph.replay()
         for opt in opts:
             opt.t += 1
+        deferred = None
+        if self.defer_scalars:   # the scalars leave for pinned memory behind the replay; nobody waits here
+            host = torch.empty(self.pending.dev.shape, dtype=self.pending.dev.dtype, pin_memory=True)
+            host.copy_(self.pending.dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            deferred = DeferredStep(self.pending, host, ev)
         for net in m._nets():    # the replay updated the weights behind Python's caches (and repacked the convolutions' in place)
             mark_dirty(net, keep_packed=True)
-        return self.pending.resolve()
+        return deferred if deferred is not None else self.pending.resolve()
 
 
 class _Base(object):
@@ -336,13 +361,17 @@ class _Base(object):
             return vals
         return finish(vals)
 
-    def enable_step_graph(self, on=True):
+    def enable_step_graph(self, on=True, defer_scalars=False):
         """Run train_instance as ONE captured HIP graph per (shapes, learning rates): the whole step — about 3 000 kernel
         launches — is replayed by a single host call.  Worth it where the step is launch-bound (small images / batches:
         64 x 64 x 4 runs 28 ms eager against the 33 ms of Python it takes to enqueue); at 256 x 256 x 32 the GPU is the
         bound either way.  The first calls run eagerly (warm-up), the tensors in the returned `visuals` are overwritten by the
-        next call, and the data-parallel exchange keeps the eager path."""
+        next call, and the data-parallel exchange keeps the eager path.  defer_scalars: a replayed step returns a DeferredStep
+        (`.result()` gives the usual tuple) instead of waiting for its scalars — the host then enqueues the next step while
+        this one runs."""
         self._step_graph = StepGraph(self) if on else None
+        if self._step_graph is not None:
+            self._step_graph.defer_scalars = bool(defer_scalars)
 
     # ---- forward-only helpers shared by both models (model.py:210-280, 606-733): compositions of the two generators.
     # Subclass hooks: _z (noise transform), _cycle_code (the latent the B -> A -> B cycle is closed with).

@@ -297,6 +297,51 @@ def test_step_as_one_captured_graph_matches_the_eager_step(aug):
         assert o_r.t == o_g.t == 7
 
 
+def test_step_graph_deferred_scalars_and_interleaved_eager_steps():
+    """Round 6: (a) enable_step_graph(defer_scalars=True) — a replayed step returns a DeferredStep whose scalars travel to pinned
+    memory behind the replay; read one step late they equal the synchronous graph's, bit for bit.  (b) eager steps between
+    replays (how bench.py samples its event brackets) and replays share the layers' packed weights, which every optimiser
+    step refreshes in place: a model that alternates graph and eager steps equals one that only replays (same kernels; the
+    eager Adam forms its bias corrections on the host, hence rounding-level differences), and the graph is not re-captured."""
+    from dtgan_amd import model as M
+    meta = dict(opt=dict(input_nc=1, output_nc=1, n_blocks=2), aug=True, seed=5, flavour="init")
+    sync, lazy, mixed = build_model(meta), build_model(meta), build_model(meta)
+    sync.enable_step_graph(); lazy.enable_step_graph(defer_scalars=True); mixed.enable_step_graph()
+    g = torch.Generator(device="cuda").manual_seed(6)
+    prev, captures = None, 0
+    for step in range(8):
+        a = torch.randn(4, 1, 64, 64, device="cuda", generator=g).clamp_(-1, 1)
+        b = torch.randn(4, 1, 64, 64, device="cuda", generator=g).clamp_(-1, 1)
+        z = torch.randn(4, 16, 1, 1, device="cuda", generator=g)
+        ls, vs, gs = sync.train_instance(a, b, z)
+        out = lazy.train_instance(a, b, z)
+        if prev is not None:                     # the PREVIOUS step's deferred scalars, read while this step is in flight
+            assert prev[0].result()[0] == prev[1] and prev[0].result()[2] == prev[2]
+            prev = None
+        if isinstance(out, M.DeferredStep):
+            prev = (out, ls, gs)
+        else:                                    # the two eager warm-up calls return the tuple itself
+            assert step < 2 and out[0] == ls
+        graph_before = mixed._step_graph.graph
+        if step in (4, 6):                       # an eagerly enqueued step between replays
+            sg, mixed._step_graph = mixed._step_graph, None
+            try:
+                lm, vm, gm = mixed.train_instance(a, b, z)
+            finally:
+                mixed._step_graph = sg
+        else:
+            lm, vm, gm = mixed.train_instance(a, b, z)
+        if graph_before is not None:
+            assert mixed._step_graph.graph is graph_before, "the graph was captured again (step %d)" % step
+        lt, gt, vt = (1e-5, 1e-4, 1e-5) if step < 5 else (2e-3, 2e-2, 2e-2)
+        for k in ls:
+            assert abs(ls[k] - lm[k]) <= lt * max(1.0, abs(ls[k])), (step, k, ls[k], lm[k])
+        for k in gs:
+            assert abs(gs[k] - gm[k]) <= gt * max(1e-3, abs(gs[k])), (step, k, gs[k], gm[k])
+        assert float((vs["fake_B"] - vm["fake_B"]).abs().max()) < vt
+    assert prev is not None and prev[0].result()[0] == prev[1]
+
+
 def test_step_graph_owns_its_scratch():
     """The captured kernels keep the POINTERS of the scratch buffers ops.workspace() handed out during the capture.  An eager
     op that needs more scratch afterwards (a larger evaluation batch backpropagating through G_A_B, train.py's eval_ubo_B)
