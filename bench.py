@@ -63,7 +63,7 @@ def parse_args(argv=None):
     ap.add_argument("--sync-scalars", action="store_true",
                     help="wait for every replayed step's losses on the host (the reference's loop does, train.py:198-243) instead of "
                          "reading them one step late")
-    ap.add_argument("--timer-every", type=int, default=5, metavar="N",
+    ap.add_argument("--timer-every", type=int, default=10, metavar="N",
                     help="bracket the roofline kernels with HIP events on every N-th timed step only (0: never; the events are "
                          "barrier packets between back-to-back launches and cost the step time)")
     ap.add_argument("--sync-bn", action="store_true", help="BatchNorm statistics over all ranks (default: per rank, as the "
