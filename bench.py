@@ -454,7 +454,7 @@ def main():
                          "launches_timed": len(ms2), "avg_launch_ms": round(k2, 4), "bytes_per_launch": bytes2},
     }
     out["fused_paths"] = {"per_step": fused_paths, "note": "launches per training step that took each fused path (ops.FUSED); "
-                          "config 3 expects 66 norm_bwd_sums_from_dgrad (54 trunk + 12 full-resolution layers), 72 wgrad_s16, 18 relu bitmask links"}
+                          "config 3 expects 70 norm_bwd_sums_from_dgrad (54 trunk + 16 full-resolution layers), 72 wgrad_s16, 18 relu bitmask links"}
     if ws == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a, [x for x in argv if x != "--no-cpu-baseline"])
     print(json.dumps(out), flush=True)

@@ -1028,8 +1028,8 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
     ACG_REQUIRE(!thin_out(d), "dgrad: stride 2 with <= 4 output channels is not supported by the thin packing");
     // stride 2: four sub-pixel phases, each a dense small-tap convolution (no zero insertion)
     ACG_REQUIRE(d->pad_mode == ACG_PAD_ZERO, "dgrad: stride 2 needs zero padding");
-    ACG_REQUIRE(addend == nullptr && relu_src == nullptr && relu_mask == nullptr && !in_s16 && !out_s16 && ns == nullptr,
-                "dgrad: stride 2 takes no fused side inputs / norm sums (query acg_conv2d_bwd_data_sums_supported)");
+    ACG_REQUIRE(addend == nullptr && relu_src == nullptr && relu_mask == nullptr && !in_s16 && !out_s16, "dgrad: stride 2 takes no fused side inputs");
+    ACG_REQUIRE(ns == nullptr || acg_conv2d_bwd_data_sums_supported(d), "dgrad: norm sums on this stride-2 geometry (query acg_conv2d_bwd_data_sums_supported)");
     g.Hout = d->Hi; g.Wout = d->Wi; g.os = 2;
     auto phase_taps = [&](int py, int px, Taps &tt, int base) {
         int n = 0;
@@ -1072,10 +1072,18 @@ static int dgrad_igemm(const acg_conv_desc *d, const float *src, const float *wb
         Geom g4 = g;
         g4.nphase = 0; g4.ph_ntaps = 0;
         Taps plan;
+        if (ns != nullptr) {   // the first backward pass of the norm in front of the stride-2 convolution rides on the four-phase tile
+            g4.ns_x = ns->x; g4.ns_mean = ns->mean; g4.ns_rstd = ns->rstd; g4.ns_gamma = ns->gamma; g4.ns_beta = ns->beta;
+            g4.ns_gstride = ns->gstride; g4.ns_mask = ns->sign_mask; g4.ns_act = ns->act; g4.ns_part = ns->part;
+            ACG_REQUIRE(ns->part != nullptr && stats == nullptr && acg_igemm_ph4_ok(g4) && acg_ph4_plan(t, ntp, &plan),
+                        "dgrad: norm sums on a stride-2 data gradient need the four-phase tile (query acg_conv2d_bwd_data_sums_supported)");
+            return acg_igemm_ph4_launch(src, wb, bias, dst, g4, plan, g.w_elems, st);
+        }
         if (acg_igemm_ph4_ok(g4) && acg_ph4_plan(t, ntp, &plan)) return acg_igemm_ph4_launch(src, wb, bias, dst, g4, plan, g.w_elems, st);
         return acg_igemm_launch(src, wb, bias, dst, g, t, st);
     }
 
+    ACG_REQUIRE(ns == nullptr, "dgrad: norm sums on a stride-2 data gradient need the four-phase tile (query acg_conv2d_bwd_data_sums_supported)");
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
             g.oy0 = py; g.ox0 = px;
@@ -1324,7 +1332,12 @@ extern "C" int acg_conv2d_bwd_data_sums_supported(const acg_conv_desc *d)
 {
     if (d == nullptr || g_acg_precision != ACG_PREC_BF16X3 || g_acg_conv_impl != ACG_IMPL_MFMA || acg_debug_switch("ACG_NO_ROWS")) return 0;
     if (check_desc(d, "acg_conv2d_bwd_data_sums_supported") != ACG_OK) return 0;
-    static const bool no_tile_sums = acg_debug_switch("ACG_NO_TILE_SUMS");   // A/B switch: the two producers of round 6
+    static const bool no_tile_sums = acg_debug_switch("ACG_NO_TILE_SUMS");   // A/B switch: the three producers of round 6
+    // the four-phase tile of the stride-2 3x3 data gradient (igemm_conv_ph4<SUMS>): 64 input channels of the convolution, phase
+    // grid rows that are whole 128-pixel tiles
+    if (!no_tile_sums && !acg_debug_switch("ACG_NO_PH4_SUMS") && d->K == 3 && d->stride == 2 && d->pad == 1 && d->pad_mode != ACG_PAD_REFLECT && d->Ci == 64 &&
+        d->Co % 32 == 0 && d->Hi == 2 * d->Ho && d->Wi == 2 * d->Wo && d->Wo % 128 == 0 && !acg_debug_switch("ACG_NO_PH4") && !acg_debug_switch("ACG_NO_PHASED"))
+        return 1;
     // the 7x7 (K <= 7) stride-1 zero-padded layer with a C4 image on its output side (the head, networks.py:187-188):
     // conv_thinrow_x3's whole 8 x 16 tiles
     if (!no_tile_sums && d->stride == 1 && d->pad_mode != ACG_PAD_REFLECT && thin_out(d) && d->Co == 4 && d->Ci == 32 && d->K >= 2 && d->K <= 7 &&

@@ -15,11 +15,12 @@
 // (smallest dx of the ROW & 0xff) << 16 | (first sub-stage of its row) << 24; a tap's weight slab and phase ride in Taps.w
 // as slab | phase << 12.  Per accumulator the taps arrive in a fixed order, (dy, dx) ascending.
 //
-// (Round 6 tried the first backward pass of the norm in front of the stride-2 convolution in this kernel's epilogue — the norm
-// input x read at the pixels each phase stores, 128 more 4-byte loads per thread and tile, the next phase's requested behind
-// the current phase's sums: 0.55-0.60 ms against 0.30 ms for the plain launch, +0.27 ms where the separate norm_bwd_partial
-// pass costs 0.18 ms — with two 256-thread workgroups per CU and 238 registers in the loop nothing hides the epilogue's load
-// latency.  Dropped; DESIGN_LOG.md R6.2 has the table.  The generic tile and the thin-row kernel do carry that epilogue.)
+// SUMS (round 6; data gradient of the stride-2 convolution behind a norm + ReLU, networks.py:164-170): dx is the gradient w.r.t.
+// that norm's output, so the epilogue also leaves the first pass of the norm's backward — per-channel sum gy and sum gy * xhat,
+// gy = dx * act'(y) — for the tile's 512 pixels in g.ns_part (chunk 4 * tile; the tile's other three chunks hold zeros).  The
+// norm's input x at the 128 pixels of a phase (32 KB) travels global -> LDS by LDS-DMA into the operand buffers the loop has
+// finished with, one phase ahead: no registers (a first version read x by 128 four-byte loads per thread and tile: the loop runs
+// at 238 of 256 registers, nothing hid their latency, 0.55-0.60 ms against 0.30 ms — slower than the separate pass).
 #include "conv_internal.h"
 #include <algorithm>
 #include <cstdlib>
@@ -40,7 +41,7 @@ __device__ constexpr int kPhase[kSub][NTX] = {{0, 1, 1}, {2, 3, 3}, {2, 3, 3}};
 __device__ constexpr bool kNewRow[kSub] = {true, false, true};
 }
 
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, bool SUMS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_conv_ph4(const float *__restrict__ in, const __bf16 *__restrict__ wp,
                                                       const float *__restrict__ bias, float *__restrict__ out, Geom g,
                                                       Taps taps, unsigned in_bytes, unsigned w_bytes, unsigned w_lo_bytes)
@@ -51,10 +52,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int APL = (BM + NTX - 1) * 8, BPL = BN * 8 + 32;                  // plane strides (conv_bf16.hip)
     constexpr int A_IMG = NK8 * APL, B_IMG = NK8 * BPL;
     static_assert(WM * WN == 4 && MB >= 1 && NB >= 1, "tile config");
-    __shared__ __attribute__((aligned(16))) __bf16 As[2 * A_IMG];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[NTX * 2 * B_IMG];
+    // ONE operand array (A images, then B images): behind the loop its first 32 KB stage the norm input of a phase (SUMS)
+    constexpr int AB_ELEMS = 2 * A_IMG + NTX * 2 * B_IMG;
+    static_assert(!SUMS || AB_ELEMS * 2 >= BM * 64 * 4, "the operand buffers hold one phase of x");
+    __shared__ __attribute__((aligned(256))) __bf16 lds_ab[AB_ELEMS];
+    __bf16 *const As = lds_ab, *const Bs = lds_ab + 2 * A_IMG;
     __shared__ __attribute__((aligned(16))) unsigned out_rel[BM];
-    __shared__ float sred[WM * BN];
+    __shared__ float sred[(SUMS ? 2 : 1) * WM * BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -200,6 +204,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)(out + off0), 0, 0xFFFFFFF0u, 0x00020000);
+    // SUMS: this thread's channel (NB == 1), the norm's per-(image, channel) constants, and the LDS-DMA of a phase's x:
+    // wave w moves pieces 8 w .. 8 w + 7, a piece = 4 consecutive phase pixels x 64 channels = 1 KB (lane l: pixel l >> 4,
+    // 16 bytes at 16 (l & 15)); xs[pixel][64] fp32
+    typedef __attribute__((address_space(3))) void lds_void;
+    float ns_mu = 0.f, ns_rs = 0.f, ns_ga = 1.f, ns_be = 1.f, ns_s1 = 0.f, ns_s2 = 0.f;
+    const int ns_co = n0 + wn * TN + (lane & 31);
+    const bool ns_relu = SUMS && g.ns_act == ACG_ACT_RELU;
+    const float *const xs = (const float *)lds_ab;
+    auto ns_dma = [&](int p) {
+        if constexpr (SUMS) {
+            const __amdgpu_buffer_rsrc_t rnx = __builtin_amdgcn_make_buffer_rsrc((void *)(g.ns_x + off0), 0, 0xFFFFFFF0u, 0x00020000);
+            const unsigned poff = (unsigned)((((p >> 1) * g.Wout + (p & 1)) * g.Cout) * 4);
+            const int w0 = __builtin_amdgcn_readfirstlane(wave) * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned voff = (unsigned)((4 * (w0 + k) + (lane >> 4)) * 2 * g.Cout * 4 + (lane & 15) * 16);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rnx, (lds_void *)((char *)lds_ab + (w0 + k) * 1024), 16, voff, poff, 0, 0);
+            }
+        }
+    };
+    if constexpr (SUMS) {
+        static_assert(!SUMS || (NB == 1 && BN == 64), "SUMS: one 32-channel block per wave, 64 stored channels");
+        if (ns_co < g.Cout) {
+            ns_mu = g.ns_mean[img * g.Cout + ns_co];
+            ns_rs = g.ns_rstd[img * g.Cout + ns_co];
+            if (ns_relu) { ns_ga = g.ns_gamma[g.ns_gstride * img + ns_co]; ns_be = g.ns_beta[g.ns_gstride * img + ns_co]; }
+        }
+        __syncthreads();   // every wave has read its last fragments: the operand buffers are free
+        ns_dma(0);
+    }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         __builtin_amdgcn_sched_barrier(0);   // one phase's accumulators in VGPRs at a time (two waves per SIMD: 256 registers)
@@ -243,6 +277,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         const unsigned poff = (unsigned)((((p >> 1) * g.Wout + (p & 1)) * g.Cout) * 4);
+        if constexpr (SUMS) {   // (bias == nullptr, act == NONE by contract: the stored value is the accumulator)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of phase p (and the previous phase's stores)
+            __syncthreads();                                   // ... and everybody else's
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * TM + i * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                    const float xh = (xs[row * 64 + ns_co] - ns_mu) * ns_rs;
+                    const float gy = (ns_relu && !(xh * ns_ga + ns_be > 0.f)) ? 0.f : acc[p][i][0][r];   // same expression as norm_apply_kernel
+                    ns_s1 += gy;
+                    ns_s2 += gy * xh;
+                }
+            __syncthreads();                                   // phase p is read: the stage is free
+            if (p < 3) ns_dma(p + 1);                          // in flight behind this phase's stores
+        }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int co = n0 + wn * TN + j * 32 + (lane & 31);
@@ -267,6 +317,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                 }
             }
+    }
+    if constexpr (SUMS) {   // 32 rows x 4 phases per thread -> the two lane halves -> the WM waves of a column block, fixed order
+        ns_s1 += __shfl_xor(ns_s1, 32);
+        ns_s2 += __shfl_xor(ns_s2, 32);
+        if (lane < 32) {
+            sred[wm * BN + wn * TN + lane] = ns_s1;
+            sred[WM * BN + wm * BN + wn * TN + lane] = ns_s2;
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < g.Cout) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { a += sred[w * BN + tid]; b += sred[WM * BN + w * BN + tid]; }
+            // part[N][4 * GHW / BM chunks][2][Cout]: this tile's four 128-pixel chunks are 4 * t .. 4 * t + 3
+            const long long tpi = (long long)GHW / BM, t = (m0 / BM) % tpi;
+            float *o = g.ns_part + (((long long)img * 4 * tpi + 4 * t) * 2) * g.Cout + n0 + tid;
+            o[0] = a;
+            o[g.Cout] = b;
+#pragma unroll
+            for (int k = 1; k < 4; ++k) { o[(long long)k * 2 * g.Cout] = 0.f; o[(long long)k * 2 * g.Cout + g.Cout] = 0.f; }
+        }
     }
 }
 
@@ -341,6 +412,17 @@ int acg_igemm_ph4_launch(const float *in, const void *wp, const float *bias, flo
     ACG_REQUIRE(g.stats == nullptr || (((long long)g.GH * g.GW) % BM == 0 && g.act == ACG_ACT_NONE),
                 "igemm_conv_ph4: per-tile statistics need whole tiles per image and no activation");
     dim3 grid((unsigned)(g.Mtot / BM) * (g.ncols_pad / 64));
+    if (g.ns_part != nullptr) {
+        ACG_REQUIRE(g.stats == nullptr && bias == nullptr && g.act == ACG_ACT_NONE && g.ns_x != nullptr && g.ns_mean != nullptr && g.ns_rstd != nullptr &&
+                    g.ns_mask == nullptr && (g.ns_act == ACG_ACT_NONE || (g.ns_act == ACG_ACT_RELU && g.ns_gamma != nullptr && g.ns_beta != nullptr)) &&
+                    (g.ns_gstride == 0 || g.ns_gstride >= g.Cout) && ((long long)g.GH * g.GW) % BM == 0 && g.ncols_pad == 64 && g.Cout == 64,
+                    "igemm_conv_ph4: the norm sums ride on a plain data gradient with 64 stored channels (no bias / activation / statistics; act NONE / RELU recomputed from x)");
+        hipLaunchKernelGGL((igemm_conv_ph4<64, 2, 2, true>), grid, dim3(256), 0, st, in, (const __bf16 *)wp, bias, out, g, tp, (unsigned)in_bytes,
+                           (unsigned)w_bytes, (unsigned)(n_w_elems * 2));
+        ACG_CHECK_LAUNCH("igemm_conv_ph4<SUMS>");
+        acg_note_kernel("igemm_conv_ph4<128,64,SUMS=1> (%d sub-stages)", plan.ngrp);
+        return ACG_OK;
+    }
     hipLaunchKernelGGL((igemm_conv_ph4<64, 2, 2>), grid, dim3(256), 0, st, in, (const __bf16 *)wp, bias, out, g, tp, (unsigned)in_bytes,
                        (unsigned)w_bytes, (unsigned)(n_w_elems * 2));
     ACG_CHECK_LAUNCH("igemm_conv_ph4");

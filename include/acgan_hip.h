@@ -186,8 +186,8 @@ int acg_conv2d_bwd_data_s16_sums(const acg_conv_desc *d, const void *dy_s16, con
                                  size_t ws_bytes, const float *addend, const unsigned *addend_sign_mask,
                                  const acg_norm_sums *ns, void *stream);
 /* ... and on fp32 operands: the persistent row pipeline (zero-padded 3x3 stride 1, Co == 32, Ci == 64, Wi % 128 == 0), and
- * from round 6 the generic row-patch tile (3x3 stride 1, Ci == 32, Co == 64, Wi % 128 == 0) and the thin-row kernel of the 7x7
- * head (Ci == 32, a C4 image on the output side, Hi % 8 == 0, Wi % 16 == 0).  ns->sign_mask must be NULL (the activation
+ * from round 6 the generic row-patch tile (3x3 stride 1, Ci == 32, Co == 64, Wi % 128 == 0), the four-phase tile of the stride-2
+ * 3x3 layer (Ci == 64, Wo % 128 == 0) and the thin-row kernel of the 7x7 head (Ci == 32, a C4 image on the output side, Hi % 8 == 0, Wi % 16 == 0).  ns->sign_mask must be NULL (the activation
  * mask is recomputed from ns->x); part[N][Hi * Wi / 128][2][Ci], every entry written. */
 int acg_conv2d_bwd_data_sums_supported(const acg_conv_desc *d);
 int acg_conv2d_bwd_data_sums(const acg_conv_desc *d, const float *dy, const float *wb, float *dx, void *ws, size_t ws_bytes,

@@ -247,15 +247,15 @@ def test_config3_step_takes_the_fused_paths():
     """The hand-off protocols between autograd nodes (ops.ConvStats / SkipGrad / ReluLink / NormSums, the S16 plan) fall back
     silently when a tensor identity does not match: the step of configs[2] must take every fused path the bench line reports
     (`fused_paths`) — counts per step, independent of the batch (here 4; 2 generators x 2 passes x 9 blocks x 2 convolutions = 72 trunk
-    convolutions; 54 of their data gradients feed a norm backward, 18 a ReLU bitmask link; three of the four norms of a generator pass that
-    sit in front of a full-resolution convolution — the stem's, the one behind the ConvTranspose, the one in front of the head — take
-    their sums from that convolution's fp32-operand data gradient: 4 x 3 = 12, round 6 (round 5: the row pipeline's 4; the
-    stride-2 layer's four-phase tile measured slower with that epilogue than the separate pass, DESIGN_LOG.md R6.2))."""
+    convolutions; 54 of their data gradients feed a norm backward, 18 a ReLU bitmask link; the four norms of a generator pass that
+    sit in front of a full-resolution convolution — the stem's, the one in front of the stride-2 layer, the one behind the
+    ConvTranspose, the one in front of the head — take their sums from that convolution's fp32-operand data gradient:
+    4 x 4 = 16, round 6 (round 5: the row pipeline's 4))."""
     from dtgan_amd import ops
     ops.FUSED.clear()
     _run_cfg(dict(FULL), 256, 4, "bf16x3", seed=0, in_seed=91)
     want = {"conv_fwd_s16": 54, "conv_fwd_s16_relu_bitmask": 18, "wgrad_s16": 72, "dgrad_s16_norm_sums": 54,
-            "dgrad_s16_relu_bitmask": 18, "dgrad_s16_lazy_skip": 36, "norm_bwd_sums_from_dgrad": 66, "dgrad_f32_norm_sums": 12,
+            "dgrad_s16_relu_bitmask": 18, "dgrad_s16_lazy_skip": 36, "norm_bwd_sums_from_dgrad": 70, "dgrad_f32_norm_sums": 16,
             "norm_bwd_sign_bitmask": 36,
             "norm_stats_from_conv_epilogue": 86, "conv_fwd_tile_stats": 28}
     got = {k: ops.FUSED.get(k, 0) for k in want}

@@ -470,6 +470,133 @@ def test_row_pipeline_data_gradient_sums_match_the_oracle(case):
 
 
 @pytest.mark.parametrize("case", ["relu_shared", "relu_per_sample", "none_shared"])
+def test_stride2_data_gradient_sums_match_the_oracle(case):
+    """acg_conv2d_bwd_data_sums on the stride-2 3x3 layer (igemm_conv_ph4<SUMS>, x staged through LDS-DMA, round 6: the data gradient of networks.py:168 is
+    the gradient w.r.t. the output of the norm at networks.py:165-166) through the C ABI at N = 2, 64 -> 128 channels, 8 x 256
+    -> 4 x 128: the data gradient against the oracle's convolution adjoint (2e-5), and S1 = sum gy, S2 = sum gy * xhat of that
+    norm against fp64 (1e-4) with `part` pre-filled with NaN (every chunk entry has to be written — the tile's sums sit in its
+    first chunk, the other three hold zeros), ReLU and no activation, shared and per-sample affine parameters."""
+    import ctypes
+    from dtgan_amd import ops, _lib
+    from hip_util import precision, t, n, rel
+    P = ops._ptr
+    N, H, W, Ci, Co = 2, 8, 256, 64, 128
+    rs = np.random.RandomState(13)
+    w = rs.normal(0, 0.05, (Co, Ci, 3, 3))
+    dy = rs.normal(0, 1e-2, (N, Co, H // 2, W // 2))
+    xn = rs.normal(0.2, 1.1, (N, Ci, H, W))
+    mean = rs.normal(0.2, 0.1, (N, Ci)); rstd = rs.uniform(0.6, 1.4, (N, Ci))
+    per_sample = case == "relu_per_sample"
+    act = ops.ACT_NONE if case == "none_shared" else ops.ACT_RELU
+    gamma = rs.normal(1.0, 0.4, (N if per_sample else 1, Ci)); beta = rs.normal(0.0, 0.5, (N if per_sample else 1, Ci))
+    nhwc = lambda a: np.ascontiguousarray(np.transpose(a, (0, 2, 3, 1)))
+    nchw = lambda a: np.transpose(a, (0, 3, 1, 2))
+    with precision("bf16x3"):
+        st = ops._stream()
+        d = ops.conv_desc(N, H, W, Ci, Co, 3, 2, 1, 0, Ci, Co)
+        D = ctypes.byref(d)
+        assert _lib.query("acg_conv2d_bwd_data_sums_supported", D)
+        pk = ops.PackedConv(t(w), t(np.zeros(Co)), Ci, Co)
+        X, Wt = leaf(np.zeros((N, Ci, H, W))), leaf(w)
+        backward(oops.conv2d(X, Wt, None, stride=2, pad=1), seed=dy.astype(np.float32).astype(np.float64))
+        xh = (xn.astype(np.float32).astype(np.float64) - mean[:, :, None, None]) * rstd[:, :, None, None]
+        g_b = np.broadcast_to(gamma, (N, Ci))[:, :, None, None]; b_b = np.broadcast_to(beta, (N, Ci))[:, :, None, None]
+        live = (xh * g_b + b_b > 0) if act == ops.ACT_RELU else np.ones_like(xh, dtype=bool)
+        edge = (np.abs(xh * g_b + b_b) < 1e-5) if act == ops.ACT_RELU else np.zeros_like(live)
+        gy = X.g * live
+        nbw = _lib.query("acg_conv2d_bwd_data_workspace_bytes", D)
+        ws = ops.workspace(max(nbw, 1))
+        dx = torch.full((N, H, W, Ci), float("nan"), device="cuda")
+        psum = torch.full((N, H * W // 128, 2, Ci), float("nan"), device="cuda")
+        ns = _lib.NormSumsDesc()
+        xn_t, mean_t, rstd_t, g_t, b_t = t(nhwc(xn)), t(mean.reshape(-1)), t(rstd.reshape(-1)), t(gamma.reshape(-1)), t(beta.reshape(-1))
+        ns.x, ns.mean, ns.rstd, ns.gamma, ns.beta = P(xn_t), P(mean_t), P(rstd_t), P(g_t), P(b_t)
+        ns.gstride, ns.sign_mask, ns.act, ns.part = (Ci if per_sample else 0), None, act, P(psum)
+        _lib.call("acg_conv2d_bwd_data_sums", D, P(t(nhwc(dy))), P(pk.wb), P(dx), P(ws), nbw, ctypes.byref(ns), st)
+        assert _lib.query("acg_last_kernel").decode().startswith("igemm_conv_ph4<128,64,SUMS=1>")
+        assert rel(nchw(n(dx)), X.g) < 2e-5, "data gradient"
+        dx0 = torch.full_like(dx, float("nan"))                  # the plain entry point: the same dx, bit for bit
+        _lib.call("acg_conv2d_bwd_data", D, P(t(nhwc(dy))), P(pk.wb), P(dx0), P(ws), nbw, st)
+        assert _lib.query("acg_last_kernel").decode().startswith("igemm_conv_ph4<128,64> ")
+        assert torch.equal(dx0, dx)
+        got = n(psum)
+        assert np.isfinite(got).all(), "a chunk entry of the sums was not written"
+        s1, s2 = got[:, :, 0].sum(1), got[:, :, 1].sum(1)
+        assert edge.mean() < 1e-4
+        gy_k = nchw(n(dx)).astype(np.float64) * live
+        assert rel(s1, gy_k.sum((2, 3))) < 1e-4 and rel(s2, (gy_k * xh).sum((2, 3))) < 1e-4, "norm backward sums (kernel dx)"
+        assert rel(s1, gy.sum((2, 3))) < 2e-4 and rel(s2, (gy * xh).sum((2, 3))) < 2e-4, "norm backward sums (oracle dx)"
+
+
+@pytest.mark.parametrize("case", ["relu_shared", "relu_per_sample", "none_shared"])
+@pytest.mark.parametrize("layer", ["a2_generic_tile", "head_thinrow"])
+def test_tile_data_gradient_sums_match_the_oracle(layer, case):
+    """acg_conv2d_bwd_data_sums on the two remaining producers of round 6 — the generic 128-pixel tile (data gradient of the
+    3x3 32 -> 64 layer, networks.py:164, the gradient w.r.t. the stem's norm output) and conv_thinrow_x3 (data gradient of the
+    7x7 head, networks.py:187-188, w.r.t. the last norm's output) — through the C ABI at N = 2: dx against the oracle's
+    convolution adjoint (2e-5) and bit-equal to the plain entry point's, S1 / S2 against fp64 (1e-4) with `part` pre-filled
+    with NaN, ReLU and no activation, shared and per-sample affine parameters."""
+    import ctypes
+    from dtgan_amd import ops, _lib
+    from hip_util import precision, t, n, rel
+    P = ops._ptr
+    if layer == "a2_generic_tile":
+        N, H, W, Ci, Co, K, pad, Cis, Cos, kern = 2, 12, 128, 32, 64, 3, 1, 32, 64, "igemm_conv_bf16<128,32,"
+    else:   # the head: 32 -> 3 channels, the image side stored C4
+        N, H, W, Ci, Co, K, pad, Cis, Cos, kern = 2, 16, 48, 32, 3, 7, 3, 32, 4, "conv_thinrow_x3<REFLECT=0,SUMS=1>"
+    rs = np.random.RandomState(17)
+    w = rs.normal(0, 0.05, (Co, Ci, K, K))
+    dy = rs.normal(0, 1e-2, (N, Co, H, W))
+    xn = rs.normal(0.2, 1.1, (N, Ci, H, W))
+    mean = rs.normal(0.2, 0.1, (N, Ci)); rstd = rs.uniform(0.6, 1.4, (N, Ci))
+    per_sample = case == "relu_per_sample"
+    act = ops.ACT_NONE if case == "none_shared" else ops.ACT_RELU
+    gamma = rs.normal(1.0, 0.4, (N if per_sample else 1, Ci)); beta = rs.normal(0.0, 0.5, (N if per_sample else 1, Ci))
+    nchw = lambda a: np.transpose(a, (0, 3, 1, 2))
+
+    def nhwc(a, Cp):
+        out = np.zeros((a.shape[0], a.shape[2], a.shape[3], Cp), np.float32)
+        out[..., :a.shape[1]] = np.transpose(a, (0, 2, 3, 1))
+        return out
+    with precision("bf16x3"):
+        st = ops._stream()
+        d = ops.conv_desc(N, H, W, Cis, Cos, K, 1, pad, 0, Ci, Co)
+        D = ctypes.byref(d)
+        assert _lib.query("acg_conv2d_bwd_data_sums_supported", D)
+        pk = ops.PackedConv(t(w), t(np.zeros(Co)), ops.cpad(Ci), ops.cpad(Co))   # (packed widths; the stored ones: pk.Cis / pk.Cos)
+        assert (pk.Cis, pk.Cos) == (Cis, Cos)
+        X, Wt = leaf(np.zeros((N, Ci, H, W))), leaf(w)
+        backward(oops.conv2d(X, Wt, None, pad=pad), seed=dy.astype(np.float32).astype(np.float64))
+        xh = (xn.astype(np.float32).astype(np.float64) - mean[:, :, None, None]) * rstd[:, :, None, None]
+        g_b = np.broadcast_to(gamma, (N, Ci))[:, :, None, None]; b_b = np.broadcast_to(beta, (N, Ci))[:, :, None, None]
+        live = (xh * g_b + b_b > 0) if act == ops.ACT_RELU else np.ones_like(xh, dtype=bool)
+        edge = (np.abs(xh * g_b + b_b) < 1e-5) if act == ops.ACT_RELU else np.zeros_like(live)
+        gy = X.g * live
+        nbw = _lib.query("acg_conv2d_bwd_data_workspace_bytes", D)
+        ws = ops.workspace(max(nbw, 1))
+        dx = torch.full((N, H, W, Cis), float("nan"), device="cuda")
+        psum = torch.full((N, H * W // 128, 2, Cis), float("nan"), device="cuda")
+        ns = _lib.NormSumsDesc()
+        xn_t, mean_t, rstd_t, g_t, b_t = t(nhwc(xn, Cis)), t(mean.reshape(-1)), t(rstd.reshape(-1)), t(gamma.reshape(-1)), t(beta.reshape(-1))
+        dy_t = t(nhwc(dy, Cos))
+        ns.x, ns.mean, ns.rstd, ns.gamma, ns.beta = P(xn_t), P(mean_t), P(rstd_t), P(g_t), P(b_t)
+        ns.gstride, ns.sign_mask, ns.act, ns.part = (Ci if per_sample else 0), None, act, P(psum)
+        _lib.call("acg_conv2d_bwd_data_sums", D, P(dy_t), P(pk.wb), P(dx), P(ws), nbw, ctypes.byref(ns), st)
+        assert _lib.query("acg_last_kernel").decode().startswith(kern), _lib.query("acg_last_kernel")
+        assert rel(nchw(n(dx)), X.g) < 2e-5, "data gradient"
+        dx0 = torch.full_like(dx, float("nan"))
+        _lib.call("acg_conv2d_bwd_data", D, P(dy_t), P(pk.wb), P(dx0), P(ws), nbw, st)
+        assert torch.equal(dx0, dx), "the sums epilogue must not change dx"
+        got = n(psum)
+        assert np.isfinite(got).all(), "a chunk entry of the sums was not written"
+        s1, s2 = got[:, :, 0].sum(1), got[:, :, 1].sum(1)
+        assert edge.mean() < 1e-4
+        gy_k = nchw(n(dx)).astype(np.float64) * live
+        assert rel(s1, gy_k.sum((2, 3))) < 1e-4 and rel(s2, (gy_k * xh).sum((2, 3))) < 1e-4, "norm backward sums (kernel dx)"
+        assert rel(s1, gy.sum((2, 3))) < 2e-4 and rel(s2, (gy * xh).sum((2, 3))) < 2e-4, "norm backward sums (oracle dx)"
+
+
+@pytest.mark.parametrize("case", ["relu_shared", "relu_per_sample", "none_shared"])
 @pytest.mark.parametrize("layer", ["a2_generic_tile", "head_thinrow"])
 def test_tile_data_gradient_sums_match_the_oracle(layer, case):
     """acg_conv2d_bwd_data_sums on the two remaining producers of round 6 — the generic 128-pixel tile (data gradient of the

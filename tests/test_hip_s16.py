@@ -120,11 +120,11 @@ def test_norm_backward_sums_from_the_data_gradient_epilogue(kind):
                 ops.NORM_SUMS = old
             used = ops.NORM_SUMS_USED - used0
             # the norm in front of the first block + per block: its output norm (all but the last block's) and, in a
-            # CINResnetBlock, the conditional norm between its two convolutions; + the three norms in front of a full-resolution
+            # CINResnetBlock, the conditional norm between its two convolutions; + the four norms in front of a full-resolution
             # convolution whose fp32-operand data gradient carries the sums (acg_conv2d_bwd_data_sums): the stem's (generic tile
-            # of the 32 -> 64 layer, round 6), the one behind the ConvTranspose (row pipeline), the one in front of the head
-            # (thin-row kernel, round 6)
-            assert used == ((1 + 2 + 3 + 3 if kind == "cin" else 1 + 2 + 3) if fused else 0), used
+            # of the 32 -> 64 layer), the one in front of the stride-2 layer (four-phase tile), the one behind the ConvTranspose
+            # (row pipeline), the one in front of the head (thin-row kernel) — all but the row pipeline's from round 6
+            assert used == ((1 + 2 + 3 + 4 if kind == "cin" else 1 + 2 + 4) if fused else 0), used
             res[fused] = (y.detach(), x.grad.detach(), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
     ya, ga, pa = res[True]
     yb, gb, pb = res[False]

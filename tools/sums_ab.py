@@ -78,6 +78,7 @@ def main():
     a = ap.parse_args()
     ops.set_precision("bf16x3")
     N, S = a.batch, a.size
+    layer("a3 3x3 s2 64->128 dgrad", N, S, S, 64, 128, 3, 2, 1, 64, 128, a.iters)
     layer("a2 3x3 32->64 dgrad", N, S, S, 32, 64, 3, 1, 1, 32, 64, a.iters)
     layer("a8 7x7 32->3 dgrad", N, S, S, 32, 3, 7, 1, 3, 32, 3, a.iters)
     layer("a7 3x3 64->32 dgrad (rows)", N, S, S, 64, 32, 3, 1, 1, 64, 32, a.iters)
