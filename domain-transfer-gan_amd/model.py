@@ -253,11 +253,20 @@ class StepGraph(object):
         m._capturing = True
         for opt in opts:
             opt.dev_step = True
+        # Python's cyclic collector must not run inside the capture: what it finds may own device objects of an EARLIER graph
+        # (another model's StepGraph in a reference cycle: its hipGraph and private pool), and destroying those while a stream is
+        # capturing is an error raised in a destructor, i.e. an abort.  torch.cuda.graph() collects once before it starts.
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.collect()
+        gc.disable()
         try:
             with torch.cuda.graph(graph), _in_train_step():
                 pending = m._train_instance(*inputs)
             graph_ws = ops._WS
         finally:
+            if gc_was_on:
+                gc.enable()
             ops._WS = eager_ws
             m._capturing = False
             for opt, t in zip(opts, t_before):     # the capture ran clip_and_step's host side without executing it
